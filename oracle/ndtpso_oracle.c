@@ -1,0 +1,548 @@
+/*
+ * ndtpso_oracle.c -- CPU restatement (plain C99, fp64) of the reference
+ * NDT-PSO scan-alignment path.  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED
+ * (see ndtpso_oracle.h for what that means and why).
+ *
+ * Build with -ffp-contract=off: the reference is built -O3 for baseline
+ * x86-64 (CMakeLists.txt:5-9, no -march), i.e. every fp operation is rounded
+ * separately; no fused multiply-add anywhere.
+ *
+ * Citations are file:line in the reference repository.
+ */
+#include "ndtpso_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ */
+/* small containers                                                    */
+
+typedef struct { double x, y; } v2;
+typedef struct { v2 *p; unsigned n, cap; } v2vec;
+
+static void v2vec_push(v2vec *v, v2 q) {
+  if (v->n == v->cap) {
+    v->cap = v->cap ? 2 * v->cap : 8;
+    v->p = (v2 *)realloc(v->p, v->cap * sizeof(v2));
+  }
+  v->p[v->n++] = q;
+}
+
+/* NDTCell, include/ndtpso_slam/ndtcell.h:63-81 */
+typedef struct {
+  v2 partial_sums[ORC_NDT_WINDOW_SIZE], current_partial_sum, global_sum;
+  double partial_covars[ORC_NDT_WINDOW_SIZE][4], global_covar_sum[4], inv_covar[4];
+  int partial_counts[ORC_NDT_WINDOW_SIZE], current_count, global_count;
+  size_t current_window_id;
+  v2vec points[ORC_NDT_WINDOW_SIZE];
+  v2 mean;
+  int built, created;
+} orc_cell;
+
+struct orc_frame {
+  double trans[3], prev_pose[3], pose_diff[3]; /* ndtframe.h:14-15 */
+  double x_min, x_max, y_min, y_max;           /* ndtframe.h:18 */
+  float laser_ignore_epsilon;                  /* config.h:44 */
+  int iter;                                    /* ndtframe.h:20 */
+  uint16_t width, height, wcells, hcells;      /* ndtframe.h:32 */
+  unsigned num_cells;
+  double cell_side;
+  int built;
+  orc_cell **cells; /* dense grid of lazily allocated cells (the reference allocates all, ndtframe.cpp:30) */
+};
+
+void orc_pso_config_default(orc_pso_config *c) {
+  /* config.h:20-25,27-38 */
+  c->iterations = 50;
+  c->population = 30;
+  c->num_threads = -1;
+  c->w = .8;
+  c->c1 = 2.;
+  c->c2 = 2.;
+  c->w_damping = 1.;
+}
+
+size_t orc_pso_rand_draws(const orc_pso_config *c) {
+  /* core.cpp:14 (3 per Particle, 1+P particles) and core.cpp:84 (2 per k, 3 k per particle per iteration) */
+  return 3u + 3u * (size_t)c->population + 6u * (size_t)c->population * (size_t)c->iterations;
+}
+
+/* ------------------------------------------------------------------ */
+/* glibc rand(): TYPE_3 additive feedback, degree 31, separation 3     */
+
+void orc_glibc_rand_fill(uint32_t seed, int32_t *out, size_t n) {
+  uint32_t st[31];
+  int32_t word;
+  int i, f = 3, r = 0;
+  size_t k;
+  if (seed == 0) seed = 1;
+  word = (int32_t)seed;
+  st[0] = (uint32_t)word;
+  for (i = 1; i < 31; ++i) {
+    /* 16807 * word mod (2^31 - 1) without overflow (Schrage) */
+    long hi = word / 127773, lo = word % 127773;
+    long t = 16807 * lo - 2836 * hi;
+    if (t < 0) t += 2147483647;
+    word = (int32_t)t;
+    st[i] = (uint32_t)word;
+  }
+  for (k = 0; k < 310 + n; ++k) {
+    uint32_t val;
+    st[f] += st[r];
+    val = st[f] >> 1;
+    if (++f == 31) f = 0;
+    if (++r == 31) r = 0;
+    if (k >= 310) out[k - 310] = (int32_t)val;
+  }
+}
+
+static int orc_draw_raw(orc_rand *g) {
+  if (g && g->table) {
+    int v = (g->cursor < g->n) ? g->table[g->cursor] : 0;
+    g->cursor++;
+    return v;
+  }
+  if (g) g->cursor++;
+  return rand();
+}
+
+/* Eigen DenseBase::Random() coefficient for double: x + (y-x)*double(rand())/double(RAND_MAX), x=-1, y=1 */
+static double orc_uniform_pm1(orc_rand *g) {
+  return -1.0 + (2.0 * (double)orc_draw_raw(g)) / (double)2147483647;
+}
+
+/* ------------------------------------------------------------------ */
+/* NDTCell                                                             */
+
+static orc_cell *cell_new(void) {
+  /* NDTCell::NDTCell, ndtcell.cpp:5-19: all window accumulators zero */
+  return (orc_cell *)calloc(1, sizeof(orc_cell));
+}
+
+static void cell_free(orc_cell *c) {
+  int i;
+  if (!c) return;
+  for (i = 0; i < ORC_NDT_WINDOW_SIZE; ++i) free(c->points[i].p);
+  free(c);
+}
+
+/* NDTCell::addPoint, ndtcell.cpp:21-34 */
+static void cell_add_point(orc_cell *c, v2 p) {
+  if (0 == c->current_count) c->points[c->current_window_id].n = 0;
+  c->current_count++;
+  c->current_partial_sum.x += p.x;
+  c->current_partial_sum.y += p.y;
+  v2vec_push(&c->points[c->current_window_id], p);
+  c->created = 1;
+  c->built = 0;
+}
+
+/* NDTCell::s_calc_covar_inverse, ndtcell.cpp:93-111 */
+static void cell_calc_covar_inverse(orc_cell *c) {
+  double n = (double)c->global_count;
+  double c00 = c->global_covar_sum[0] / n, c01 = c->global_covar_sum[1] / n;
+  double c10 = c->global_covar_sum[2] / n, c11 = c->global_covar_sum[3] / n;
+  /* eigenvalues of the (symmetric) 2x2, closed form; EigenSolver in the reference (ndtcell.cpp:96-97) */
+  double hp = 0.5 * (c00 - c11);
+  double q = sqrt(hp * hp + c01 * c10);
+  double mid = 0.5 * (c00 + c11);
+  double e0 = mid + q, e1 = mid - q;
+  double large_val = (e0 > e1) ? e0 : e1; /* ndtcell.cpp:100 */
+  double small_val = (e0 < e1) ? e0 : e1; /* ndtcell.cpp:101 */
+  double det;
+  if (small_val < .001 * large_val)
+    det = .001 * large_val * large_val; /* ndtcell.cpp:103-105 */
+  else
+    det = c00 * c11 - c10 * c01; /* Matrix2d::determinant(), ndtcell.cpp:107 */
+  c->inv_covar[0] = c11 / det;  /* ndtcell.cpp:109-110 */
+  c->inv_covar[1] = -c01 / det;
+  c->inv_covar[2] = -c10 / det;
+  c->inv_covar[3] = c00 / det;
+}
+
+/* NDTCell::build, ndtcell.cpp:36-68 */
+static int cell_build(orc_cell *c) {
+  size_t id = c->current_window_id;
+  unsigned i;
+  /* WINDOW_ADD (ndtcell.h:13-15): global = (global + partial) - partials[idx]; partials[idx] = partial */
+  c->global_sum.x = (c->global_sum.x + c->current_partial_sum.x) - c->partial_sums[id].x;
+  c->global_sum.y = (c->global_sum.y + c->current_partial_sum.y) - c->partial_sums[id].y;
+  c->partial_sums[id] = c->current_partial_sum;
+  c->global_count = (c->global_count + c->current_count) - c->partial_counts[id];
+  c->partial_counts[id] = c->current_count;
+
+  if (c->global_count > 2) {
+    double cov[4] = {0., 0., 0., 0.};
+    int k;
+    c->mean.x = c->global_sum.x / (double)c->global_count; /* ndtcell.cpp:44 */
+    c->mean.y = c->global_sum.y / (double)c->global_count;
+    for (i = 0; i < c->points[id].n; ++i) { /* ndtcell.cpp:49-52 */
+      double d0 = c->points[id].p[i].x - c->mean.x;
+      double d1 = c->points[id].p[i].y - c->mean.y;
+      cov[0] += d0 * d0;
+      cov[1] += d0 * d1;
+      cov[2] += d1 * d0;
+      cov[3] += d1 * d1;
+    }
+    for (k = 0; k < 4; ++k) { /* ndtcell.cpp:54-55 */
+      c->global_covar_sum[k] = (c->global_covar_sum[k] + cov[k]) - c->partial_covars[id][k];
+      c->partial_covars[id][k] = cov[k];
+    }
+    cell_calc_covar_inverse(c); /* ndtcell.cpp:57 */
+    c->built = 1;
+  }
+
+  if (c->current_count > ORC_NDT_MAX_POINTS_PER_CELL) { /* ndtcell.cpp:61-65 */
+    c->current_window_id = (c->current_window_id + 1) % ORC_NDT_WINDOW_SIZE;
+    c->current_count = 0;
+    c->current_partial_sum.x = 0.;
+    c->current_partial_sum.y = 0.;
+  }
+  return c->built;
+}
+
+/* NDTCell::normalDistribution, ndtcell.cpp:70-78 */
+static double cell_normal_distribution(const orc_cell *c, double px, double py) {
+  if (c->built) {
+    double d0 = px - c->mean.x, d1 = py - c->mean.y;
+    /* (diff^T * inv) * diff: row vector first, then inner product */
+    double r0 = d0 * c->inv_covar[0] + d1 * c->inv_covar[2];
+    double r1 = d0 * c->inv_covar[1] + d1 * c->inv_covar[3];
+    return exp(-(r0 * d0 + r1 * d1) / 2.);
+  }
+  return 0.;
+}
+
+/* ------------------------------------------------------------------ */
+/* NDTFrame                                                            */
+
+orc_frame *orc_frame_create(const double trans[3], unsigned short width, unsigned short height,
+                            double cell_side, float laser_ignore_epsilon) {
+  orc_frame *f = (orc_frame *)calloc(1, sizeof(orc_frame));
+  memcpy(f->trans, trans, sizeof(f->trans));
+  f->laser_ignore_epsilon = laser_ignore_epsilon;
+  f->width = width;
+  f->height = height;
+  f->cell_side = cell_side;
+  f->built = 0;
+  f->wcells = (uint16_t)ceil(width / cell_side);  /* ndtframe.cpp:27 */
+  f->hcells = (uint16_t)ceil(height / cell_side); /* ndtframe.cpp:28 */
+  f->num_cells = (unsigned)f->wcells * (unsigned)f->hcells;
+  f->cells = (orc_cell **)calloc(f->num_cells ? f->num_cells : 1, sizeof(orc_cell *));
+  f->x_min = -width / 2.; /* ndtframe.cpp:57-65 */
+  f->x_max = width / 2.;
+  f->y_min = -height / 2.;
+  f->y_max = height / 2.;
+  return f;
+}
+
+void orc_frame_destroy(orc_frame *f) {
+  unsigned i;
+  if (!f) return;
+  for (i = 0; i < f->num_cells; ++i) cell_free(f->cells[i]);
+  free(f->cells);
+  free(f);
+}
+
+void orc_frame_set_trans(orc_frame *f, const double trans[3]) { memcpy(f->trans, trans, sizeof(f->trans)); }
+
+void orc_frame_dims(const orc_frame *f, int32_t *wc, int32_t *hc) {
+  *wc = f->wcells;
+  *hc = f->hcells;
+}
+
+/* NDTFrame::getCellIndex, ndtframe.cpp:240-249 */
+int orc_frame_get_cell_index(const orc_frame *f, double x, double y) {
+  if ((x > f->x_min) && (x < f->x_max) && (y > f->y_min) && (y < f->y_max)) {
+    return (int)(floor((x + (f->width / 2.)) / f->cell_side) +
+                 (int)f->wcells * (floor((y + (f->height / 2.)) / f->cell_side)));
+  }
+  return -1;
+}
+
+/* transform_point, core.h:28-31 (cos/sin of the same argument hoisted by the caller: same values) */
+static v2 transform_point_cs(v2 p, double c, double s, double tx, double ty) {
+  v2 q;
+  q.x = p.x * c - p.y * s + tx;
+  q.y = p.x * s + p.y * c + ty;
+  return q;
+}
+
+void orc_frame_add_point(orc_frame *f, double x, double y) {
+  int idx = orc_frame_get_cell_index(f, x, y);
+  /* idx >= num_cells is reachable in the reference only when fl(y + h/2) == h (undefined
+     behaviour there: out-of-range vector access); dropped here. */
+  if (-1 != idx && idx >= 0 && (unsigned)idx < f->num_cells) {
+    v2 p;
+    p.x = x;
+    p.y = y;
+    if (!f->cells[idx]) f->cells[idx] = cell_new();
+    cell_add_point(f->cells[idx], p);
+    f->built = 0;
+  }
+}
+
+static int vec3_is_zero(const double v[3], double prec) {
+  /* Eigen isZero(prec): every |coeff| <= prec */
+  return fabs(v[0]) <= prec && fabs(v[1]) <= prec && fabs(v[2]) <= prec;
+}
+
+void orc_frame_load_laser(orc_frame *f, const float *ranges, unsigned n, float min_angle,
+                          float angle_increment, float max_range) {
+  unsigned i;
+  int do_trans = !vec3_is_zero(f->trans, 1e-6); /* ndtframe.cpp:152-153 */
+  double tc = cos(f->trans[2]), ts = sin(f->trans[2]);
+  f->built = 0;
+  for (i = 0; i < n; ++i) {
+    /* ndtframe.cpp:165 */
+    if ((ranges[i] > 0.) && (ranges[i] < max_range) && (ranges[i] > f->laser_ignore_epsilon)) {
+      float theta = (float)i * angle_increment + min_angle; /* index_to_angle, core.h:40-42 (fp32) */
+      v2 p;                                                  /* laser_to_point, core.h:45-47 */
+      p.x = (double)ranges[i] * cos((double)theta);
+      p.y = (double)ranges[i] * sin((double)theta);
+      if (do_trans) p = transform_point_cs(p, tc, ts, f->trans[0], f->trans[1]); /* ndtframe.cpp:175-176 */
+      orc_frame_add_point(f, p.x, p.y);
+    }
+  }
+}
+
+void orc_frame_update(orc_frame *ref, const double trans[3], const orc_frame *nf) {
+  unsigned ci, i;
+  double c = cos(trans[2]), s = sin(trans[2]);
+  ref->built = 0;
+  for (ci = 0; ci < nf->num_cells; ++ci) {
+    const orc_cell *cell = nf->cells[ci];
+    if (cell && cell->created) {
+      for (i = 0; i < cell->points[0].n; ++i) {
+        v2 q = transform_point_cs(cell->points[0].p[i], c, s, trans[0], trans[1]);
+        orc_frame_add_point(ref, q.x, q.y);
+      }
+    }
+  }
+}
+
+void orc_frame_build(orc_frame *f) {
+  unsigned i;
+  for (i = 0; i < f->num_cells; ++i)
+    if (f->cells[i] && f->cells[i]->created) cell_build(f->cells[i]);
+  f->built = 1;
+}
+
+unsigned orc_frame_num_points(const orc_frame *f) {
+  unsigned i, n = 0;
+  for (i = 0; i < f->num_cells; ++i)
+    if (f->cells[i]) n += f->cells[i]->points[0].n;
+  return n;
+}
+
+unsigned orc_frame_get_points(const orc_frame *f, double *xy) {
+  unsigned i, k, n = 0;
+  for (i = 0; i < f->num_cells; ++i)
+    if (f->cells[i])
+      for (k = 0; k < f->cells[i]->points[0].n; ++k) {
+        xy[2 * n] = f->cells[i]->points[0].p[k].x;
+        xy[2 * n + 1] = f->cells[i]->points[0].p[k].y;
+        ++n;
+      }
+  return n;
+}
+
+unsigned orc_frame_num_created(const orc_frame *f) {
+  unsigned i, n = 0;
+  for (i = 0; i < f->num_cells; ++i)
+    if (f->cells[i] && f->cells[i]->created) ++n;
+  return n;
+}
+
+unsigned orc_frame_export_cells(const orc_frame *f, orc_cell_row *rows, unsigned max_rows) {
+  unsigned i, n = 0;
+  for (i = 0; i < f->num_cells && n < max_rows; ++i) {
+    const orc_cell *c = f->cells[i];
+    if (c && c->created) {
+      rows[n].index = (int32_t)i;
+      rows[n].count = c->global_count;
+      rows[n].built = c->built;
+      rows[n].n_slot0 = (int32_t)c->points[0].n;
+      rows[n].mean[0] = c->mean.x;
+      rows[n].mean[1] = c->mean.y;
+      memcpy(rows[n].icov, c->inv_covar, sizeof(rows[n].icov));
+      ++n;
+    }
+  }
+  return n;
+}
+
+/* ------------------------------------------------------------------ */
+/* cost_function, core.cpp:26-48                                       */
+
+double orc_cost_function(const double trans[3], orc_frame *ref, const orc_frame *nf, int32_t *cell_idx) {
+  double cost = 0.;
+  double c, s;
+  unsigned ci, i, k = 0;
+  if (!ref->built) orc_frame_build(ref); /* core.cpp:27-28 */
+  c = cos(trans[2]);
+  s = sin(trans[2]);
+  for (ci = 0; ci < nf->num_cells; ++ci) { /* core.cpp:33 */
+    const orc_cell *nc = nf->cells[ci];
+    if (!nc) continue;
+    for (i = 0; i < nc->points[0].n; ++i, ++k) { /* core.cpp:36 */
+      v2 q = transform_point_cs(nc->points[0].p[i], c, s, trans[0], trans[1]);
+      int idx = orc_frame_get_cell_index(ref, q.x, q.y);
+      int tag = -1;
+      if (-1 != idx && idx >= 0 && (unsigned)idx < ref->num_cells) {
+        const orc_cell *rc = ref->cells[idx];
+        if (rc && rc->built) { /* core.cpp:40 */
+          cost -= cell_normal_distribution(rc, q.x, q.y);
+          tag = idx;
+        } else
+          tag = -2;
+      }
+      if (cell_idx) cell_idx[k] = tag;
+    }
+  }
+  return cost;
+}
+
+/* ------------------------------------------------------------------ */
+/* pso_optimization, core.cpp:50-116 -- single-thread order            */
+
+typedef struct {
+  double position[3], velocity[3], best_position[3];
+  double best_cost, cost;
+} orc_particle;
+
+/* Particle::Particle, core.cpp:13-23 */
+static void particle_init(orc_particle *p, const double mean[3], const double dev[3], orc_frame *ref,
+                          const orc_frame *nf, orc_rand *g, orc_pso_stats *st) {
+  int k;
+  for (k = 0; k < 3; ++k) {
+    p->position[k] = mean[k] + (orc_uniform_pm1(g) * dev[k]);
+    p->velocity[k] = 0.;
+  }
+  p->cost = orc_cost_function(p->position, ref, nf, NULL);
+  memcpy(p->best_position, p->position, sizeof(p->position));
+  p->best_cost = p->cost;
+  if (st) {
+    st->rand_draws += 3;
+    st->cost_evals += 1;
+  }
+}
+
+void orc_pso_optimization(const double guess[3], orc_frame *ref, const orc_frame *nf, const double deviation[3],
+                          const orc_pso_config *cfg, orc_rand *g, double out_pose[3], double *out_cost,
+                          orc_pso_stats *st) {
+  const double zero_devi[3] = {1E-4, 1E-4, 1E-5}; /* core.cpp:53 */
+  double w = cfg->w;
+  int P = cfg->population, I = cfg->iterations, i, j, k;
+  orc_particle gbest, *ps = (orc_particle *)malloc((size_t)(P > 0 ? P : 1) * sizeof(orc_particle));
+  if (st) memset(st, 0, sizeof(*st));
+
+  particle_init(&gbest, guess, zero_devi, ref, nf, g, st); /* core.cpp:58 */
+  for (i = 0; i < P; ++i) {                                 /* core.cpp:60-69 */
+    particle_init(&ps[i], guess, deviation, ref, nf, g, st);
+    if (ps[i].cost < gbest.best_cost) {
+      gbest.best_cost = ps[i].best_cost;
+      memcpy(gbest.best_position, ps[i].best_position, sizeof(gbest.best_position));
+    }
+  }
+
+  for (i = 0; i < I; ++i) { /* core.cpp:78 */
+    for (j = 0; j < P; ++j) {
+      orc_particle *p = &ps[j];
+      for (k = 0; k < 3; ++k) { /* core.cpp:83-90 */
+        double r1 = fabs(orc_uniform_pm1(g));
+        double r2 = fabs(orc_uniform_pm1(g));
+        p->velocity[k] = w * p->velocity[k] + cfg->c1 * r1 * (p->best_position[k] - p->position[k]) +
+                         cfg->c2 * r2 * (gbest.best_position[k] - p->position[k]);
+        p->position[k] = p->position[k] + p->velocity[k];
+      }
+      p->cost = orc_cost_function(p->position, ref, nf, NULL); /* core.cpp:92 */
+      if (st) {
+        st->rand_draws += 6;
+        st->cost_evals += 1;
+      }
+      if (p->cost < p->best_cost) { /* core.cpp:94-105 */
+        p->best_cost = p->cost;
+        memcpy(p->best_position, p->position, sizeof(p->position));
+        if (st) st->pbest_updates++;
+        if (p->cost < gbest.best_cost) {
+          gbest.best_cost = p->best_cost;
+          memcpy(gbest.best_position, p->best_position, sizeof(gbest.best_position));
+          if (st) st->gbest_updates++;
+        }
+      }
+    }
+    w *= cfg->w_damping; /* core.cpp:108 */
+  }
+  memcpy(out_pose, gbest.best_position, 3 * sizeof(double)); /* core.cpp:115 */
+  if (out_cost) *out_cost = gbest.best_cost;
+  free(ps);
+}
+
+/* NDTFrame::align, ndtframe.cpp:251-266 */
+void orc_frame_align(orc_frame *ref, const double guess[3], const orc_frame *nf, const orc_pso_config *cfg,
+                     orc_rand *g, double out_pose[3]) {
+  double dev[3];
+  orc_pso_config def;
+  int k;
+  if (ref->iter < 2) { /* ndtframe.cpp:253 */
+    dev[0] = .1;
+    dev[1] = .1;
+    dev[2] = 3.1415E-3;
+  } else {
+    for (k = 0; k < 3; ++k) dev[k] = fabs(ref->pose_diff[k] * 2.);
+  }
+  ++ref->iter;
+  orc_pso_config_default(&def); /* ndtframe.cpp:257 passes no config: PSOConfig() */
+  orc_pso_optimization(guess, ref, nf, dev, cfg ? cfg : &def, g, out_pose, NULL, NULL);
+  /* TRANSFORM_POSE_AFTER_ALIGN is false (config.h:9-10) */
+  for (k = 0; k < 3; ++k) { /* ndtframe.cpp:263-264 */
+    ref->pose_diff[k] = out_pose[k] - ref->prev_pose[k];
+    ref->prev_pose[k] = out_pose[k];
+  }
+}
+
+/* ------------------------------------------------------------------ */
+/* batched pairs: the CPU baseline workload                            */
+
+int orc_align_pairs(int n_pairs, const float *ref_ranges, const float *new_ranges, unsigned n_beams,
+                    float min_angle, float angle_increment, float max_range, float eps, unsigned short width,
+                    unsigned short height, double cell_side, const double *guess, const double *deviation,
+                    const orc_pso_config *cfg, const uint32_t *seeds, int n_threads, double *out_pose,
+                    double *out_cost) {
+  int used = 1, b;
+  size_t n_draw = orc_pso_rand_draws(cfg);
+#ifdef _OPENMP
+  if (n_threads <= 0) n_threads = omp_get_max_threads();
+  if (n_threads > n_pairs) n_threads = n_pairs > 0 ? n_pairs : 1;
+  used = n_threads;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads)
+#else
+  (void)n_threads;
+#endif
+  for (b = 0; b < n_pairs; ++b) {
+    const double zero[3] = {0., 0., 0.};
+    unsigned short one_cell = width > height ? width : height;
+    orc_frame *ref = orc_frame_create(zero, width, height, cell_side, eps);
+    /* ndtpso_slam_node.cpp:229-230: the frame being matched is a one-cell frame */
+    orc_frame *nf = orc_frame_create(zero, width, height, (double)one_cell, eps);
+    int32_t *tab = (int32_t *)malloc(n_draw * sizeof(int32_t));
+    orc_rand g;
+    orc_frame_load_laser(ref, ref_ranges + (size_t)b * n_beams, n_beams, min_angle, angle_increment, max_range);
+    orc_frame_load_laser(nf, new_ranges + (size_t)b * n_beams, n_beams, min_angle, angle_increment, max_range);
+    orc_glibc_rand_fill(seeds[b], tab, n_draw);
+    g.table = tab;
+    g.n = n_draw;
+    g.cursor = 0;
+    orc_pso_optimization(guess + 3 * (size_t)b, ref, nf, deviation + 3 * (size_t)b, cfg, &g,
+                         out_pose + 3 * (size_t)b, out_cost ? out_cost + b : NULL, NULL);
+    free(tab);
+    orc_frame_destroy(ref);
+    orc_frame_destroy(nf);
+  }
+  return used;
+}
