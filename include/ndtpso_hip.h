@@ -1,0 +1,152 @@
+/*
+ * ndtpso_hip.h -- C-ABI of the MI355X (gfx950) NDT-PSO scan-alignment path.
+ *
+ * The reference (abougouffa/ndtpso_slam) has no FFI/plugin layer: its boundary
+ * is the C++ class API of libndtpso_slam consumed by ndtpso_slam_node
+ * (CMakeLists.txt:155-160,183-187).  This header is the thin C-ABI that the
+ * drop-in host library (host/ndtpso_slam/ *.h, same class names and
+ * signatures as include/ndtpso_slam/ndtframe.h:37-70 of the reference) calls
+ * into; each entry point names the reference code it replaces.  Plain
+ * pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns 0 (NDTPSO_OK) or a negative NDTPSO_E_* code;
+ *     ndtpso_last_error(ctx) gives the text.  Nothing throws across the ABI
+ *     (the reference API never throws either; SURVEY 8b "Errors").
+ *   - `_dev` variants take DEVICE pointers, enqueue on the context stream and
+ *     return without synchronising; the others take HOST pointers and return
+ *     after the results are back on the host.
+ *   - there is no CPU fallback: with no usable HIP device every call fails
+ *     with NDTPSO_E_HIP.
+ */
+#ifndef NDTPSO_HIP_H
+#define NDTPSO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDTPSO_OK 0
+#define NDTPSO_E_HIP (-1)      /* HIP runtime error / no device */
+#define NDTPSO_E_ARG (-2)      /* invalid argument */
+#define NDTPSO_E_CAPACITY (-3) /* problem does not fit the on-chip (LDS) layout */
+#define NDTPSO_E_STATE (-4)    /* call order (e.g. align before a reference table is set) */
+
+/* score arithmetic after the fp64 transform + cell lookup */
+#define NDTPSO_SCORE_F32 0 /* Mahalanobis + exp in fp32, fp64 accumulation (BASELINE config 2: "fp32") */
+#define NDTPSO_SCORE_F64 1 /* everything in fp64, reference operation order */
+
+typedef struct ndtpso_ctx ndtpso_ctx;
+
+/* PSOConfig, include/ndtpso_slam/config.h:27-38 (field for field; num_threads is ignored on the device) */
+typedef struct {
+  int32_t iterations;
+  int32_t population;
+  int32_t num_threads;
+  double w, c1, c2, w_damping;
+} ndtpso_pso_config;
+
+/* NDTFrame grid geometry: width/height in metres (uint16, ndtframe.h:32), cell_side (ndtframe.h:36) */
+typedef struct {
+  uint16_t width, height;
+  double cell_side;
+} ndtpso_grid;
+
+/* arguments of NDTFrame::loadLaser (ndtframe.h:47-48) + NDTPSOConfig::laserIgnoreEpsilon (config.h:44) */
+typedef struct {
+  uint32_t n_beams;
+  float min_angle, angle_increment, max_range;
+  float laser_ignore_epsilon;
+} ndtpso_scan_geom;
+
+/* one row per created cell (ascending linear index), for inspection / parity tests */
+typedef struct {
+  int32_t index; /* ix + W*iy, NDTFrame::getCellIndex (ndtframe.cpp:244-245) */
+  int32_t count; /* points accumulated */
+  int32_t built; /* NDTCell::built (count > 2, ndtcell.cpp:43) */
+  int32_t reserved;
+  double mean[2];
+  double icov[4]; /* row-major inverse covariance (ndtcell.cpp:109-110) */
+} ndtpso_cell_row;
+
+typedef struct {
+  uint32_t n_points;      /* new-scan points that entered the PSO */
+  uint32_t n_built;       /* built reference cells */
+  uint32_t cost_evals;    /* particle evaluations incl. replays */
+  uint32_t rounds;        /* evaluation rounds (iterations + replays) */
+  uint32_t gbest_updates; /* in-iteration gbest improvements */
+  uint32_t status;        /* 0 ok; bit0: a reference point fell outside the staging window */
+  uint32_t reserved[2];
+} ndtpso_align_stats;
+
+/* ---- context --------------------------------------------------------- */
+int ndtpso_ctx_create(int device, ndtpso_ctx **out);
+void ndtpso_ctx_destroy(ndtpso_ctx *ctx);
+const char *ndtpso_last_error(const ndtpso_ctx *ctx);
+/* hipStream_t to enqueue on (NULL = the context's own stream) */
+int ndtpso_set_stream(ndtpso_ctx *ctx, void *hip_stream);
+int ndtpso_synchronize(ndtpso_ctx *ctx);
+/* number of std::rand() draws one alignment consumes: 3 + 3P + 6PI (core.cpp:14,84) */
+size_t ndtpso_rand_draws(const ndtpso_pso_config *cfg);
+
+/* ---- K3 companions: scan ingest and cell statistics ------------------- */
+/* NDTFrame::loadLaser's beam filter + index_to_angle + laser_to_point (+ s_trans transform)
+ * (ndtframe.cpp:144-185, core.h:40-47).  xy_out: 2*n_beams doubles; *n_out = surviving points, beam order. */
+int ndtpso_scan_to_points(ndtpso_ctx *ctx, const float *ranges, const ndtpso_scan_geom *geom,
+                          const double trans[3], double *xy_out, uint32_t *n_out);
+
+/* Reference table of a FRESH frame from points: NDTFrame::addPoint binning (ndtframe.cpp:215-235) +
+ * NDTCell::build / s_calc_covar_inverse (ndtcell.cpp:36-68,93-111).  The table stays on the device
+ * as the context's reference table. */
+int ndtpso_ref_from_points(ndtpso_ctx *ctx, const ndtpso_grid *grid, const double *xy, uint32_t n_points);
+/* same, starting from a LaserScan (loadLaser at pose `trans`, then build) */
+int ndtpso_ref_from_scan(ndtpso_ctx *ctx, const ndtpso_grid *grid, const float *ranges,
+                         const ndtpso_scan_geom *geom, const double trans[3]);
+/* Reference table from host-side cell statistics (an accumulated map kept by the host NDTFrame):
+ * built cells only; index[] ascending or not, mean 2*n, icov 4*n row-major. */
+int ndtpso_ref_set_cells(ndtpso_ctx *ctx, const ndtpso_grid *grid, uint32_t n_cells, const int32_t *index,
+                         const double *mean, const double *icov);
+/* created cells of the table built by ndtpso_ref_from_points/_scan (parity inspection) */
+int ndtpso_ref_get_cells(ndtpso_ctx *ctx, ndtpso_cell_row *rows, uint32_t max_rows, uint32_t *n_rows);
+
+/* ---- K1: cost_function (core.cpp:26-48) for M candidate poses ---------- */
+/* xy: n_points new-frame points; poses: 3*M; costs: M; cell_idx (optional, M*n_points):
+ * linear cell index scored against, -1 outside frame, -2 cell not built. */
+int ndtpso_cost_batch(ndtpso_ctx *ctx, const double *xy, uint32_t n_points, const double *poses, uint32_t m,
+                      int score_mode, double *costs, int32_t *cell_idx);
+
+/* ---- K2: pso_optimization (core.cpp:50-116) --------------------------- */
+/* rand_table: the std::rand() outputs the reference would draw (ndtpso_rand_draws() values), or NULL
+ * to replay glibc's srand(seed) stream on the device. */
+int ndtpso_align(ndtpso_ctx *ctx, const double *xy, uint32_t n_points, const double guess[3],
+                 const double deviation[3], const ndtpso_pso_config *cfg, uint32_t seed,
+                 const int32_t *rand_table, int score_mode, double out_pose[3], double *out_cost,
+                 ndtpso_align_stats *stats);
+
+/* ---- fused batched scan pairs (BASELINE configs 3/4) ------------------- */
+/* For pair b: reference frame <- ref scan loaded at identity and built; new frame <- new scan
+ * (ndtpso_slam_node.cpp:186,229-230); pose_b = pso_optimization(guess_b, ref, new, deviation_b, cfg)
+ * under the srand(seeds[b]) stream (or rand_tables + b*ndtpso_rand_draws(cfg) when not NULL).
+ * ranges are [n_pairs][n_beams] row-major; guess/deviation/out_pose [n_pairs][3]. */
+int ndtpso_align_pairs(ndtpso_ctx *ctx, uint32_t n_pairs, const float *ref_ranges, const float *new_ranges,
+                       const ndtpso_scan_geom *geom, const ndtpso_grid *grid, const double *guess,
+                       const double *deviation, const ndtpso_pso_config *cfg, const uint32_t *seeds,
+                       const int32_t *rand_tables, int score_mode, double *out_pose, double *out_cost,
+                       ndtpso_align_stats *stats);
+/* same with DEVICE pointers; asynchronous on the context stream */
+int ndtpso_align_pairs_dev(ndtpso_ctx *ctx, uint32_t n_pairs, const float *d_ref_ranges,
+                           const float *d_new_ranges, const ndtpso_scan_geom *geom, const ndtpso_grid *grid,
+                           const double *d_guess, const double *d_deviation, const ndtpso_pso_config *cfg,
+                           const uint32_t *d_seeds, const int32_t *d_rand_tables, int score_mode,
+                           double *d_out_pose, double *d_out_cost, ndtpso_align_stats *d_stats);
+/* LDS bytes and workgroup size the fused kernel would be launched with (occupancy study; 0 if it does not fit) */
+int ndtpso_align_pairs_footprint(const ndtpso_scan_geom *geom, const ndtpso_grid *grid,
+                                 const ndtpso_pso_config *cfg, uint32_t *lds_bytes, uint32_t *block_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

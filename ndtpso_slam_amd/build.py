@@ -1,0 +1,49 @@
+"""Builds the gfx950 HIP library in-tree (ndtpso_slam_amd/lib/libndtpso_hip.so).
+
+hipcc cross-compiles for gfx950 without a GPU present.  -ffp-contract=off is part of the
+numerical contract: the fp64 PSO update / index arithmetic must round like the reference
+(baseline x86-64, no FMA); fused multiply-adds exist only where the kernels spell fma().
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "ndtpso_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "ndtpso_kernels.hpp"),
+        os.path.join(os.path.dirname(HERE), "include", "ndtpso_hip.h")]
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libndtpso_hip.so")
+
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+         "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP library cannot be built")
+    return exe
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build():
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = [hipcc()] + FLAGS + [SRC, "-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

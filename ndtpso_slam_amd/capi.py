@@ -1,0 +1,256 @@
+"""ctypes binding of the C-ABI in include/ndtpso_hip.h (libndtpso_hip.so).
+
+There is no CPU fallback: if the library is missing or no HIP device is usable every
+call raises NdtpsoError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+SCORE_F32 = 0
+SCORE_F64 = 1
+
+OK, E_HIP, E_ARG, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4
+
+
+class NdtpsoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ndtpso error {code}: {msg}")
+        self.code = code
+
+
+class PSOConfig(C.Structure):
+    """PSOConfig, include/ndtpso_slam/config.h:27-38 of the reference."""
+    _fields_ = [("iterations", C.c_int32), ("population", C.c_int32), ("num_threads", C.c_int32),
+                ("w", C.c_double), ("c1", C.c_double), ("c2", C.c_double), ("w_damping", C.c_double)]
+
+    @staticmethod
+    def make(iterations=50, population=30, w=0.8, c1=2.0, c2=2.0, w_damping=1.0):
+        return PSOConfig(iterations, population, -1, w, c1, c2, w_damping)
+
+
+class Grid(C.Structure):
+    _fields_ = [("width", C.c_uint16), ("height", C.c_uint16), ("cell_side", C.c_double)]
+
+
+class ScanGeom(C.Structure):
+    _fields_ = [("n_beams", C.c_uint32), ("min_angle", C.c_float), ("angle_increment", C.c_float),
+                ("max_range", C.c_float), ("laser_ignore_epsilon", C.c_float)]
+
+
+class CellRow(C.Structure):
+    _fields_ = [("index", C.c_int32), ("count", C.c_int32), ("built", C.c_int32), ("reserved", C.c_int32),
+                ("mean", C.c_double * 2), ("icov", C.c_double * 4)]
+
+
+class AlignStats(C.Structure):
+    _fields_ = [("n_points", C.c_uint32), ("n_built", C.c_uint32), ("cost_evals", C.c_uint32),
+                ("rounds", C.c_uint32), ("gbest_updates", C.c_uint32), ("status", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
+
+
+STATS_DTYPE = np.dtype([("n_points", "<u4"), ("n_built", "<u4"), ("cost_evals", "<u4"), ("rounds", "<u4"),
+                        ("gbest_updates", "<u4"), ("status", "<u4"), ("reserved", "<u4", (2,))])
+assert STATS_DTYPE.itemsize == C.sizeof(AlignStats)
+
+EXPORTS = [
+    "ndtpso_ctx_create", "ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_set_stream", "ndtpso_synchronize",
+    "ndtpso_rand_draws", "ndtpso_scan_to_points", "ndtpso_ref_from_points", "ndtpso_ref_from_scan",
+    "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
+    "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint",
+]
+
+_lib = None
+
+
+def library_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """dlopen the HIP library (building it with hipcc first if it is absent)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB
+    if build_if_missing and _build.needs_build():
+        _build.build_hip()
+    if not os.path.exists(path):
+        raise NdtpsoError(E_HIP, f"{path} is missing: build it with `python -m ndtpso_slam_amd.build`")
+    L = C.CDLL(path)
+    vp, dp, fp = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_float)
+    ip, up = C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    L.ndtpso_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ndtpso_ctx_destroy.argtypes = [vp]
+    L.ndtpso_ctx_destroy.restype = None
+    L.ndtpso_last_error.argtypes = [vp]
+    L.ndtpso_last_error.restype = C.c_char_p
+    L.ndtpso_set_stream.argtypes = [vp, vp]
+    L.ndtpso_synchronize.argtypes = [vp]
+    L.ndtpso_rand_draws.argtypes = [C.POINTER(PSOConfig)]
+    L.ndtpso_rand_draws.restype = C.c_size_t
+    L.ndtpso_scan_to_points.argtypes = [vp, fp, C.POINTER(ScanGeom), dp, dp, up]
+    L.ndtpso_ref_from_points.argtypes = [vp, C.POINTER(Grid), dp, C.c_uint32]
+    L.ndtpso_ref_from_scan.argtypes = [vp, C.POINTER(Grid), fp, C.POINTER(ScanGeom), dp]
+    L.ndtpso_ref_set_cells.argtypes = [vp, C.POINTER(Grid), C.c_uint32, ip, dp, dp]
+    L.ndtpso_ref_get_cells.argtypes = [vp, C.POINTER(CellRow), C.c_uint32, up]
+    L.ndtpso_cost_batch.argtypes = [vp, dp, C.c_uint32, dp, C.c_uint32, C.c_int, dp, ip]
+    L.ndtpso_align.argtypes = [vp, dp, C.c_uint32, dp, dp, C.POINTER(PSOConfig), C.c_uint32, ip, C.c_int, dp, dp,
+                               C.POINTER(AlignStats)]
+    pairs_args = [vp, C.c_uint32, vp, vp, C.POINTER(ScanGeom), C.POINTER(Grid), vp, vp, C.POINTER(PSOConfig),
+                  vp, vp, C.c_int, vp, vp, vp]
+    L.ndtpso_align_pairs.argtypes = pairs_args
+    L.ndtpso_align_pairs_dev.argtypes = pairs_args
+    L.ndtpso_align_pairs_footprint.argtypes = [C.POINTER(ScanGeom), C.POINTER(Grid), C.POINTER(PSOConfig), up, up]
+    for name in EXPORTS:
+        fn = getattr(L, name)
+        if name not in ("ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_rand_draws"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _p(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+class Context:
+    """One HIP device context (one per host thread / stream)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load()
+        h = C.c_void_p()
+        rc = self._lib.ndtpso_ctx_create(int(device), C.byref(h))
+        if rc != OK:
+            raise NdtpsoError(rc, "no usable HIP device (ndtpso_ctx_create failed); there is no CPU fallback")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndtpso_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise NdtpsoError(rc, self._lib.ndtpso_last_error(self._h).decode())
+
+    def set_stream(self, stream_handle: int | None):
+        self._chk(self._lib.ndtpso_set_stream(self._h, C.c_void_p(stream_handle or 0)))
+
+    def synchronize(self):
+        self._chk(self._lib.ndtpso_synchronize(self._h))
+
+    # ---- K3 ----
+    def scan_to_points(self, ranges, geom: ScanGeom, trans=(0.0, 0.0, 0.0)) -> np.ndarray:
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        assert r.size == geom.n_beams
+        xy = np.empty((r.size, 2))
+        n = C.c_uint32()
+        self._chk(self._lib.ndtpso_scan_to_points(self._h, _p(r, C.c_float), C.byref(geom),
+                                                  _p(_f64(trans, 3), C.c_double), _p(xy, C.c_double), C.byref(n)))
+        return xy[:n.value].copy()
+
+    def ref_from_points(self, grid: Grid, xy):
+        xy = _f64(xy).reshape(-1, 2)
+        self._chk(self._lib.ndtpso_ref_from_points(self._h, C.byref(grid), _p(xy, C.c_double), xy.shape[0]))
+
+    def ref_from_scan(self, grid: Grid, ranges, geom: ScanGeom, trans=(0.0, 0.0, 0.0)):
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        self._chk(self._lib.ndtpso_ref_from_scan(self._h, C.byref(grid), _p(r, C.c_float), C.byref(geom),
+                                                 _p(_f64(trans, 3), C.c_double)))
+
+    def ref_set_cells(self, grid: Grid, index, mean, icov):
+        index = np.ascontiguousarray(index, dtype=np.int32)
+        mean = _f64(mean).reshape(-1, 2)
+        icov = _f64(icov).reshape(-1, 4)
+        self._chk(self._lib.ndtpso_ref_set_cells(self._h, C.byref(grid), index.size, _p(index, C.c_int32),
+                                                 _p(mean, C.c_double), _p(icov, C.c_double)))
+
+    def ref_get_cells(self):
+        n = C.c_uint32()
+        self._chk(self._lib.ndtpso_ref_get_cells(self._h, None, 0, C.byref(n)))
+        rows = (CellRow * max(n.value, 1))()
+        self._chk(self._lib.ndtpso_ref_get_cells(self._h, rows, n.value, C.byref(n)))
+        return [dict(index=r.index, count=r.count, built=bool(r.built), mean=np.array(r.mean[:]),
+                     icov=np.array(r.icov[:])) for r in rows[:n.value]]
+
+    # ---- K1 ----
+    def cost_batch(self, xy, poses, mode=SCORE_F32, want_cells=False):
+        xy = _f64(xy).reshape(-1, 2)
+        poses = _f64(poses).reshape(-1, 3)
+        costs = np.empty(poses.shape[0])
+        idx = np.empty((poses.shape[0], xy.shape[0]), dtype=np.int32) if want_cells else None
+        self._chk(self._lib.ndtpso_cost_batch(self._h, _p(xy, C.c_double), xy.shape[0], _p(poses, C.c_double),
+                                              poses.shape[0], mode, _p(costs, C.c_double),
+                                              _p(idx, C.c_int32) if want_cells else None))
+        return (costs, idx) if want_cells else costs
+
+    # ---- K2 ----
+    def align(self, xy, guess, deviation, cfg: PSOConfig, seed=1, rand_table=None, mode=SCORE_F32):
+        xy = _f64(xy).reshape(-1, 2)
+        pose = np.empty(3)
+        cost = C.c_double()
+        st = AlignStats()
+        tab = None
+        if rand_table is not None:
+            tab = np.ascontiguousarray(rand_table, dtype=np.int32)
+            assert tab.size >= self._lib.ndtpso_rand_draws(C.byref(cfg))
+        self._chk(self._lib.ndtpso_align(self._h, _p(xy, C.c_double), xy.shape[0], _p(_f64(guess, 3), C.c_double),
+                                         _p(_f64(deviation, 3), C.c_double), C.byref(cfg), C.c_uint32(int(seed)),
+                                         _p(tab, C.c_int32) if tab is not None else None, mode,
+                                         _p(pose, C.c_double), C.byref(cost), C.byref(st)))
+        stats = {k: getattr(st, k) for k, _ in AlignStats._fields_ if k != "reserved"}
+        return pose, cost.value, stats
+
+    # ---- fused pairs ----
+    def align_pairs(self, ref_ranges, new_ranges, geom: ScanGeom, grid: Grid, guess, deviation, cfg: PSOConfig,
+                    seeds=None, rand_tables=None, mode=SCORE_F32):
+        ref = np.ascontiguousarray(ref_ranges, dtype=np.float32)
+        new = np.ascontiguousarray(new_ranges, dtype=np.float32)
+        B = ref.shape[0]
+        assert ref.shape == new.shape == (B, geom.n_beams)
+        guess = np.ascontiguousarray(np.broadcast_to(_f64(guess), (B, 3)))
+        deviation = np.ascontiguousarray(np.broadcast_to(_f64(deviation), (B, 3)))
+        pose = np.empty((B, 3))
+        cost = np.empty(B)
+        stats = np.zeros(B, dtype=STATS_DTYPE)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32) if seeds is not None else None
+        tb = np.ascontiguousarray(rand_tables, dtype=np.int32) if rand_tables is not None else None
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None  # noqa: E731
+        self._chk(self._lib.ndtpso_align_pairs(self._h, B, vp(ref), vp(new), C.byref(geom), C.byref(grid), vp(guess),
+                                               vp(deviation), C.byref(cfg), vp(sd), vp(tb), mode, vp(pose), vp(cost),
+                                               vp(stats)))
+        return pose, cost, stats
+
+    def align_pairs_dev(self, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode,
+                        d_pose, d_cost, d_stats):
+        """Device pointers (ints); asynchronous on the context stream."""
+        vp = lambda a: C.c_void_p(int(a)) if a else None  # noqa: E731
+        self._chk(self._lib.ndtpso_align_pairs_dev(self._h, int(n_pairs), vp(d_ref), vp(d_new), C.byref(geom),
+                                                   C.byref(grid), vp(d_guess), vp(d_dev), C.byref(cfg), vp(d_seeds),
+                                                   vp(d_tables), mode, vp(d_pose), vp(d_cost), vp(d_stats)))
+
+
+def align_pairs_footprint(geom: ScanGeom, grid: Grid, cfg: PSOConfig):
+    L = load()
+    lds, thr = C.c_uint32(), C.c_uint32()
+    rc = L.ndtpso_align_pairs_footprint(C.byref(geom), C.byref(grid), C.byref(cfg), C.byref(lds), C.byref(thr))
+    return rc, lds.value, thr.value

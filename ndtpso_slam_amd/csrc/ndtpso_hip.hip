@@ -1,0 +1,734 @@
+// ndtpso_hip.hip -- __global__ entry points and the C-ABI (include/ndtpso_hip.h) of the gfx950
+// NDT-PSO alignment path.  Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -shared -fPIC.
+#include "ndtpso_kernels.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/ndtpso_hip.h"
+
+using namespace ndtpso;
+
+static_assert(sizeof(CellRow) == sizeof(ndtpso_cell_row), "cell row ABI");
+static_assert(sizeof(AlignStats) == sizeof(ndtpso_align_stats), "stats ABI");
+
+namespace {
+
+constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
+constexpr int kCtrlBytes = 512;      // control block (PsoShared + compaction counters) at LDS offset 0
+
+// LDS layout shared by every kernel: [ctrl | image | pts | region], region = max(build scratch, swarm)
+struct Layout {
+  int image_off, pts_off, region_off, total;
+  int key_off, cellkey_off, cnt_off, bm2_off;  // build scratch inside region
+};
+
+Layout make_layout(int n_words, int rec_cap, int n_max, int P) {
+  Layout L;
+  L.image_off = kCtrlBytes;
+  L.pts_off = L.image_off + align16(image_bytes(n_words, rec_cap));
+  L.region_off = L.pts_off + align16(n_max * 16);
+  const int ints = align16(n_max * 4);
+  L.key_off = L.region_off;
+  L.cellkey_off = L.key_off + ints;
+  L.cnt_off = L.cellkey_off + ints;
+  L.bm2_off = L.cnt_off + ints;
+  const int scratch = 3 * ints + align16(n_words * 8);
+  const int swarm = (P > 0) ? swarm_bytes(P) : 0;
+  L.total = L.region_off + std::max(scratch, swarm);
+  return L;
+}
+
+}  // namespace
+
+static_assert(sizeof(PsoShared) + 32 * sizeof(int) <= kCtrlBytes, "control block too small");
+
+extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
+
+__device__ __forceinline__ PsoShared* lds_ctrl() { return reinterpret_cast<PsoShared*>(g_lds); }
+__device__ __forceinline__ int* lds_cnt() { return reinterpret_cast<int*>(g_lds + sizeof(PsoShared)); }
+
+__device__ __forceinline__ void copy_global_to_lds16(void* dst, const void* src, int bytes) {
+  // bytes is a multiple of 16; 16 B per lane, consecutive lanes consecutive addresses (coalesced)
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  for (int i = threadIdx.x; i < (bytes >> 4); i += blockDim.x) d[i] = s[i];
+}
+
+// ---- K3a -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_scan_to_points(const float* __restrict__ ranges, ScanP sp, int do_trans, double tc, double ts, double ttx,
+                 double tty, double2* __restrict__ out_xy, uint32_t* __restrict__ out_n) {
+  const size_t b = blockIdx.x;
+  const int n = scan_to_points_wg(ranges + b * sp.n_beams, sp, do_trans != 0, tc, ts, ttx, tty,
+                                  out_xy + b * sp.n_beams, lds_cnt());
+  if (threadIdx.x == 0) out_n[b] = (uint32_t)n;
+}
+
+// ---- K3b -------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_build_table(const double2* __restrict__ xy, int n, GridP g, WinP wn, Layout L, unsigned char* __restrict__ image_out,
+              CellRow* __restrict__ rows, uint32_t* __restrict__ n_rows) {
+  double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
+  copy_global_to_lds16(pts, xy, n * 16);
+  __syncthreads();
+  build_table_wg(g, wn, pts, n, g_lds + L.image_off, reinterpret_cast<int*>(g_lds + L.key_off),
+                 reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
+                 reinterpret_cast<uint2*>(g_lds + L.bm2_off), rows, n_rows);
+  copy_global_to_lds16(image_out, g_lds + L.image_off, image_bytes(wn.n_words, wn.rec_cap));  // LDS -> global
+}
+
+// ---- K1 --------------------------------------------------------------------------------------
+template <int MODE, bool DUMP>
+__global__ void __launch_bounds__(1024)
+k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n, GridP g, WinP wn,
+             Layout L, const double* __restrict__ poses, int m, double* __restrict__ costs,
+             int32_t* __restrict__ dump) {
+  unsigned char* img = g_lds + L.image_off;
+  double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
+  copy_global_to_lds16(img, image, image_bytes(wn.n_words, wn.rec_cap));
+  copy_global_to_lds16(pts, xy, n * 16);
+  __syncthreads();
+  const uint2* bm = reinterpret_cast<const uint2*>(img + kImageHeaderBytes);
+  const Rec* rec = reinterpret_cast<const Rec*>(img + image_rec_offset(wn.n_words));
+  const int n_waves = blockDim.x >> 6;
+  for (int k = blockIdx.x * n_waves + wave_id(); k < m; k += gridDim.x * n_waves) {
+    const double th = poses[3 * k + 2];
+    double sn, cn;
+    sincos(th, &sn, &cn);
+    const double cost = eval_pose_wave<MODE, DUMP>(g, wn, bm, rec, pts, n, cn, sn, poses[3 * k], poses[3 * k + 1],
+                                                   DUMP ? dump + (size_t)k * n : nullptr);
+    if (lane_id() == 0) costs[k] = cost;
+  }
+}
+
+// ---- K2 --------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n, GridP g, WinP wn, Layout L,
+        PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
+        const int32_t* __restrict__ table, double* __restrict__ out_pose, double* __restrict__ out_cost,
+        AlignStats* __restrict__ stats) {
+  unsigned char* img = g_lds + L.image_off;
+  double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
+  copy_global_to_lds16(img, image, image_bytes(wn.n_words, wn.rec_cap));
+  copy_global_to_lds16(pts, xy, n * 16);
+  __syncthreads();
+  const uint2* bm = reinterpret_cast<const uint2*>(img + kImageHeaderBytes);
+  const Rec* rec = reinterpret_cast<const Rec*>(img + image_rec_offset(wn.n_words));
+  const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
+  pso_run_wg<MODE>(g, wn, bm, rec, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(), out_pose, out_cost, stats);
+  if (threadIdx.x == 0 && stats) {
+    const ImageHeader* h = reinterpret_cast<const ImageHeader*>(img);
+    stats->n_built = h->n_built;
+    stats->status = h->status;
+  }
+}
+
+// ---- fused scan pairs: K3a(ref) + K3b + K3a(new) + K2, everything in LDS -------------------------
+template <int MODE>
+__global__ void __launch_bounds__(1024)
+k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
+              Layout L, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev,
+              const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables, size_t table_stride,
+              double* __restrict__ out_pose, double* __restrict__ out_cost, AlignStats* __restrict__ stats) {
+  const size_t b = blockIdx.x;
+  unsigned char* img = g_lds + L.image_off;
+  double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
+
+  // reference frame <- scan A at identity (ndtpso_slam_node.cpp:186,198 for the first scan), then build
+  const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt());
+  __syncthreads();
+  build_table_wg(g, wn, pts, n_ref, img, reinterpret_cast<int*>(g_lds + L.key_off),
+                 reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
+                 reinterpret_cast<uint2*>(g_lds + L.bm2_off), nullptr, nullptr);
+  // new frame <- scan B (one-cell frame: just the point list, ndtpso_slam_node.cpp:229-230)
+  const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt());
+  __syncthreads();
+
+  const uint2* bm = reinterpret_cast<const uint2*>(img + kImageHeaderBytes);
+  const Rec* rec = reinterpret_cast<const Rec*>(img + image_rec_offset(wn.n_words));
+  const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
+  pso_run_wg<MODE>(g, wn, bm, rec, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                   tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(), out_pose + 3 * b,
+                   out_cost ? out_cost + b : nullptr, stats ? stats + b : nullptr);
+  if (threadIdx.x == 0 && stats) {
+    const ImageHeader* h = reinterpret_cast<const ImageHeader*>(img);
+    stats[b].n_built = h->n_built;
+    stats[b].status = h->status;
+  }
+}
+
+// =================================================================================================
+// host side
+// =================================================================================================
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct ndtpso_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  std::string err;
+  // reference table currently staged in HBM (image layout == LDS layout)
+  bool have_ref = false;
+  ndtpso_grid grid{};
+  GridP g{};
+  WinP wn{};
+  uint32_t n_rows = 0;
+  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds;
+};
+
+namespace {
+
+int fail(ndtpso_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+  do {                                                                                             \
+    hipError_t e__ = (expr);                                                                       \
+    if (e__ != hipSuccess)                                                                         \
+      return fail((ctx), NDTPSO_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));        \
+  } while (0)
+
+bool is_pow2_double(double v) {
+  int e;
+  return v > 0. && std::frexp(v, &e) == 0.5;
+}
+
+int make_grid(const ndtpso_grid* grid, GridP* g) {
+  if (!grid || !(grid->cell_side > 0.) || grid->width == 0 || grid->height == 0) return NDTPSO_E_ARG;
+  g->hw = grid->width / 2.;
+  g->hh = grid->height / 2.;
+  g->cs = grid->cell_side;
+  g->cs_pow2 = is_pow2_double(grid->cell_side) ? 1 : 0;
+  g->inv_cs = 1. / grid->cell_side;
+  g->W = (uint16_t)std::ceil(grid->width / grid->cell_side);   // ndtframe.cpp:27
+  g->H = (uint16_t)std::ceil(grid->height / grid->cell_side);  // ndtframe.cpp:28
+  return NDTPSO_OK;
+}
+
+// conservative staging window covering [xmin,xmax] x [ymin,ymax] (metres), clipped to the grid
+WinP make_window(const GridP& g, double xmin, double xmax, double ymin, double ymax, int rec_cap) {
+  auto cell = [&](double v, double h) { return (int)std::floor((v + h) / g.cs); };
+  int x0 = std::max(0, cell(xmin, g.hw) - 1), x1 = std::min(g.W - 1, cell(xmax, g.hw) + 1);
+  int y0 = std::max(0, cell(ymin, g.hh) - 1), y1 = std::min(g.H - 1, cell(ymax, g.hh) + 1);
+  if (x1 < x0) x1 = x0;
+  if (y1 < y0) y1 = y0;
+  WinP w;
+  w.x0 = x0;
+  w.y0 = y0;
+  w.w = x1 - x0 + 1;
+  w.h = y1 - y0 + 1;
+  w.n_words = (w.w * w.h + 31) / 32;
+  w.rec_cap = std::max(rec_cap, 1);
+  return w;
+}
+
+ScanP make_scan(const ndtpso_scan_geom* s) {
+  ScanP p;
+  p.n_beams = (int)s->n_beams;
+  p.amin = s->min_angle;
+  p.ainc = s->angle_increment;
+  p.rmax = s->max_range;
+  p.eps = s->laser_ignore_epsilon;
+  return p;
+}
+
+PsoP make_pso(const ndtpso_pso_config* c) {
+  PsoP p;
+  p.P = c->population;
+  p.I = c->iterations;
+  p.w = c->w;
+  p.c1 = c->c1;
+  p.c2 = c->c2;
+  p.wdamp = c->w_damping;
+  return p;
+}
+
+// waves per workgroup for the PSO kernels: the evaluation round hands one particle to one wave,
+// so pick the wave count (<= 16) that wastes the fewest wave-slots on P particles
+int pick_waves(int P) {
+  int best = 4;
+  double best_eff = 0.;
+  for (int w = 4; w <= 16; ++w) {
+    const int rounds = (P + w - 1) / w;
+    const double eff = (double)P / (double)(rounds * w);
+    if (eff > best_eff + 1e-9 || (std::fabs(eff - best_eff) <= 1e-9 && w > best)) {
+      best_eff = eff;
+      best = w;
+    }
+  }
+  return best;
+}
+
+bool trans_is_zero(const double t[3]) {  // Vector3d::isZero(1e-6), ndtframe.cpp:152
+  return std::fabs(t[0]) <= 1e-6 && std::fabs(t[1]) <= 1e-6 && std::fabs(t[2]) <= 1e-6;
+}
+
+template <typename K>
+hipError_t allow_big_lds(K kernel) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+}
+
+int check_pso(ndtpso_ctx* ctx, const ndtpso_pso_config* cfg) {
+  if (!cfg || cfg->population < 1 || cfg->iterations < 0) return fail(ctx, NDTPSO_E_ARG, "bad PSO config");
+  return NDTPSO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
+  if (!out) return NDTPSO_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return NDTPSO_E_HIP;
+  ndtpso_ctx* c = new ndtpso_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->own_stream) != hipSuccess) {
+    delete c;
+    return NDTPSO_E_HIP;
+  }
+  c->stream = c->own_stream;
+  hipError_t e = hipSuccess;
+  if (e == hipSuccess) e = allow_big_lds(k_build_table);
+  if (e == hipSuccess) e = allow_big_lds(k_cost_batch<kScoreF32, false>);
+  if (e == hipSuccess) e = allow_big_lds(k_cost_batch<kScoreF32, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_cost_batch<kScoreF64, false>);
+  if (e == hipSuccess) e = allow_big_lds(k_cost_batch<kScoreF64, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32>);
+  if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF64>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF64>);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return NDTPSO_E_HIP;
+  }
+  *out = c;
+  return NDTPSO_OK;
+}
+
+void ndtpso_ctx_destroy(ndtpso_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
+                    &c->small, &c->table, &c->out, &c->seeds})
+    b->release();
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* ndtpso_last_error(const ndtpso_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int ndtpso_set_stream(ndtpso_ctx* c, void* s) {
+  if (!c) return NDTPSO_E_ARG;
+  c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  return NDTPSO_OK;
+}
+
+int ndtpso_synchronize(ndtpso_ctx* c) {
+  if (!c) return NDTPSO_E_ARG;
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NDTPSO_OK;
+}
+
+size_t ndtpso_rand_draws(const ndtpso_pso_config* cfg) {
+  if (!cfg) return 0;
+  return 3u + 3u * (size_t)cfg->population + 6u * (size_t)cfg->population * (size_t)cfg->iterations;
+}
+
+// ---- K3 ------------------------------------------------------------------------------------------
+
+int ndtpso_scan_to_points(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_geom* geom, const double trans[3],
+                          double* xy_out, uint32_t* n_out) {
+  if (!c || !ranges || !geom || !xy_out || !n_out || geom->n_beams == 0) return fail(c, NDTPSO_E_ARG, "null argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t nb = geom->n_beams;
+  HIP_TRY(c, c->ranges.reserve(nb * 4));
+  HIP_TRY(c, c->xy.reserve(nb * 16));
+  HIP_TRY(c, c->small.reserve(256));
+  HIP_TRY(c, hipMemcpyAsync(c->ranges.p, ranges, nb * 4, hipMemcpyHostToDevice, c->stream));
+  const double zero[3] = {0., 0., 0.};
+  const double* t = trans ? trans : zero;
+  const int do_trans = trans_is_zero(t) ? 0 : 1;
+  hipLaunchKernelGGL(k_scan_to_points, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p,
+                     make_scan(geom), do_trans, std::cos(t[2]), std::sin(t[2]), t[0], t[1], (double2*)c->xy.p,
+                     (uint32_t*)c->small.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(n_out, c->small.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (*n_out) HIP_TRY(c, hipMemcpy(xy_out, c->xy.p, (size_t)*n_out * 16, hipMemcpyDeviceToHost));
+  return NDTPSO_OK;
+}
+
+static int build_from_device_points(ndtpso_ctx* c, const ndtpso_grid* grid, const GridP& g, const WinP& wn, int n) {
+  const Layout L = make_layout(wn.n_words, wn.rec_cap, std::max(n, 1), 0);
+  if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "reference table does not fit in LDS");
+  HIP_TRY(c, c->image.reserve(image_bytes(wn.n_words, wn.rec_cap)));
+  HIP_TRY(c, c->rows.reserve(sizeof(CellRow) * (size_t)std::max(n, 1)));
+  HIP_TRY(c, c->small.reserve(256));
+  hipLaunchKernelGGL(k_build_table, dim3(1), dim3(1024), L.total, c->stream, (const double2*)c->xy.p, n, g, wn, L,
+                     (unsigned char*)c->image.p, (CellRow*)c->rows.p, (uint32_t*)c->small.p);
+  HIP_TRY(c, hipGetLastError());
+  uint32_t n_rows = 0;
+  ImageHeader hdr;
+  HIP_TRY(c, hipMemcpyAsync(&n_rows, c->small.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(&hdr, c->image.p, sizeof(hdr), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (hdr.status & 1u) return fail(c, NDTPSO_E_CAPACITY, "a reference point fell outside the staging window");
+  if (hdr.status & 2u) return fail(c, NDTPSO_E_CAPACITY, "more built cells than record capacity");
+  c->grid = *grid;
+  c->g = g;
+  c->wn = wn;
+  c->n_rows = n_rows;
+  c->have_ref = true;
+  return NDTPSO_OK;
+}
+
+int ndtpso_ref_from_points(ndtpso_ctx* c, const ndtpso_grid* grid, const double* xy, uint32_t n) {
+  if (!c || !xy && n) return fail(c, NDTPSO_E_ARG, "null argument");
+  GridP g;
+  if (make_grid(grid, &g) != NDTPSO_OK) return fail(c, NDTPSO_E_ARG, "bad grid");
+  HIP_TRY(c, hipSetDevice(c->device));
+  double xmin = 0., xmax = 0., ymin = 0., ymax = 0.;
+  bool any = false;
+  for (uint32_t i = 0; i < n; ++i) {
+    const double x = xy[2 * i], y = xy[2 * i + 1];
+    if (!(std::fabs(x) < g.hw && std::fabs(y) < g.hh)) continue;  // dropped by addPoint anyway
+    if (!any) {
+      xmin = xmax = x;
+      ymin = ymax = y;
+      any = true;
+    } else {
+      xmin = std::min(xmin, x);
+      xmax = std::max(xmax, x);
+      ymin = std::min(ymin, y);
+      ymax = std::max(ymax, y);
+    }
+  }
+  const WinP wn = make_window(g, xmin, xmax, ymin, ymax, (int)(n / 3) + 1);
+  HIP_TRY(c, c->xy.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  return build_from_device_points(c, grid, g, wn, (int)n);
+}
+
+int ndtpso_ref_from_scan(ndtpso_ctx* c, const ndtpso_grid* grid, const float* ranges, const ndtpso_scan_geom* geom,
+                         const double trans[3]) {
+  if (!c || !ranges || !geom || geom->n_beams == 0) return fail(c, NDTPSO_E_ARG, "null argument");
+  GridP g;
+  if (make_grid(grid, &g) != NDTPSO_OK) return fail(c, NDTPSO_E_ARG, "bad grid");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const double zero[3] = {0., 0., 0.};
+  const double* t = trans ? trans : zero;
+  const size_t nb = geom->n_beams;
+  HIP_TRY(c, c->ranges.reserve(nb * 4));
+  HIP_TRY(c, c->xy.reserve(nb * 16));
+  HIP_TRY(c, c->small.reserve(256));
+  HIP_TRY(c, hipMemcpyAsync(c->ranges.p, ranges, nb * 4, hipMemcpyHostToDevice, c->stream));
+  const int do_trans = trans_is_zero(t) ? 0 : 1;
+  hipLaunchKernelGGL(k_scan_to_points, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p,
+                     make_scan(geom), do_trans, std::cos(t[2]), std::sin(t[2]), t[0], t[1], (double2*)c->xy.p,
+                     (uint32_t*)c->small.p);
+  HIP_TRY(c, hipGetLastError());
+  uint32_t n = 0;
+  HIP_TRY(c, hipMemcpyAsync(&n, c->small.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  const double r = (double)geom->max_range;
+  const double cx = do_trans ? t[0] : 0., cy = do_trans ? t[1] : 0.;
+  const WinP wn = make_window(g, cx - r, cx + r, cy - r, cy + r, (int)(n / 3) + 1);
+  return build_from_device_points(c, grid, g, wn, (int)n);
+}
+
+int ndtpso_ref_set_cells(ndtpso_ctx* c, const ndtpso_grid* grid, uint32_t n_cells, const int32_t* index,
+                         const double* mean, const double* icov) {
+  if (!c || (n_cells && (!index || !mean || !icov))) return fail(c, NDTPSO_E_ARG, "null argument");
+  GridP g;
+  if (make_grid(grid, &g) != NDTPSO_OK) return fail(c, NDTPSO_E_ARG, "bad grid");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+  for (uint32_t i = 0; i < n_cells; ++i) {
+    if (index[i] < 0 || index[i] >= g.W * g.H) return fail(c, NDTPSO_E_ARG, "cell index outside the grid");
+    const int ix = index[i] % g.W, iy = index[i] / g.W;
+    if (i == 0) {
+      x0 = x1 = ix;
+      y0 = y1 = iy;
+    } else {
+      x0 = std::min(x0, ix);
+      x1 = std::max(x1, ix);
+      y0 = std::min(y0, iy);
+      y1 = std::max(y1, iy);
+    }
+  }
+  WinP wn;
+  wn.x0 = x0;
+  wn.y0 = y0;
+  wn.w = x1 - x0 + 1;
+  wn.h = y1 - y0 + 1;
+  wn.n_words = (wn.w * wn.h + 31) / 32;
+  wn.rec_cap = std::max<int>((int)n_cells, 1);
+  const Layout L = make_layout(wn.n_words, wn.rec_cap, 1, 0);
+  if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "reference table does not fit in LDS");
+  // pack the LDS image on the host: bitmap words {bits, exclusive prefix}, records in ascending cell order
+  const size_t bytes = image_bytes(wn.n_words, wn.rec_cap);
+  std::vector<unsigned char> img(bytes, 0);
+  ImageHeader* hdr = reinterpret_cast<ImageHeader*>(img.data());
+  uint2* bm = reinterpret_cast<uint2*>(img.data() + kImageHeaderBytes);
+  Rec* rec = reinterpret_cast<Rec*>(img.data() + image_rec_offset(wn.n_words));
+  std::vector<std::pair<int, uint32_t>> order(n_cells);
+  for (uint32_t i = 0; i < n_cells; ++i) {
+    const int ix = index[i] % g.W, iy = index[i] / g.W;
+    const int k = (iy - wn.y0) * wn.w + (ix - wn.x0);
+    if ((bm[k >> 5].x >> (k & 31)) & 1u) return fail(c, NDTPSO_E_ARG, "duplicate cell index");
+    bm[k >> 5].x |= 1u << (k & 31);
+    order[i] = {k, i};
+  }
+  std::sort(order.begin(), order.end());
+  uint32_t run = 0;
+  for (int w = 0; w < wn.n_words; ++w) {
+    bm[w].y = run;
+    run += (uint32_t)__builtin_popcount(bm[w].x);
+  }
+  for (uint32_t s = 0; s < n_cells; ++s) {
+    const uint32_t i = order[s].second;
+    Rec& r = rec[s];
+    r.mx = mean[2 * i];
+    r.my = mean[2 * i + 1];
+    r.a = icov[4 * i];
+    r.b = icov[4 * i + 1];
+    r.c = icov[4 * i + 2];
+    r.d = icov[4 * i + 3];
+    const double kf = -0.72134752044448170368;
+    r.fa = (float)(kf * r.a);
+    r.fb = (float)(kf * (r.b + r.c));
+    r.fd = (float)(kf * r.d);
+    r.key = (uint32_t)order[s].first;
+  }
+  hdr->n_built = n_cells;
+  hdr->n_created = n_cells;
+  HIP_TRY(c, c->image.reserve(bytes));
+  HIP_TRY(c, hipMemcpyAsync(c->image.p, img.data(), bytes, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->grid = *grid;
+  c->g = g;
+  c->wn = wn;
+  c->n_rows = 0;
+  c->have_ref = true;
+  return NDTPSO_OK;
+}
+
+int ndtpso_ref_get_cells(ndtpso_ctx* c, ndtpso_cell_row* rows, uint32_t max_rows, uint32_t* n_rows) {
+  if (!c || !n_rows) return fail(c, NDTPSO_E_ARG, "null argument");
+  if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
+  *n_rows = c->n_rows;
+  const uint32_t n = std::min(max_rows, c->n_rows);
+  if (n && rows) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(rows, c->rows.p, sizeof(CellRow) * (size_t)n, hipMemcpyDeviceToHost));
+  }
+  return NDTPSO_OK;
+}
+
+// ---- K1 ------------------------------------------------------------------------------------------
+
+int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double* poses, uint32_t m, int mode,
+                      double* costs, int32_t* cell_idx) {
+  if (!c || (!xy && n) || !poses || !costs || m == 0) return fail(c, NDTPSO_E_ARG, "null argument");
+  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
+  if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const Layout L = make_layout(c->wn.n_words, c->wn.rec_cap, std::max<int>((int)n, 1), 0);
+  if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "table + points do not fit in LDS");
+  HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
+  HIP_TRY(c, c->poses.reserve((size_t)m * 24));
+  HIP_TRY(c, c->costs.reserve((size_t)m * 8));
+  if (cell_idx) HIP_TRY(c, c->dump.reserve((size_t)m * std::max<uint32_t>(n, 1) * 4));
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->poses.p, poses, (size_t)m * 24, hipMemcpyHostToDevice, c->stream));
+  const int waves = 16;
+  const int grid = (int)std::min<uint32_t>((m + waves - 1) / waves, 512u);
+#define LAUNCH_COST(MODE, DUMP)                                                                                   \
+  hipLaunchKernelGGL((k_cost_batch<MODE, DUMP>), dim3(grid), dim3(waves * 64), L.total, c->stream,                \
+                     (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L,          \
+                     (const double*)c->poses.p, (int)m, (double*)c->costs.p, (int32_t*)c->dump.p)
+  if (mode == NDTPSO_SCORE_F32) {
+    if (cell_idx) LAUNCH_COST(kScoreF32, true); else LAUNCH_COST(kScoreF32, false);
+  } else {
+    if (cell_idx) LAUNCH_COST(kScoreF64, true); else LAUNCH_COST(kScoreF64, false);
+  }
+#undef LAUNCH_COST
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(costs, c->costs.p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
+  if (cell_idx && n) HIP_TRY(c, hipMemcpyAsync(cell_idx, c->dump.p, (size_t)m * n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NDTPSO_OK;
+}
+
+// ---- K2 ------------------------------------------------------------------------------------------
+
+int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess[3], const double deviation[3],
+                 const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
+                 double* out_cost, ndtpso_align_stats* stats) {
+  if (!c || (!xy && n) || !guess || !deviation || !out_pose) return fail(c, NDTPSO_E_ARG, "null argument");
+  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
+  if (int rc = check_pso(c, cfg)) return rc;
+  if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const Layout L = make_layout(c->wn.n_words, c->wn.rec_cap, std::max<int>((int)n, 1), cfg->population);
+  if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "table + points + swarm do not fit in LDS");
+  const size_t n_draw = ndtpso_rand_draws(cfg);
+  HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
+  HIP_TRY(c, c->small.reserve(256));
+  HIP_TRY(c, c->out.reserve(256));
+  if (rand_table) HIP_TRY(c, c->table.reserve(n_draw * 4));
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  double gd[6] = {guess[0], guess[1], guess[2], deviation[0], deviation[1], deviation[2]};
+  HIP_TRY(c, hipMemcpyAsync(c->small.p, gd, sizeof(gd), hipMemcpyHostToDevice, c->stream));
+  if (rand_table) HIP_TRY(c, hipMemcpyAsync(c->table.p, rand_table, n_draw * 4, hipMemcpyHostToDevice, c->stream));
+  double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
+  AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
+  HIP_TRY(c, hipMemsetAsync(c->out.p, 0, 256, c->stream));
+  const int waves = pick_waves(cfg->population);
+  const PsoP ps = make_pso(cfg);
+#define LAUNCH_ALIGN(MODE)                                                                                         \
+  hipLaunchKernelGGL((k_align<MODE>), dim3(1), dim3(waves * 64), L.total, c->stream, (const unsigned char*)c->image.p, \
+                     (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, ps, (const double*)c->small.p,             \
+                     (const double*)c->small.p + 3, seed, rand_table ? (const int32_t*)c->table.p : nullptr, d_out, \
+                     d_out + 3, d_stats)
+  if (mode == NDTPSO_SCORE_F32) LAUNCH_ALIGN(kScoreF32); else LAUNCH_ALIGN(kScoreF64);
+#undef LAUNCH_ALIGN
+  HIP_TRY(c, hipGetLastError());
+  double host[4 + sizeof(AlignStats) / 8];
+  HIP_TRY(c, hipMemcpyAsync(host, c->out.p, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  out_pose[0] = host[0];
+  out_pose[1] = host[1];
+  out_pose[2] = host[2];
+  if (out_cost) *out_cost = host[3];
+  if (stats) std::memcpy(stats, host + 4, sizeof(AlignStats));
+  return NDTPSO_OK;
+}
+
+// ---- fused pairs -----------------------------------------------------------------------------------
+
+static int pairs_plan(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg, GridP* g,
+                      WinP* wn, Layout* L, int* waves) {
+  if (!geom || geom->n_beams == 0 || !cfg || cfg->population < 1 || cfg->iterations < 0) return NDTPSO_E_ARG;
+  if (make_grid(grid, g) != NDTPSO_OK) return NDTPSO_E_ARG;
+  const double r = (double)geom->max_range;
+  *wn = make_window(*g, -r, r, -r, r, (int)(geom->n_beams / 3) + 1);
+  *L = make_layout(wn->n_words, wn->rec_cap, (int)geom->n_beams, cfg->population);
+  *waves = pick_waves(cfg->population);
+  return (L->total > kMaxLds) ? NDTPSO_E_CAPACITY : NDTPSO_OK;
+}
+
+int ndtpso_align_pairs_footprint(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg,
+                                 uint32_t* lds_bytes, uint32_t* block_threads) {
+  GridP g;
+  WinP wn;
+  Layout L;
+  int waves = 0;
+  const int rc = pairs_plan(geom, grid, cfg, &g, &wn, &L, &waves);
+  if (rc == NDTPSO_E_ARG) return rc;
+  if (lds_bytes) *lds_bytes = (rc == NDTPSO_OK) ? (uint32_t)L.total : 0u;
+  if (block_threads) *block_threads = (uint32_t)waves * 64u;
+  return rc;
+}
+
+int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, const float* d_new,
+                           const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess,
+                           const double* d_dev, const ndtpso_pso_config* cfg, const uint32_t* d_seeds,
+                           const int32_t* d_tables, int mode, double* d_pose, double* d_cost,
+                           ndtpso_align_stats* d_stats) {
+  if (!c || !d_ref || !d_new || !d_guess || !d_dev || !d_pose || (!d_seeds && !d_tables))
+    return fail(c, NDTPSO_E_ARG, "null argument");
+  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
+  if (n_pairs == 0) return NDTPSO_OK;
+  GridP g;
+  WinP wn;
+  Layout L;
+  int waves = 0;
+  const int rc = pairs_plan(geom, grid, cfg, &g, &wn, &L, &waves);
+  if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
+  if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const ScanP sp = make_scan(geom);
+  const PsoP ps = make_pso(cfg);
+  const size_t stride = ndtpso_rand_draws(cfg);
+#define LAUNCH_PAIRS(MODE)                                                                                        \
+  hipLaunchKernelGGL((k_align_pairs<MODE>), dim3(n_pairs), dim3(waves * 64), L.total, c->stream, d_ref, d_new, sp, g, \
+                     wn, L, ps, d_guess, d_dev, d_seeds, d_tables, stride, d_pose, d_cost,                         \
+                     reinterpret_cast<AlignStats*>(d_stats))
+  if (mode == NDTPSO_SCORE_F32) LAUNCH_PAIRS(kScoreF32); else LAUNCH_PAIRS(kScoreF64);
+#undef LAUNCH_PAIRS
+  HIP_TRY(c, hipGetLastError());
+  return NDTPSO_OK;
+}
+
+int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges, const float* new_ranges,
+                       const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* guess,
+                       const double* deviation, const ndtpso_pso_config* cfg, const uint32_t* seeds,
+                       const int32_t* rand_tables, int mode, double* out_pose, double* out_cost,
+                       ndtpso_align_stats* stats) {
+  if (!c || !ref_ranges || !new_ranges || !geom || !guess || !deviation || !out_pose || (!seeds && !rand_tables))
+    return fail(c, NDTPSO_E_ARG, "null argument");
+  if (int rc = check_pso(c, cfg)) return rc;
+  if (n_pairs == 0) return NDTPSO_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t B = n_pairs, nb = geom->n_beams, n_draw = ndtpso_rand_draws(cfg);
+  HIP_TRY(c, c->ranges.reserve(B * nb * 4));
+  HIP_TRY(c, c->ranges2.reserve(B * nb * 4));
+  HIP_TRY(c, c->poses.reserve(B * 48));
+  HIP_TRY(c, c->out.reserve(B * (32 + sizeof(AlignStats))));
+  HIP_TRY(c, c->seeds.reserve(B * 4));
+  if (rand_tables) HIP_TRY(c, c->table.reserve(B * n_draw * 4));
+  HIP_TRY(c, hipMemcpyAsync(c->ranges.p, ref_ranges, B * nb * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->ranges2.p, new_ranges, B * nb * 4, hipMemcpyHostToDevice, c->stream));
+  double* d_guess = (double*)c->poses.p;
+  double* d_dev = d_guess + 3 * B;
+  HIP_TRY(c, hipMemcpyAsync(d_guess, guess, B * 24, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_dev, deviation, B * 24, hipMemcpyHostToDevice, c->stream));
+  if (seeds) HIP_TRY(c, hipMemcpyAsync(c->seeds.p, seeds, B * 4, hipMemcpyHostToDevice, c->stream));
+  if (rand_tables) HIP_TRY(c, hipMemcpyAsync(c->table.p, rand_tables, B * n_draw * 4, hipMemcpyHostToDevice, c->stream));
+  double* d_pose = (double*)c->out.p;
+  double* d_cost = d_pose + 3 * B;
+  ndtpso_align_stats* d_stats = reinterpret_cast<ndtpso_align_stats*>(d_cost + B);
+  HIP_TRY(c, hipMemsetAsync(c->out.p, 0, B * (32 + sizeof(AlignStats)), c->stream));
+  const int rc = ndtpso_align_pairs_dev(c, n_pairs, (const float*)c->ranges.p, (const float*)c->ranges2.p, geom, grid,
+                                        d_guess, d_dev, cfg, seeds ? (const uint32_t*)c->seeds.p : nullptr,
+                                        rand_tables ? (const int32_t*)c->table.p : nullptr, mode, d_pose, d_cost,
+                                        d_stats);
+  if (rc != NDTPSO_OK) return rc;
+  HIP_TRY(c, hipMemcpyAsync(out_pose, d_pose, B * 24, hipMemcpyDeviceToHost, c->stream));
+  if (out_cost) HIP_TRY(c, hipMemcpyAsync(out_cost, d_cost, B * 8, hipMemcpyDeviceToHost, c->stream));
+  if (stats) HIP_TRY(c, hipMemcpyAsync(stats, d_stats, B * sizeof(AlignStats), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NDTPSO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu() -> bool:
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+# the BASELINE sensor / grid / PSO configuration (configs 1-4)
+FRAME_M = 60
+CELL_SIDE = 0.5
+DEVIATION = (0.1, 0.1, 3.1415e-3)   # NDTFrame::align's first-call deviation, ndtframe.cpp:253
+
+
+@pytest.fixture(scope="session")
+def pairs8():
+    from ndtpso_slam_amd import synth
+    return synth.make_pairs(8, seed=7)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import pyoracle
+    pyoracle.lib()
+    return pyoracle
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    from ndtpso_slam_amd import capi
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def oracle_frames(oracle, p, b, cell_side=CELL_SIDE, frame=FRAME_M):
+    ref = oracle.Frame((0, 0, 0), frame, frame, cell_side)
+    ref.load_laser(p.ref_ranges[b], p.angle_min, p.angle_inc, p.range_max)
+    new = oracle.Frame((0, 0, 0), frame, frame, float(frame))
+    new.load_laser(p.new_ranges[b], p.angle_min, p.angle_inc, p.range_max)
+    return ref, new

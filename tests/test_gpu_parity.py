@@ -1,0 +1,157 @@
+"""HIP path vs the CPU oracle, through the C-ABI (ctypes).  -m gpu."""
+import numpy as np
+import pytest
+
+from conftest import CELL_SIDE, DEVIATION, FRAME_M, oracle_frames
+
+pytestmark = pytest.mark.gpu
+
+
+def _geom(p, capi):
+    return capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+
+
+def _grid(capi, cs=CELL_SIDE, frame=FRAME_M):
+    return capi.Grid(frame, frame, cs)
+
+
+def test_scan_to_points_matches_oracle(ctx, oracle, pairs8):
+    """K3a vs NDTFrame::loadLaser restatement: same survivors, same order, xy within a few ulp
+    (device sincos vs glibc sin/cos)."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    r = p.new_ranges[0].copy()
+    r[::37] = 0.0          # misses
+    r[5] = 0.05            # below laserIgnoreEpsilon
+    r[6] = 0.1             # == epsilon (fp32 0.1f): rejected by the strict >
+    r[7] = 30.0            # == max_range: rejected
+    r[8] = 45.0
+    r[9] = -1.0
+    r[10] = np.float32(0.1) + np.float32(1e-6)
+    for trans in [(0, 0, 0), (1.5, -2.25, 0.3)]:
+        of = oracle.Frame(trans, FRAME_M, FRAME_M, float(FRAME_M))
+        of.load_laser(r, p.angle_min, p.angle_inc, p.range_max)
+        want = of.points()
+        got = ctx.scan_to_points(r, _geom(p, capi), trans)
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 5e-14
+
+
+def test_cell_table_matches_oracle_bitwise_on_identical_points(ctx, oracle, pairs8):
+    """K3b fed the oracle's own fp64 points: cell membership, counts, built flags exact; mean and
+    inverse covariance identical (same operation order, no contraction)."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    for cs in (0.5, 0.25, 0.3):
+        ref, _ = oracle_frames(oracle, p, 1, cell_side=cs)
+        pts = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+        pts.load_laser(p.ref_ranges[1], p.angle_min, p.angle_inc, p.range_max)
+        xy = pts.points()
+        ref.build()
+        want = ref.cells()
+        ctx.ref_from_points(_grid(capi, cs), xy)
+        got = ctx.ref_get_cells()
+        assert [c["index"] for c in got] == [c["index"] for c in want]
+        assert [c["count"] for c in got] == [c["count"] for c in want]
+        assert [c["built"] for c in got] == [c["built"] for c in want]
+        for g, w in zip(got, want):
+            if w["built"]:
+                assert np.array_equal(g["mean"], w["mean"])
+                np.testing.assert_allclose(g["icov"], w["icov"], rtol=1e-13, atol=0)
+
+
+def test_cell_table_from_scan(ctx, oracle, pairs8):
+    """K3a+K3b from raw ranges: membership/counts/built exact, statistics to 1e-9 relative."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    ref, _ = oracle_frames(oracle, p, 2)
+    ref.build()
+    want = ref.cells()
+    ctx.ref_from_scan(_grid(capi), p.ref_ranges[2], _geom(p, capi))
+    got = ctx.ref_get_cells()
+    assert [(c["index"], c["count"], c["built"]) for c in got] == [(c["index"], c["count"], c["built"]) for c in want]
+    for g, w in zip(got, want):
+        if w["built"]:
+            np.testing.assert_allclose(g["mean"], w["mean"], rtol=0, atol=1e-13)
+            np.testing.assert_allclose(g["icov"], w["icov"], rtol=1e-8, atol=1e-6)
+
+
+@pytest.mark.parametrize("cs", [0.5, 0.3])
+def test_cost_batch_matches_oracle(ctx, oracle, pairs8, cs):
+    """K1 vs cost_function: identical cell membership for every point of every pose; fp64 score to
+    1e-9, fp32 score to 1e-4*N."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    ref, new = oracle_frames(oracle, p, 3, cell_side=cs)
+    xy = new.points()
+    rng = np.random.default_rng(5)
+    poses = p.delta[3] + rng.uniform(-1, 1, (300, 3)) * np.array([0.15, 0.15, 0.03])
+    poses[0] = 0.0
+    want_c = np.empty(len(poses))
+    want_i = np.empty((len(poses), len(xy)), dtype=np.int32)
+    for k, q in enumerate(poses):
+        want_c[k], want_i[k] = ref.cost(q, new, want_cells=True)
+    ctx.ref_from_points(_grid(capi, cs), oracle_frames(oracle, p, 3, cell_side=float(FRAME_M))[0].points())
+    c64, i64 = ctx.cost_batch(xy, poses, capi.SCORE_F64, want_cells=True)
+    c32, i32 = ctx.cost_batch(xy, poses, capi.SCORE_F32, want_cells=True)
+    assert np.array_equal(i64, want_i)
+    assert np.array_equal(i32, want_i)
+    assert np.abs(c64 - want_c).max() < 1e-9
+    assert np.abs(c32 - want_c).max() < 1e-4 * len(xy)
+    print("max |dcost| f64 %.3e  f32 %.3e" % (np.abs(c64 - want_c).max(), np.abs(c32 - want_c).max()))
+    # no-dump kernels give the same numbers
+    assert np.array_equal(ctx.cost_batch(xy, poses, capi.SCORE_F64), c64)
+    assert np.array_equal(ctx.cost_batch(xy, poses, capi.SCORE_F32), c32)
+
+
+@pytest.mark.parametrize("P,I", [(30, 50), (70, 70)])
+def test_align_matches_oracle_pose(ctx, oracle, pairs8, P, I):
+    """K2 vs pso_optimization on the same rand() stream: pose within 1e-3 m / 1e-3 rad (BASELINE);
+    the fp64 score mode is expected to reproduce the trajectory exactly."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    ocfg = oracle.PSOConfig.make(I, P)
+    cfg = capi.PSOConfig.make(I, P)
+    worst = {capi.SCORE_F64: 0.0, capi.SCORE_F32: 0.0}
+    for b in range(4):
+        ref, new = oracle_frames(oracle, p, b)
+        want, want_cost, st = ref.pso((0, 0, 0), new, DEVIATION, ocfg, seed=int(p.seeds[b]))
+        ctx.ref_from_scan(_grid(capi), p.ref_ranges[b], _geom(p, capi))
+        xy = new.points()
+        table = oracle.glibc_rand(int(p.seeds[b]), 3 + 3 * P + 6 * P * I)
+        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+            got, cost, gst = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, rand_table=table, mode=mode)
+            d = np.abs(got - want)
+            worst[mode] = max(worst[mode], d.max())
+            assert d[0] < 1e-3 and d[1] < 1e-3 and d[2] < 1e-3, (b, mode, got, want)
+            assert gst["cost_evals"] >= 1 + P + P * I
+            # device-side srand(seed) replay == host table
+            got2, cost2, _ = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, seed=int(p.seeds[b]), mode=mode)
+            assert np.array_equal(got, got2) and cost == cost2
+        got64, cost64, gst = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, rand_table=table, mode=capi.SCORE_F64)
+        assert np.abs(got64 - want).max() < 1e-9, (got64, want)
+        assert abs(cost64 - want_cost) < 1e-9
+        assert gst["gbest_updates"] == st["gbest_updates"]
+    print("worst |dpose| f64 %.3e f32 %.3e" % (worst[capi.SCORE_F64], worst[capi.SCORE_F32]))
+
+
+def test_align_pairs_fused_matches_oracle(ctx, oracle, pairs8):
+    """Fused K3+K2 batch vs the oracle's batch, both score modes, 70x70."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    P, I = 70, 70
+    want, want_cost, _ = oracle.align_pairs(p.ref_ranges, p.new_ranges, p.angle_min, p.angle_inc, p.range_max, 0.1,
+                                            FRAME_M, FRAME_M, CELL_SIDE, (0, 0, 0), DEVIATION,
+                                            oracle.PSOConfig.make(I, P), p.seeds)
+    for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        got, cost, stats = ctx.align_pairs(p.ref_ranges, p.new_ranges, _geom(p, capi), _grid(capi), (0, 0, 0),
+                                           DEVIATION, capi.PSOConfig.make(I, P), seeds=p.seeds, mode=mode)
+        assert (stats["status"] == 0).all()
+        d = np.abs(got - want)
+        print("mode", mode, "max |dpose|", d.max(axis=0), "evals", stats["cost_evals"])
+        assert (d < 1e-3).all()
+        if mode == capi.SCORE_F64:
+            assert d.max() < 1e-9
+            assert np.abs(cost - want_cost).max() < 1e-9
+    # accuracy vs ground truth is the reference's own (a few mm)
+    assert np.abs(got - p.delta).max() < 2e-2
