@@ -77,8 +77,8 @@ def load(build_if_missing: bool = True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB
-    if build_if_missing and _build.needs_build():
+    path = os.environ.get("NDTPSO_LIB") or _build.LIB   # NDTPSO_LIB: kernel-variant experiments
+    if path == _build.LIB and build_if_missing and _build.needs_build():
         _build.build_hip()
     if not os.path.exists(path):
         raise NdtpsoError(E_HIP, f"{path} is missing: build it with `python -m ndtpso_slam_amd.build`")

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -19,28 +20,75 @@ static_assert(sizeof(AlignStats) == sizeof(ndtpso_align_stats), "stats ABI");
 namespace {
 
 constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
-constexpr int kCtrlBytes = 512;      // control block (PsoShared + compaction counters) at LDS offset 0
+constexpr int kCtrlBytes = 512;      // control block (PsoShared + compaction counters)
 
-// LDS layout shared by every kernel: [ctrl | image | pts | region], region = max(build scratch, swarm)
+// LDS layout shared by every kernel.
+//   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
+//                header..chol are contiguous exactly as in the HBM image
+//   dense form : [u16 cell table @0 | ctrl | DenseRec[cap+1] | header | points | region]
+//   region = max(table-build scratch {key, cellkey, cnt, bm2, (bm)}, swarm)
 struct Layout {
-  int image_off, pts_off, region_off, total;
+  int ctrl_off, hdr_off, bm_off, mean_off, ab_off, cd_off, chol_off, drec_off, pts_off, region_off, total;
   int key_off, cellkey_off, cnt_off, bm2_off;  // build scratch inside region
 };
 
-Layout make_layout(int n_words, int rec_cap, int n_max, int P) {
+// fmt: kScoreF32 -> mean+chol, kScoreF64 -> mean+ab+cd, 2 -> everything (table build kernel);
+// ddw > 0: dense form with a ddw x ddh cell table (fp32 score only)
+Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw = 0, int ddh = 0) {
   Layout L;
-  L.image_off = kCtrlBytes;
-  L.pts_off = L.image_off + align16(image_bytes(n_words, rec_cap));
-  L.region_off = L.pts_off + align16(n_max * 16);
+  const bool dense = ddw > 0;
+  int off = dense ? dense_tab_bytes(ddw, ddh) : 0;
+  L.ctrl_off = off;
+  off += kCtrlBytes;
+  L.drec_off = -1;
+  if (dense) {
+    L.drec_off = off;
+    off += 32 * (rec_cap + 1);
+  }
+  L.hdr_off = off;
+  off += kImageHeaderBytes;
+  L.bm_off = L.mean_off = L.ab_off = L.cd_off = L.chol_off = -1;
+  if (!dense) {
+    L.bm_off = off;
+    off += align16(n_words * 8);
+    L.mean_off = off;
+    off += 16 * rec_cap;
+    if (fmt == kScoreF64 || fmt == 2) {
+      L.ab_off = off;
+      L.cd_off = off + 16 * rec_cap;
+      off += 32 * rec_cap;
+    }
+    if (fmt == kScoreF32 || fmt == 2) {
+      L.chol_off = off;
+      off += 16 * rec_cap;
+    }
+  }
+  L.pts_off = off;
+  off += round_up(n_max, kPointPad) * 16;
+  L.region_off = off;
   const int ints = align16(n_max * 4);
   L.key_off = L.region_off;
   L.cellkey_off = L.key_off + ints;
   L.cnt_off = L.cellkey_off + ints;
   L.bm2_off = L.cnt_off + ints;
-  const int scratch = 3 * ints + align16(n_words * 8);
+  int scratch = 3 * ints + align16(n_words * 8);
+  if (dense) {  // the built-cell bitmap is only needed while the table is being built
+    L.bm_off = L.region_off + scratch;
+    scratch += align16(n_words * 8);
+  }
   const int swarm = (P > 0) ? swarm_bytes(P) : 0;
   L.total = L.region_off + std::max(scratch, swarm);
   return L;
+}
+
+DenseP make_dense(const WinP& wn, const Layout& L) {
+  DenseP d;
+  d.dw = wn.w + 1;
+  d.dh = wn.h + 1;
+  d.ox = wn.x0 - 1;
+  d.oy = wn.y0 - 1;
+  d.rec_off = L.drec_off;
+  return d;
 }
 
 }  // namespace
@@ -49,14 +97,59 @@ static_assert(sizeof(PsoShared) + 32 * sizeof(int) <= kCtrlBytes, "control block
 
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
-__device__ __forceinline__ PsoShared* lds_ctrl() { return reinterpret_cast<PsoShared*>(g_lds); }
-__device__ __forceinline__ int* lds_cnt() { return reinterpret_cast<int*>(g_lds + sizeof(PsoShared)); }
+__device__ __forceinline__ PsoShared* lds_ctrl(int ctrl_off) { return reinterpret_cast<PsoShared*>(g_lds + ctrl_off); }
+__device__ __forceinline__ int* lds_cnt(int ctrl_off) {
+  return reinterpret_cast<int*>(g_lds + ctrl_off + sizeof(PsoShared));
+}
 
-__device__ __forceinline__ void copy_global_to_lds16(void* dst, const void* src, int bytes) {
+__device__ __forceinline__ void copy16(void* dst, const void* src, int bytes) {
   // bytes is a multiple of 16; 16 B per lane, consecutive lanes consecutive addresses (coalesced)
   const uint4* s = reinterpret_cast<const uint4*>(src);
   uint4* d = reinterpret_cast<uint4*>(dst);
   for (int i = threadIdx.x; i < (bytes >> 4); i += blockDim.x) d[i] = s[i];
+}
+
+__device__ __forceinline__ TableView lds_table_view(const Layout& L) {
+  TableView T;
+  T.bm = L.bm_off >= 0 ? reinterpret_cast<const uint2*>(g_lds + L.bm_off) : nullptr;
+  T.mean = L.mean_off >= 0 ? reinterpret_cast<const double2*>(g_lds + L.mean_off) : nullptr;
+  T.ab = L.ab_off >= 0 ? reinterpret_cast<const double2*>(g_lds + L.ab_off) : nullptr;
+  T.cd = L.cd_off >= 0 ? reinterpret_cast<const double2*>(g_lds + L.cd_off) : nullptr;
+  T.chol = L.chol_off >= 0 ? reinterpret_cast<const float4*>(g_lds + L.chol_off) : nullptr;
+  return T;
+}
+__device__ __forceinline__ TableOut lds_table_out(const Layout& L) {
+  TableOut T;
+  T.bm = reinterpret_cast<uint2*>(g_lds + L.bm_off);
+  T.mean = L.mean_off >= 0 ? reinterpret_cast<double2*>(g_lds + L.mean_off) : nullptr;
+  T.ab = L.ab_off >= 0 ? reinterpret_cast<double2*>(g_lds + L.ab_off) : nullptr;
+  T.cd = L.cd_off >= 0 ? reinterpret_cast<double2*>(g_lds + L.cd_off) : nullptr;
+  T.chol = L.chol_off >= 0 ? reinterpret_cast<float4*>(g_lds + L.chol_off) : nullptr;
+  return T;
+}
+__device__ __forceinline__ EvalCtx make_eval_ctx(const GridP& g, const WinP& wn, const Layout& L, const DenseP& dn) {
+  EvalCtx E;
+  E.g = g;
+  E.wn = wn;
+  E.T = lds_table_view(L);
+  E.dn = dn;
+  E.lds0 = g_lds;
+  return E;
+}
+
+// stage a table image (HBM) into LDS in the form the kernel's PATH wants
+template <int MODE, int PATH>
+__device__ __forceinline__ void stage_image(const unsigned char* __restrict__ image, const GridP& g, const WinP& wn,
+                                            const Layout& L, const DenseP& dn) {
+  if constexpr (PATH == 2) {
+    copy16(g_lds + L.hdr_off, image, kImageHeaderBytes);
+    dense_from_image_wg(g, wn, image, dn, g_lds);
+  } else if constexpr (MODE == kScoreF64) {
+    copy16(g_lds + L.hdr_off, image, image_chol_offset(wn.n_words, wn.rec_cap));  // header .. cd, contiguous
+  } else {
+    copy16(g_lds + L.hdr_off, image, image_ab_offset(wn.n_words, wn.rec_cap));  // header .. mean
+    copy16(g_lds + L.chol_off, image + image_chol_offset(wn.n_words, wn.rec_cap), 16 * wn.rec_cap);
+  }
 }
 
 // ---- K3a -------------------------------------------------------------------------------------
@@ -65,7 +158,7 @@ k_scan_to_points(const float* __restrict__ ranges, ScanP sp, int do_trans, doubl
                  double tty, double2* __restrict__ out_xy, uint32_t* __restrict__ out_n) {
   const size_t b = blockIdx.x;
   const int n = scan_to_points_wg(ranges + b * sp.n_beams, sp, do_trans != 0, tc, ts, ttx, tty,
-                                  out_xy + b * sp.n_beams, lds_cnt());
+                                  out_xy + b * sp.n_beams, lds_cnt(0));
   if (threadIdx.x == 0) out_n[b] = (uint32_t)n;
 }
 
@@ -74,92 +167,96 @@ __global__ void __launch_bounds__(1024)
 k_build_table(const double2* __restrict__ xy, int n, GridP g, WinP wn, Layout L, unsigned char* __restrict__ image_out,
               CellRow* __restrict__ rows, uint32_t* __restrict__ n_rows) {
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
-  copy_global_to_lds16(pts, xy, n * 16);
+  copy16(pts, xy, n * 16);
   __syncthreads();
-  build_table_wg(g, wn, pts, n, g_lds + L.image_off, reinterpret_cast<int*>(g_lds + L.key_off),
-                 reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
-                 reinterpret_cast<uint2*>(g_lds + L.bm2_off), rows, n_rows);
-  copy_global_to_lds16(image_out, g_lds + L.image_off, image_bytes(wn.n_words, wn.rec_cap));  // LDS -> global
+  build_table_wg(g, wn, pts, n, reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off), lds_table_out(L),
+                 reinterpret_cast<int*>(g_lds + L.key_off), reinterpret_cast<int*>(g_lds + L.cellkey_off),
+                 reinterpret_cast<int*>(g_lds + L.cnt_off), reinterpret_cast<uint2*>(g_lds + L.bm2_off), rows, n_rows,
+                 nullptr, nullptr);
+  // LDS -> HBM image (fmt 2 layout == image layout)
+  copy16(image_out, g_lds + L.hdr_off, image_bytes(wn.n_words, wn.rec_cap));
 }
 
 // ---- K1 --------------------------------------------------------------------------------------
-template <int MODE, bool DUMP>
+template <int MODE, int PATH, bool DUMP>
 __global__ void __launch_bounds__(1024)
 k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n, GridP g, WinP wn,
-             Layout L, const double* __restrict__ poses, int m, double* __restrict__ costs,
+             Layout L, DenseP dn, const double* __restrict__ poses, int m, double* __restrict__ costs,
              int32_t* __restrict__ dump) {
-  unsigned char* img = g_lds + L.image_off;
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
-  copy_global_to_lds16(img, image, image_bytes(wn.n_words, wn.rec_cap));
-  copy_global_to_lds16(pts, xy, n * 16);
+  stage_image<MODE, PATH>(image, g, wn, L, dn);
+  copy16(pts, xy, n * 16);
+  pad_points_wg(pts, n);
   __syncthreads();
-  const uint2* bm = reinterpret_cast<const uint2*>(img + kImageHeaderBytes);
-  const Rec* rec = reinterpret_cast<const Rec*>(img + image_rec_offset(wn.n_words));
+  const EvalCtx E = make_eval_ctx(g, wn, L, dn);
   const int n_waves = blockDim.x >> 6;
   for (int k = blockIdx.x * n_waves + wave_id(); k < m; k += gridDim.x * n_waves) {
     const double th = poses[3 * k + 2];
     double sn, cn;
     sincos(th, &sn, &cn);
-    const double cost = eval_pose_wave<MODE, DUMP>(g, wn, bm, rec, pts, n, cn, sn, poses[3 * k], poses[3 * k + 1],
-                                                   DUMP ? dump + (size_t)k * n : nullptr);
+    const double tx = poses[3 * k], ty = poses[3 * k + 1];
+    int32_t* dp = DUMP ? dump + (size_t)k * n : nullptr;
+    double cost;
+    if constexpr (PATH == 2)
+      cost = eval_pose_wave_dense<DUMP>(E.g, E.dn, E.lds0, pts, n, cn, sn, tx, ty, dp);
+    else
+      cost = eval_pose_wave_t<MODE, PATH == 1, DUMP>(E.g, E.wn, E.T, pts, n, cn, sn, tx, ty, dp);
     if (lane_id() == 0) costs[k] = cost;
   }
 }
 
 // ---- K2 --------------------------------------------------------------------------------------
-template <int MODE>
+template <int MODE, int PATH>
 __global__ void __launch_bounds__(1024)
 k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n, GridP g, WinP wn, Layout L,
-        PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
+        DenseP dn, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
         const int32_t* __restrict__ table, double* __restrict__ out_pose, double* __restrict__ out_cost,
         AlignStats* __restrict__ stats) {
-  unsigned char* img = g_lds + L.image_off;
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
-  copy_global_to_lds16(img, image, image_bytes(wn.n_words, wn.rec_cap));
-  copy_global_to_lds16(pts, xy, n * 16);
+  stage_image<MODE, PATH>(image, g, wn, L, dn);
+  copy16(pts, xy, n * 16);
+  pad_points_wg(pts, n);
   __syncthreads();
-  const uint2* bm = reinterpret_cast<const uint2*>(img + kImageHeaderBytes);
-  const Rec* rec = reinterpret_cast<const Rec*>(img + image_rec_offset(wn.n_words));
+  const EvalCtx E = make_eval_ctx(g, wn, L, dn);
   const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
-  pso_run_wg<MODE>(g, wn, bm, rec, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(), out_pose, out_cost, stats);
+  pso_run_wg<MODE, PATH>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost, stats);
   if (threadIdx.x == 0 && stats) {
-    const ImageHeader* h = reinterpret_cast<const ImageHeader*>(img);
+    const ImageHeader* h = reinterpret_cast<const ImageHeader*>(g_lds + L.hdr_off);
     stats->n_built = h->n_built;
     stats->status = h->status;
   }
 }
 
 // ---- fused scan pairs: K3a(ref) + K3b + K3a(new) + K2, everything in LDS -------------------------
-template <int MODE>
+template <int MODE, int PATH>
 __global__ void __launch_bounds__(1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
-              Layout L, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev,
+              Layout L, DenseP dn, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev,
               const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables, size_t table_stride,
               double* __restrict__ out_pose, double* __restrict__ out_cost, AlignStats* __restrict__ stats) {
   const size_t b = blockIdx.x;
-  unsigned char* img = g_lds + L.image_off;
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
+  ImageHeader* hdr = reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off);
 
   // reference frame <- scan A at identity (ndtpso_slam_node.cpp:186,198 for the first scan), then build
-  const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt());
+  const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
   __syncthreads();
-  build_table_wg(g, wn, pts, n_ref, img, reinterpret_cast<int*>(g_lds + L.key_off),
+  build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
                  reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
-                 reinterpret_cast<uint2*>(g_lds + L.bm2_off), nullptr, nullptr);
+                 reinterpret_cast<uint2*>(g_lds + L.bm2_off), nullptr, nullptr, PATH == 2 ? &dn : nullptr, g_lds);
   // new frame <- scan B (one-cell frame: just the point list, ndtpso_slam_node.cpp:229-230)
-  const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt());
+  const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
+  pad_points_wg(pts, n_new);
   __syncthreads();
 
-  const uint2* bm = reinterpret_cast<const uint2*>(img + kImageHeaderBytes);
-  const Rec* rec = reinterpret_cast<const Rec*>(img + image_rec_offset(wn.n_words));
+  const EvalCtx E = make_eval_ctx(g, wn, L, dn);
   const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
-  pso_run_wg<MODE>(g, wn, bm, rec, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                   tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(), out_pose + 3 * b,
-                   out_cost ? out_cost + b : nullptr, stats ? stats + b : nullptr);
+  pso_run_wg<MODE, PATH>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                         tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off), out_pose + 3 * b,
+                         out_cost ? out_cost + b : nullptr, stats ? stats + b : nullptr);
   if (threadIdx.x == 0 && stats) {
-    const ImageHeader* h = reinterpret_cast<const ImageHeader*>(img);
-    stats[b].n_built = h->n_built;
-    stats[b].status = h->status;
+    stats[b].n_built = hdr->n_built;
+    stats[b].status = hdr->status;
   }
 }
 
@@ -271,6 +368,10 @@ PsoP make_pso(const ndtpso_pso_config* c) {
 // waves per workgroup for the PSO kernels: the evaluation round hands one particle to one wave,
 // so pick the wave count (<= 16) that wastes the fewest wave-slots on P particles
 int pick_waves(int P) {
+  if (const char* e = std::getenv("NDTPSO_WAVES")) {  // tuning knob
+    const int w = std::atoi(e);
+    if (w >= 1 && w <= 16) return w;
+  }
   int best = 4;
   double best_eff = 0.;
   for (int w = 4; w <= 16; ++w) {
@@ -282,6 +383,35 @@ int pick_waves(int P) {
     }
   }
   return best;
+}
+
+// Which score-loop variant a launch uses, and its LDS layout.
+//   path 2 (dense fast path): fp32 score, power-of-two cell side, and the dense table fits; preferred when
+//   it still allows two workgroups per CU (<= 80 KiB) or when the bitmap form does not either.
+struct Plan {
+  int path;  // 0 division + bitmap, 1 pow2 + bitmap, 2 dense
+  Layout L;
+  DenseP dn;
+};
+bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan* plan) {
+  const int bitmap_path = g.cs_pow2 ? 1 : 0;
+  const Layout Lb = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode);
+  plan->path = bitmap_path;
+  plan->L = Lb;
+  plan->dn = DenseP{0, 0, 0, 0, 0};
+  int force = -1;
+  if (const char* e = std::getenv("NDTPSO_PATH")) force = std::atoi(e);  // tuning knob
+  if (mode == kScoreF32 && g.cs_pow2 && force != 0 && force != 1) {
+    const Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, wn.w + 1, wn.h + 1);
+    const int half = kMaxLds / 2;
+    const bool take = Ld.total <= kMaxLds && (Ld.total <= half || Lb.total > half || force == 2);
+    if (take) {
+      plan->path = 2;
+      plan->L = Ld;
+      plan->dn = make_dense(wn, Ld);
+    }
+  }
+  return plan->L.total <= kMaxLds;
 }
 
 bool trans_is_zero(const double t[3]) {  // Vector3d::isZero(1e-6), ndtframe.cpp:152
@@ -316,14 +446,19 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   c->stream = c->own_stream;
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = allow_big_lds(k_build_table);
-  if (e == hipSuccess) e = allow_big_lds(k_cost_batch<kScoreF32, false>);
-  if (e == hipSuccess) e = allow_big_lds(k_cost_batch<kScoreF32, true>);
-  if (e == hipSuccess) e = allow_big_lds(k_cost_batch<kScoreF64, false>);
-  if (e == hipSuccess) e = allow_big_lds(k_cost_batch<kScoreF64, true>);
-  if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32>);
-  if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF64>);
-  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32>);
-  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF64>);
+#define BIG_PATHS(K, ...)                                                      \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 0 __VA_ARGS__>);         \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 1 __VA_ARGS__>);         \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 2 __VA_ARGS__>);         \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF64, 0 __VA_ARGS__>);         \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF64, 1 __VA_ARGS__>);
+#define COMMA ,
+  BIG_PATHS(k_cost_batch, COMMA false)
+  BIG_PATHS(k_cost_batch, COMMA true)
+  BIG_PATHS(k_align)
+  BIG_PATHS(k_align_pairs)
+#undef COMMA
+#undef BIG_PATHS
   if (e != hipSuccess) {
     (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -388,7 +523,7 @@ int ndtpso_scan_to_points(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_
 }
 
 static int build_from_device_points(ndtpso_ctx* c, const ndtpso_grid* grid, const GridP& g, const WinP& wn, int n) {
-  const Layout L = make_layout(wn.n_words, wn.rec_cap, std::max(n, 1), 0);
+  const Layout L = make_layout(wn.n_words, wn.rec_cap, std::max(n, 1), 0, 2);
   if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "reference table does not fit in LDS");
   HIP_TRY(c, c->image.reserve(image_bytes(wn.n_words, wn.rec_cap)));
   HIP_TRY(c, c->rows.reserve(sizeof(CellRow) * (size_t)std::max(n, 1)));
@@ -412,7 +547,7 @@ static int build_from_device_points(ndtpso_ctx* c, const ndtpso_grid* grid, cons
 }
 
 int ndtpso_ref_from_points(ndtpso_ctx* c, const ndtpso_grid* grid, const double* xy, uint32_t n) {
-  if (!c || !xy && n) return fail(c, NDTPSO_E_ARG, "null argument");
+  if (!c || (!xy && n)) return fail(c, NDTPSO_E_ARG, "null argument");
   GridP g;
   if (make_grid(grid, &g) != NDTPSO_OK) return fail(c, NDTPSO_E_ARG, "bad grid");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -492,14 +627,17 @@ int ndtpso_ref_set_cells(ndtpso_ctx* c, const ndtpso_grid* grid, uint32_t n_cell
   wn.h = y1 - y0 + 1;
   wn.n_words = (wn.w * wn.h + 31) / 32;
   wn.rec_cap = std::max<int>((int)n_cells, 1);
-  const Layout L = make_layout(wn.n_words, wn.rec_cap, 1, 0);
+  const Layout L = make_layout(wn.n_words, wn.rec_cap, 1, 0, 2);
   if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "reference table does not fit in LDS");
   // pack the LDS image on the host: bitmap words {bits, exclusive prefix}, records in ascending cell order
   const size_t bytes = image_bytes(wn.n_words, wn.rec_cap);
   std::vector<unsigned char> img(bytes, 0);
   ImageHeader* hdr = reinterpret_cast<ImageHeader*>(img.data());
   uint2* bm = reinterpret_cast<uint2*>(img.data() + kImageHeaderBytes);
-  Rec* rec = reinterpret_cast<Rec*>(img.data() + image_rec_offset(wn.n_words));
+  double2* t_mean = reinterpret_cast<double2*>(img.data() + image_mean_offset(wn.n_words));
+  double2* t_ab = reinterpret_cast<double2*>(img.data() + image_ab_offset(wn.n_words, wn.rec_cap));
+  double2* t_cd = reinterpret_cast<double2*>(img.data() + image_cd_offset(wn.n_words, wn.rec_cap));
+  float4* t_chol = reinterpret_cast<float4*>(img.data() + image_chol_offset(wn.n_words, wn.rec_cap));
   std::vector<std::pair<int, uint32_t>> order(n_cells);
   for (uint32_t i = 0; i < n_cells; ++i) {
     const int ix = index[i] % g.W, iy = index[i] / g.W;
@@ -516,18 +654,12 @@ int ndtpso_ref_set_cells(ndtpso_ctx* c, const ndtpso_grid* grid, uint32_t n_cell
   }
   for (uint32_t s = 0; s < n_cells; ++s) {
     const uint32_t i = order[s].second;
-    Rec& r = rec[s];
-    r.mx = mean[2 * i];
-    r.my = mean[2 * i + 1];
-    r.a = icov[4 * i];
-    r.b = icov[4 * i + 1];
-    r.c = icov[4 * i + 2];
-    r.d = icov[4 * i + 3];
-    const double kf = -0.72134752044448170368;
-    r.fa = (float)(kf * r.a);
-    r.fb = (float)(kf * (r.b + r.c));
-    r.fd = (float)(kf * r.d);
-    r.key = (uint32_t)order[s].first;
+    t_mean[s] = make_double2(mean[2 * i], mean[2 * i + 1]);
+    t_ab[s] = make_double2(icov[4 * i], icov[4 * i + 1]);
+    t_cd[s] = make_double2(icov[4 * i + 2], icov[4 * i + 3]);
+    float l[4];
+    make_chol(icov[4 * i], icov[4 * i + 1], icov[4 * i + 2], icov[4 * i + 3], l);
+    t_chol[s] = make_float4(l[0], l[1], l[2], l[3]);
   }
   hdr->n_built = n_cells;
   hdr->n_created = n_cells;
@@ -562,8 +694,10 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
   if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
   if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
   HIP_TRY(c, hipSetDevice(c->device));
-  const Layout L = make_layout(c->wn.n_words, c->wn.rec_cap, std::max<int>((int)n, 1), 0);
-  if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "table + points do not fit in LDS");
+  Plan plan;
+  if (!make_plan(mode, c->g, c->wn, std::max<int>((int)n, 1), 0, &plan))
+    return fail(c, NDTPSO_E_CAPACITY, "table + points do not fit in LDS");
+  const Layout& L = plan.L;
   HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
   HIP_TRY(c, c->poses.reserve((size_t)m * 24));
   HIP_TRY(c, c->costs.reserve((size_t)m * 8));
@@ -572,15 +706,18 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
   HIP_TRY(c, hipMemcpyAsync(c->poses.p, poses, (size_t)m * 24, hipMemcpyHostToDevice, c->stream));
   const int waves = 16;
   const int grid = (int)std::min<uint32_t>((m + waves - 1) / waves, 512u);
-#define LAUNCH_COST(MODE, DUMP)                                                                                   \
-  hipLaunchKernelGGL((k_cost_batch<MODE, DUMP>), dim3(grid), dim3(waves * 64), L.total, c->stream,                \
-                     (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L,          \
+#define LAUNCH_COST(MODE, PATH, DUMP)                                                                             \
+  hipLaunchKernelGGL((k_cost_batch<MODE, PATH, DUMP>), dim3(grid), dim3(waves * 64), L.total, c->stream,          \
+                     (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, plan.dn, \
                      (const double*)c->poses.p, (int)m, (double*)c->costs.p, (int32_t*)c->dump.p)
+#define LAUNCH_COST2(MODE, PATH) \
+  do { if (cell_idx) LAUNCH_COST(MODE, PATH, true); else LAUNCH_COST(MODE, PATH, false); } while (0)
   if (mode == NDTPSO_SCORE_F32) {
-    if (cell_idx) LAUNCH_COST(kScoreF32, true); else LAUNCH_COST(kScoreF32, false);
+    if (plan.path == 2) LAUNCH_COST2(kScoreF32, 2); else if (plan.path == 1) LAUNCH_COST2(kScoreF32, 1); else LAUNCH_COST2(kScoreF32, 0);
   } else {
-    if (cell_idx) LAUNCH_COST(kScoreF64, true); else LAUNCH_COST(kScoreF64, false);
+    if (plan.path == 1) LAUNCH_COST2(kScoreF64, 1); else LAUNCH_COST2(kScoreF64, 0);
   }
+#undef LAUNCH_COST2
 #undef LAUNCH_COST
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(costs, c->costs.p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
@@ -599,8 +736,10 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   if (int rc = check_pso(c, cfg)) return rc;
   if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
   HIP_TRY(c, hipSetDevice(c->device));
-  const Layout L = make_layout(c->wn.n_words, c->wn.rec_cap, std::max<int>((int)n, 1), cfg->population);
-  if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "table + points + swarm do not fit in LDS");
+  Plan plan;
+  if (!make_plan(mode, c->g, c->wn, std::max<int>((int)n, 1), cfg->population, &plan))
+    return fail(c, NDTPSO_E_CAPACITY, "table + points + swarm do not fit in LDS");
+  const Layout& L = plan.L;
   const size_t n_draw = ndtpso_rand_draws(cfg);
   HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
   HIP_TRY(c, c->small.reserve(256));
@@ -615,12 +754,16 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   HIP_TRY(c, hipMemsetAsync(c->out.p, 0, 256, c->stream));
   const int waves = pick_waves(cfg->population);
   const PsoP ps = make_pso(cfg);
-#define LAUNCH_ALIGN(MODE)                                                                                         \
-  hipLaunchKernelGGL((k_align<MODE>), dim3(1), dim3(waves * 64), L.total, c->stream, (const unsigned char*)c->image.p, \
-                     (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, ps, (const double*)c->small.p,             \
-                     (const double*)c->small.p + 3, seed, rand_table ? (const int32_t*)c->table.p : nullptr, d_out, \
-                     d_out + 3, d_stats)
-  if (mode == NDTPSO_SCORE_F32) LAUNCH_ALIGN(kScoreF32); else LAUNCH_ALIGN(kScoreF64);
+#define LAUNCH_ALIGN(MODE, PATH)                                                                                   \
+  hipLaunchKernelGGL((k_align<MODE, PATH>), dim3(1), dim3(waves * 64), L.total, c->stream,                         \
+                     (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, plan.dn,  \
+                     ps, (const double*)c->small.p, (const double*)c->small.p + 3, seed,                           \
+                     rand_table ? (const int32_t*)c->table.p : nullptr, d_out, d_out + 3, d_stats)
+  if (mode == NDTPSO_SCORE_F32) {
+    if (plan.path == 2) LAUNCH_ALIGN(kScoreF32, 2); else if (plan.path == 1) LAUNCH_ALIGN(kScoreF32, 1); else LAUNCH_ALIGN(kScoreF32, 0);
+  } else {
+    if (plan.path == 1) LAUNCH_ALIGN(kScoreF64, 1); else LAUNCH_ALIGN(kScoreF64, 0);
+  }
 #undef LAUNCH_ALIGN
   HIP_TRY(c, hipGetLastError());
   double host[4 + sizeof(AlignStats) / 8];
@@ -636,26 +779,25 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
 
 // ---- fused pairs -----------------------------------------------------------------------------------
 
-static int pairs_plan(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg, GridP* g,
-                      WinP* wn, Layout* L, int* waves) {
+static int pairs_plan(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg, int mode,
+                      GridP* g, WinP* wn, Plan* plan, int* waves) {
   if (!geom || geom->n_beams == 0 || !cfg || cfg->population < 1 || cfg->iterations < 0) return NDTPSO_E_ARG;
   if (make_grid(grid, g) != NDTPSO_OK) return NDTPSO_E_ARG;
   const double r = (double)geom->max_range;
   *wn = make_window(*g, -r, r, -r, r, (int)(geom->n_beams / 3) + 1);
-  *L = make_layout(wn->n_words, wn->rec_cap, (int)geom->n_beams, cfg->population);
   *waves = pick_waves(cfg->population);
-  return (L->total > kMaxLds) ? NDTPSO_E_CAPACITY : NDTPSO_OK;
+  return make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan) ? NDTPSO_OK : NDTPSO_E_CAPACITY;
 }
 
 int ndtpso_align_pairs_footprint(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg,
                                  uint32_t* lds_bytes, uint32_t* block_threads) {
   GridP g;
   WinP wn;
-  Layout L;
+  Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, &g, &wn, &L, &waves);
+  const int rc = pairs_plan(geom, grid, cfg, NDTPSO_SCORE_F32, &g, &wn, &plan, &waves);
   if (rc == NDTPSO_E_ARG) return rc;
-  if (lds_bytes) *lds_bytes = (rc == NDTPSO_OK) ? (uint32_t)L.total : 0u;
+  if (lds_bytes) *lds_bytes = (rc == NDTPSO_OK) ? (uint32_t)plan.L.total : 0u;
   if (block_threads) *block_threads = (uint32_t)waves * 64u;
   return rc;
 }
@@ -671,20 +813,24 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
   if (n_pairs == 0) return NDTPSO_OK;
   GridP g;
   WinP wn;
-  Layout L;
+  Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, &g, &wn, &L, &waves);
+  const int rc = pairs_plan(geom, grid, cfg, mode, &g, &wn, &plan, &waves);
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
   HIP_TRY(c, hipSetDevice(c->device));
   const ScanP sp = make_scan(geom);
   const PsoP ps = make_pso(cfg);
   const size_t stride = ndtpso_rand_draws(cfg);
-#define LAUNCH_PAIRS(MODE)                                                                                        \
-  hipLaunchKernelGGL((k_align_pairs<MODE>), dim3(n_pairs), dim3(waves * 64), L.total, c->stream, d_ref, d_new, sp, g, \
-                     wn, L, ps, d_guess, d_dev, d_seeds, d_tables, stride, d_pose, d_cost,                         \
-                     reinterpret_cast<AlignStats*>(d_stats))
-  if (mode == NDTPSO_SCORE_F32) LAUNCH_PAIRS(kScoreF32); else LAUNCH_PAIRS(kScoreF64);
+#define LAUNCH_PAIRS(MODE, PATH)                                                                                  \
+  hipLaunchKernelGGL((k_align_pairs<MODE, PATH>), dim3(n_pairs), dim3(waves * 64), plan.L.total, c->stream, d_ref,  \
+                     d_new, sp, g, wn, plan.L, plan.dn, ps, d_guess, d_dev, d_seeds, d_tables, stride, d_pose,     \
+                     d_cost, reinterpret_cast<AlignStats*>(d_stats))
+  if (mode == NDTPSO_SCORE_F32) {
+    if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
+  } else {
+    if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
+  }
 #undef LAUNCH_PAIRS
   HIP_TRY(c, hipGetLastError());
   return NDTPSO_OK;

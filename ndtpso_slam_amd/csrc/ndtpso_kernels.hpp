@@ -22,7 +22,9 @@ constexpr int kScoreF32 = 0;
 constexpr int kScoreF64 = 1;
 constexpr int kWave = 64;
 constexpr int kImageHeaderBytes = 64;
-constexpr int kRecBytes = 64;
+__host__ __device__ constexpr int align16_c(int x) { return (x + 15) & ~15; }
+__host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
+constexpr int kPointPad = 64;  // the point list is padded to whole waves with out-of-frame sentinels
 
 // ---- uniform parameter blocks (kernel arguments -> SGPRs) ---------------
 
@@ -51,14 +53,44 @@ struct PsoP {
   double w, c1, c2, wdamp;
 };
 
-// one reference cell as the score loop reads it (64 B, 16-B aligned pieces)
-struct __attribute__((aligned(16))) Rec {
-  double mx, my;      // NDTCell::mean
-  double a, b, c, d;  // s_inv_covar (0,0),(0,1),(1,0),(1,1)
-  float fa, fb, fd;   // -0.5*log2(e) * {a, b+c, d} rounded to fp32 (fp32 score path)
-  uint32_t key;       // window-linear cell id
+// Reference cell table as the score loop reads it: structure of 16-byte arrays indexed by record slot
+// (ds_read_b128 gathers: two slots collide on LDS banks only when they are congruent mod 16).
+//   mean[slot] = NDTCell::mean                                 (both score paths)
+//   ab[slot], cd[slot] = s_inv_covar rows (0,0),(0,1) / (1,0),(1,1)   (fp64 score path)
+//   chol[slot] = {l11, l21, l22, 0}: with M = 0.5*log2(e)*s_inv_covar = L L^T (Cholesky),
+//       exp(-d^T S d / 2) = exp2(-((l11 d0 + l21 d1)^2 + (l22 d1)^2)); no cancellation between large
+//       terms for thin, rotated Gaussians, which is what makes fp32 sufficient here  (fp32 score path)
+struct TableView {
+  const uint2* bm;      // bitmap words {bits, exclusive prefix popcount} over the staging window
+  const double2* mean;
+  const double2* ab;
+  const double2* cd;
+  const float4* chol;
 };
-static_assert(sizeof(Rec) == kRecBytes, "record must be 64 bytes");
+struct TableOut {  // same arrays, writable (table build); null = not wanted
+  uint2* bm;
+  double2* mean;
+  double2* ab;
+  double2* cd;
+  float4* chol;
+};
+
+// Dense form used by the fp32-score fast path (power-of-two cell side): a u16 entry per cell of the
+// staging window (plus one empty border row/column on the low sides) holding the LDS address / 16 of the
+// cell's 32-byte record; cells that are not built point at a null record whose exponent is -inf, so a miss
+// needs no mask, select or compare.  The table sits at LDS offset 0: entry address = cell index * 2.
+struct __attribute__((aligned(16))) DenseRec {
+  double mgx, mgy;        // NDTCell::mean in cell units, relative to the dense window origin
+  float l11, l21, l22, w; // Cholesky factor of 0.5*log2(e)*s_inv_covar scaled to cell units; w: 0, or +inf for the null record
+};
+static_assert(sizeof(DenseRec) == 32, "dense record must be 32 bytes");
+struct DenseP {
+  int dw, dh;    // dense window size in cells, = wn.w + 1, wn.h + 1
+  int ox, oy;    // grid coordinates of dense cell (0,0), = wn.x0 - 1, wn.y0 - 1
+  int rec_off;   // LDS byte offset of DenseRec[rec_cap + 1] (record 0 = null), 16-byte aligned
+};
+__host__ __device__ inline int dense_tab_bytes(int dw, int dh) { return align16_c(dw * dh * 2); }
+constexpr int kRecImageBytes = 64;  // per record in the HBM image: mean, ab, cd, chol
 
 struct ImageHeader {
   uint32_t n_built, n_created, status, pad[13];
@@ -75,10 +107,30 @@ struct AlignStats {  // == ndtpso_align_stats
   uint32_t n_points, n_built, cost_evals, rounds, gbest_updates, status, reserved[2];
 };
 
-__host__ __device__ inline int align16(int x) { return (x + 15) & ~15; }
-__host__ __device__ inline int image_rec_offset(int n_words) { return kImageHeaderBytes + align16(n_words * 8); }
-__host__ __device__ inline int image_bytes(int n_words, int rec_cap) {
-  return image_rec_offset(n_words) + rec_cap * kRecBytes;
+
+__host__ __device__ inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+// table image in HBM: [header | bitmap words | mean[cap] | ab[cap] | cd[cap] | chol[cap]] (all 16-B elements)
+__host__ __device__ inline int image_mean_offset(int n_words) { return kImageHeaderBytes + align16(n_words * 8); }
+__host__ __device__ inline int image_ab_offset(int n_words, int cap) { return image_mean_offset(n_words) + 16 * cap; }
+__host__ __device__ inline int image_cd_offset(int n_words, int cap) { return image_mean_offset(n_words) + 32 * cap; }
+__host__ __device__ inline int image_chol_offset(int n_words, int cap) { return image_mean_offset(n_words) + 48 * cap; }
+__host__ __device__ inline int image_bytes(int n_words, int cap) { return image_mean_offset(n_words) + 64 * cap; }
+
+// Cholesky factor of 0.5*log2(e)*[[a, (b+c)/2], [(b+c)/2, d]] for the fp32 score path
+__host__ __device__ inline void make_chol(double a, double b, double c, double d, float out[4]) {
+  const double k = 0.72134752044448170368;  // 0.5 * log2(e)
+  const double A = k * a, B = k * (0.5 * (b + c)), D = k * d;
+  double l11 = 0., l21 = 0.;
+  if (A > 0.) {
+    l11 = sqrt(A);
+    l21 = B / l11;
+  }
+  const double rem = D - l21 * l21;
+  const double l22 = rem > 0. ? sqrt(rem) : 0.;
+  out[0] = (float)l11;
+  out[1] = (float)l21;
+  out[2] = (float)l22;
+  out[3] = 0.f;
 }
 
 // ---- small device helpers ------------------------------------------------
@@ -86,18 +138,33 @@ __host__ __device__ inline int image_bytes(int n_words, int rec_cap) {
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 
+// sum over the 64 lanes, fixed association order, result uniform: 4 DPP steps inside each row of 16
+// lanes (quad xor 1, quad xor 2, half-row mirror, row mirror), then the four row sums via readlane.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-  return v;
+  v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);  // row_half_mirror
+  v += dpp_f64<0x140>(v);  // row_mirror
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
 // cell coordinates of an in-frame point, following NDTFrame::getCellIndex (ndtframe.cpp:240-249):
 // floor((x + width/2.)/cell_side), floor((y + height/2.)/cell_side).  x + hw > 0 inside the
 // strict bounds, so truncation equals floor.
+template <bool POW2>
 __device__ __forceinline__ void cell_coords(const GridP& g, double qx, double qy, int& ix, int& iy) {
   const double ux = qx + g.hw, uy = qy + g.hh;
-  if (g.cs_pow2) {
+  if (POW2) {
     ix = (int)(ux * g.inv_cs);
     iy = (int)(uy * g.inv_cs);
   } else {
@@ -105,71 +172,233 @@ __device__ __forceinline__ void cell_coords(const GridP& g, double qx, double qy
     iy = (int)(uy / g.cs);
   }
 }
+__device__ __forceinline__ void cell_coords_rt(const GridP& g, double qx, double qy, int& ix, int& iy) {
+  if (g.cs_pow2) cell_coords<true>(g, qx, qy, ix, iy); else cell_coords<false>(g, qx, qy, ix, iy);
+}
+
+#ifndef NDTPSO_UNROLL
+#define NDTPSO_UNROLL 4
+#endif
 
 // ---- K1: NDT score of one candidate pose, one wave --------------------------
 //
 // cost_function (core.cpp:26-48) + transform_point (core.h:28-31) + getCellIndex
 // (ndtframe.cpp:240-249) + NDTCell::normalDistribution (ndtcell.cpp:70-78), fused.
-// Lanes stride the points (coalesced 16-B LDS reads); the cell index is a bitmap
-// word + prefix popcount; the record gather is 2 (fp32 score) or 3 (fp64) ds_read_b128.
+// Lanes stride the points (coalesced 16-B LDS reads); the cell lookup is one 8-byte bitmap word
+// {bits, prefix} + popcount; the record gather is 2 (fp32 score) or 3 (fp64) ds_read_b128.
+// The body is branch-free (misses read slot 0 and are masked) and written phase by phase over U
+// points per lane, so the three dependent LDS round trips of U independent points overlap.
 // Returns the cost (-sum) on every lane.
-template <int MODE, bool DUMP>
-__device__ __forceinline__ double eval_pose_wave(const GridP& g, const WinP& wn, const uint2* __restrict__ bm,
-                                                 const Rec* __restrict__ rec, const double2* __restrict__ pts,
-                                                 int n, double c, double s, double tx, double ty,
-                                                 int32_t* __restrict__ dump) {
+template <int MODE, bool POW2, int U, bool DUMP>
+__device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const TableView& T,
+                                           const double2* __restrict__ pts, int base, int n, double c, double s,
+                                           double tx, double ty, double (&acc)[4], int32_t* __restrict__ dump) {
   const int lane = lane_id();
-  double acc = 0.0;
-  for (int base = 0; base < n; base += kWave) {
-    const int i = base + lane;
-    int tag = -1;
-    if (i < n) {
-      const double2 p = pts[i];
-      double qx, qy;
-      if (MODE == kScoreF64) {
-        qx = (p.x * c - p.y * s) + tx;  // reference rounding, no fma
-        qy = (p.x * s + p.y * c) + ty;
-      } else {
-        qx = fma(p.x, c, fma(-p.y, s, tx));
-        qy = fma(p.x, s, fma(p.y, c, ty));
-      }
-      if (fabs(qx) < g.hw && fabs(qy) < g.hh) {
-        int ix, iy;
-        cell_coords(g, qx, qy, ix, iy);
-        if (DUMP) tag = (iy < g.H) ? -2 : -1;
-        const int lin_frame = ix + g.W * iy;
-        if (__builtin_expect(ix == g.W, 0)) {  // fl(x + w/2) == w: the reference's linear index wraps to the next row
-          ix = 0;
-          iy += 1;
-        }
-        const unsigned rx = (unsigned)(ix - wn.x0), ry = (unsigned)(iy - wn.y0);
-        if (rx < (unsigned)wn.w && ry < (unsigned)wn.h) {
-          const unsigned lin = ry * (unsigned)wn.w + rx;
-          const uint2 e = bm[lin >> 5];
-          const unsigned bit = lin & 31u;
-          if ((e.x >> bit) & 1u) {
-            const unsigned slot = e.y + __popc(e.x & ((1u << bit) - 1u));
-            const Rec* r = rec + slot;
-            if (MODE == kScoreF64) {
-              const double d0 = qx - r->mx, d1 = qy - r->my;
-              const double r0 = d0 * r->a + d1 * r->c;  // (diff^T * inv_covar), ndtcell.cpp:73-75
-              const double r1 = d0 * r->b + d1 * r->d;
-              acc += exp(-(r0 * d0 + r1 * d1) / 2.);
-            } else {
-              const double2 m = *reinterpret_cast<const double2*>(&r->mx);
-              const float4 f = *reinterpret_cast<const float4*>(&r->fa);
-              const float d0 = (float)(qx - m.x), d1 = (float)(qy - m.y);
-              const float q = fmaf(d0, fmaf(f.x, d0, f.y * d1), (f.z * d1) * d1);
-              acc += (double)__builtin_amdgcn_exp2f(q);
-            }
-            if (DUMP) tag = lin_frame;
-          }
-        }
-      }
-      if (DUMP) dump[i] = tag;
+  double2 p[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) p[u] = pts[base + u * kWave + lane];
+
+  double qx[U], qy[U];
+  unsigned lin[U];
+  bool ok[U];
+  int tagv[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if constexpr (MODE == kScoreF64) {
+      qx[u] = (p[u].x * c - p[u].y * s) + tx;  // reference rounding, no fma
+      qy[u] = (p[u].x * s + p[u].y * c) + ty;
+    } else {
+      qx[u] = fma(p[u].x, c, fma(-p[u].y, s, tx));
+      qy[u] = fma(p[u].x, s, fma(p[u].y, c, ty));
+    }
+    const bool inframe = (int)(fabs(qx[u]) < g.hw) & (int)(fabs(qy[u]) < g.hh);  // strict bounds, ndtframe.cpp:242
+    int ix, iy;
+    cell_coords<POW2>(g, qx[u], qy[u], ix, iy);
+    const bool wrap = (ix == g.W);  // fl(x + w/2) == w: the reference's linear index lands in the next row
+    if (DUMP) tagv[u] = ix + g.W * iy;
+    ix = wrap ? 0 : ix;
+    iy = wrap ? iy + 1 : iy;
+    if (DUMP) tagv[u] = (!inframe || iy >= g.H) ? -1 : tagv[u];
+    const unsigned rx = (unsigned)(ix - wn.x0), ry = (unsigned)(iy - wn.y0);
+    ok[u] = (int)inframe & (int)(rx < (unsigned)wn.w) & (int)(ry < (unsigned)wn.h);
+    lin[u] = ok[u] ? __umul24(ry, (unsigned)wn.w) + rx : 0u;
+  }
+
+  unsigned long long e[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) e[u] = reinterpret_cast<const unsigned long long*>(T.bm)[lin[u] >> 5];
+
+  unsigned slot[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned bits = (unsigned)e[u], pre = (unsigned)(e[u] >> 32), bit = lin[u] & 31u;
+    ok[u] = (int)ok[u] & (int)((bits >> bit) & 1u);
+    const unsigned sl = pre + __popc(bits & ((1u << bit) - 1u));
+    slot[u] = ok[u] ? sl : 0u;
+  }
+
+  if constexpr (MODE == kScoreF64) {
+    double2 m[U], ab[U], cd[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      m[u] = T.mean[slot[u]];
+      ab[u] = T.ab[slot[u]];
+      cd[u] = T.cd[slot[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double d0 = qx[u] - m[u].x, d1 = qy[u] - m[u].y;
+      const double r0 = d0 * ab[u].x + d1 * cd[u].x;  // (diff^T * inv_covar), ndtcell.cpp:73-75
+      const double r1 = d0 * ab[u].y + d1 * cd[u].y;
+      const double x = -(r0 * d0 + r1 * d1) / 2.;
+      acc[u] += exp(fmin(x, ok[u] ? (double)__builtin_inff() : -(double)__builtin_inff()));  // exp(-inf) = 0
+    }
+  } else {
+    double2 m[U];
+    float4 f[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      m[u] = T.mean[slot[u]];
+      f[u] = T.chol[slot[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float d0 = (float)(qx[u] - m[u].x), d1 = (float)(qy[u] - m[u].y);
+      const float a = fmaf(f[u].x, d0, f[u].y * d1), b = f[u].z * d1;
+      // chol.w is 0: folding it in keeps the gather a single ds_read_b128.  Misses are masked through the
+      // exponent (min with -inf; exp2(-inf) = 0) so the whole body stays straight-line code.
+      const float x = -fmaf(a, a, fmaf(b, b, f[u].w));
+      const float q = fminf(x, ok[u] ? __builtin_inff() : -__builtin_inff());
+      acc[u] += (double)__builtin_amdgcn_exp2f(q);
     }
   }
-  return -wave_sum(acc);
+  if (DUMP) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kWave + lane;
+      if (i < n) dump[i] = (tagv[u] < 0) ? -1 : (ok[u] ? tagv[u] : -2);
+    }
+  }
+}
+
+
+// ---- fp32-score fast path: dense table, folded index arithmetic ------------------------------------------
+//
+// For a power-of-two cell side, floor((x + w/2)/cs) is floor(fl(x + w/2) * 2^k) and scaling by 2^k commutes
+// with rounding, so the window-relative cell coordinates come straight out of the transform:
+//   gx = x*C - y*S + TX,  C = cos/cs, S = sin/cs, TX = (tx + w/2)/cs - ox      (2 fp64 FMAs per axis)
+// and the Mahalanobis form is evaluated in cell units against DenseRec.  Per point: 4 FMA, 2 cvt, 2 cmp,
+// mad, select, 3 LDS reads, 2 sub, 2 cvt, 5 fp32, exp2, cvt, add.  (The transform is a single-rounded FMA
+// chain, so a point within 1 ulp of a cell edge may bin differently from the reference; the fp64 score
+// path keeps the reference's rounding step by step.)
+struct DenseItem {  // per-pose constants
+  double C, S, TX, TY;
+};
+__device__ __forceinline__ DenseItem dense_item(const GridP& g, const DenseP& dn, double c, double s, double tx,
+                                                double ty) {
+  DenseItem it;
+  it.C = c * g.inv_cs;
+  it.S = s * g.inv_cs;
+  it.TX = (tx + g.hw) * g.inv_cs - (double)dn.ox;
+  it.TY = (ty + g.hh) * g.inv_cs - (double)dn.oy;
+  return it;
+}
+
+template <int U, bool DUMP>
+__device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
+                                                 const double2* __restrict__ pts, int base, int n,
+                                                 const DenseItem& it, double (&acc)[4], int32_t* __restrict__ dump) {
+  const int lane = lane_id();
+  double2 p[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) p[u] = pts[base + u * kWave + lane];
+  double gx[U], gy[U];
+  unsigned lin[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    gx[u] = fma(p[u].x, it.C, fma(-p[u].y, it.S, it.TX));
+    gy[u] = fma(p[u].x, it.S, fma(p[u].y, it.C, it.TY));
+    const unsigned rx = (unsigned)(int)gx[u], ry = (unsigned)(int)gy[u];
+    const bool ok = (int)(rx < (unsigned)dn.dw) & (int)(ry < (unsigned)dn.dh);
+    lin[u] = ok ? __umul24(ry, (unsigned)dn.dw) + rx : 0u;  // cell 0 is a border cell: always the null record
+  }
+  unsigned e[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) e[u] = reinterpret_cast<const unsigned short*>(lds0)[lin[u]];
+  double2 m[U];
+  float4 f[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned char* r = lds0 + (e[u] << 4);
+    m[u] = *reinterpret_cast<const double2*>(r);
+    f[u] = *reinterpret_cast<const float4*>(r + 16);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float d0 = (float)(gx[u] - m[u].x), d1 = (float)(gy[u] - m[u].y);
+    const float a = fmaf(f[u].x, d0, f[u].y * d1), b = f[u].z * d1;
+    acc[u] += (double)__builtin_amdgcn_exp2f(-fmaf(a, a, fmaf(b, b, f[u].w)));  // null record: w = +inf -> 0
+  }
+  if (DUMP) {
+    const unsigned null16 = (unsigned)dn.rec_off >> 4;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base + u * kWave + lane;
+      const double fx = gx[u] + (double)dn.ox, fy = gy[u] + (double)dn.oy;  // frame cell coordinates
+      const bool inframe = fx > 0. && fx < (double)g.W && fy > 0. && fy < (double)g.H;
+      const int cell = (int)fx + g.W * (int)fy;
+      if (i < n) dump[i] = !inframe ? -1 : (e[u] != null16 ? cell : -2);
+    }
+  }
+}
+
+template <bool DUMP>
+__device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
+                                                       const double2* __restrict__ pts, int n, double c, double s,
+                                                       double tx, double ty, int32_t* __restrict__ dump) {
+  constexpr int U = NDTPSO_UNROLL;
+  const DenseItem it = dense_item(g, dn, c, s, tx, ty);
+  double acc[4] = {0., 0., 0., 0.};
+  const int n_pad = round_up(n, kWave);
+  int base = 0;
+  for (; base + U * kWave <= n_pad; base += U * kWave)
+    score_trip_dense<U, DUMP>(g, dn, lds0, pts, base, n, it, acc, dump);
+  for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP>(g, dn, lds0, pts, base, n, it, acc, dump);
+  return -wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+
+// pts must be padded to a multiple of kPointPad with out-of-frame sentinels (pad_points_wg)
+template <int MODE, bool POW2, bool DUMP>
+__device__ __forceinline__ double eval_pose_wave_t(const GridP& g, const WinP& wn, const TableView& T,
+                                                   const double2* __restrict__ pts, int n, double c, double s,
+                                                   double tx, double ty, int32_t* __restrict__ dump) {
+  constexpr int U = NDTPSO_UNROLL;
+  double acc[4] = {0., 0., 0., 0.};
+  const int n_pad = round_up(n, kWave);
+  int base = 0;
+  for (; base + U * kWave <= n_pad; base += U * kWave)
+    score_trip<MODE, POW2, U, DUMP>(g, wn, T, pts, base, n, c, s, tx, ty, acc, dump);
+  for (; base < n_pad; base += kWave)
+    score_trip<MODE, POW2, 1, DUMP>(g, wn, T, pts, base, n, c, s, tx, ty, acc, dump);
+  return -wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+template <int MODE, bool POW2>
+__device__ __forceinline__ double eval_pose_wave(const GridP& g, const WinP& wn, const TableView& T,
+                                                 const double2* __restrict__ pts, int n, double c, double s,
+                                                 double tx, double ty) {
+  return eval_pose_wave_t<MODE, POW2, false>(g, wn, T, pts, n, c, s, tx, ty, nullptr);
+}
+template <int MODE, bool POW2>
+__device__ __forceinline__ double eval_pose_wave_dump(const GridP& g, const WinP& wn, const TableView& T,
+                                                      const double2* __restrict__ pts, int n, double c, double s,
+                                                      double tx, double ty, int32_t* __restrict__ dump) {
+  return eval_pose_wave_t<MODE, POW2, true>(g, wn, T, pts, n, c, s, tx, ty, dump);
+}
+
+// fill pts[n .. round_up(n, kPointPad)) with points no pose can bring into the frame
+__device__ inline void pad_points_wg(double2* pts, int n) {
+  const int n_pad = round_up(n, kPointPad);
+  for (int i = n + threadIdx.x; i < n_pad; i += blockDim.x) pts[i] = make_double2(1e6, 1e6);  // beyond any uint16-metre frame, finite in fp32
 }
 
 // ---- K3a: LaserScan -> points (NDTFrame::loadLaser, ndtframe.cpp:144-185) --------------------
@@ -257,13 +486,47 @@ __device__ __forceinline__ unsigned bm_slot(const uint2* bm, int k) {
 }
 
 // scratch: key[n], cellkey[n], cnt[n] ints and bm2[n_words] uint2
+// hdr/out: where the table goes (LDS); out.ab/out.cd or out.chol may be null when a kernel needs one score form
+// dn/lds0 (optional): also emit the dense form (u16 table at lds0, DenseRec[] at lds0 + dn->rec_off)
+__device__ inline void dense_clear_wg(const DenseP& dn, unsigned char* lds0) {
+  const unsigned null16 = (unsigned)dn.rec_off >> 4;
+  uint32_t* t32 = reinterpret_cast<uint32_t*>(lds0);
+  const int n32 = dense_tab_bytes(dn.dw, dn.dh) >> 2;
+  for (int i = threadIdx.x; i < n32; i += blockDim.x) t32[i] = null16 | (null16 << 16);
+  if (threadIdx.x == 0) {
+    DenseRec z;
+    z.mgx = 0.;
+    z.mgy = 0.;
+    z.l11 = z.l21 = z.l22 = 0.f;
+    z.w = __builtin_inff();
+    *reinterpret_cast<DenseRec*>(lds0 + dn.rec_off) = z;
+  }
+}
+// one built cell -> dense record `slot + 1` and its table entry; (rx, ry) = cell inside the staging window
+__device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsigned char* lds0, unsigned slot, int rx,
+                                          int ry, double mx, double my, double ia, double ib, double ic, double id) {
+  float l[4];
+  make_chol(ia, ib, ic, id, l);
+  DenseRec r;
+  r.mgx = (mx + g.hw) * g.inv_cs - (double)dn.ox;
+  r.mgy = (my + g.hh) * g.inv_cs - (double)dn.oy;
+  const float csf = (float)g.cs;  // exact: the dense path requires a power-of-two cell side
+  r.l11 = l[0] * csf;
+  r.l21 = l[1] * csf;
+  r.l22 = l[2] * csf;
+  r.w = 0.f;
+  reinterpret_cast<DenseRec*>(lds0 + dn.rec_off)[slot + 1] = r;
+  reinterpret_cast<unsigned short*>(lds0)[(ry + 1) * dn.dw + (rx + 1)] =
+      (unsigned short)(((unsigned)dn.rec_off >> 4) + 2u * (slot + 1));
+}
+
 __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const double2* pts, int n,
-                                      unsigned char* image, int* key, int* cellkey, int* cnt, uint2* bm2,
-                                      CellRow* rows, uint32_t* n_rows_out) {
+                                      ImageHeader* hdr, const TableOut& out, int* key, int* cellkey, int* cnt,
+                                      uint2* bm2, CellRow* rows, uint32_t* n_rows_out, const DenseP* dn,
+                                      unsigned char* lds0) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  ImageHeader* hdr = reinterpret_cast<ImageHeader*>(image);
-  uint2* bm = reinterpret_cast<uint2*>(image + kImageHeaderBytes);
-  Rec* rec = reinterpret_cast<Rec*>(image + image_rec_offset(wn.n_words));
+  uint2* bm = out.bm;
+  if (dn) dense_clear_wg(*dn, lds0);
 
   for (int w = tid; w < wn.n_words; w += nt) {
     bm[w] = make_uint2(0u, 0u);
@@ -282,8 +545,8 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
     int k = -1;
     if (fabs(p.x) < g.hw && fabs(p.y) < g.hh) {
       int ix, iy;
-      cell_coords(g, p.x, p.y, ix, iy);
-      if (ix == g.W) {  // reference linear-index wrap (see eval_pose_wave)
+      cell_coords_rt(g, p.x, p.y, ix, iy);
+      if (ix == g.W) {  // reference linear-index wrap (see score_point)
         ix = 0;
         iy += 1;
       }
@@ -388,19 +651,17 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
       id = c00 / det;
       const unsigned slot = bm_slot(bm, mykey);
       if ((int)slot < wn.rec_cap) {
-        Rec r;
-        r.mx = mx;
-        r.my = my;
-        r.a = ia;
-        r.b = ib;
-        r.c = ic;
-        r.d = id;
-        const double kf = -0.72134752044448170368;  // -0.5 * log2(e)
-        r.fa = (float)(kf * ia);
-        r.fb = (float)(kf * (ib + ic));
-        r.fd = (float)(kf * id);
-        r.key = (uint32_t)mykey;
-        rec[slot] = r;
+        if (dn) dense_put(g, *dn, lds0, slot, mykey % wn.w, mykey / wn.w, mx, my, ia, ib, ic, id);
+        if (out.mean) out.mean[slot] = make_double2(mx, my);
+        if (out.ab) {
+          out.ab[slot] = make_double2(ia, ib);
+          out.cd[slot] = make_double2(ic, id);
+        }
+        if (out.chol) {
+          float l[4];
+          make_chol(ia, ib, ic, id, l);
+          out.chol[slot] = make_float4(l[0], l[1], l[2], l[3]);
+        }
       }
     }
     if (rows) {
@@ -421,6 +682,31 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   }
   if (n_rows_out && tid == 0) *n_rows_out = (uint32_t)n_created;
   __syncthreads();
+}
+
+// dense form from a table image in HBM (kernels that stage a prebuilt table): one thread per bitmap word
+__device__ inline void dense_from_image_wg(const GridP& g, const WinP& wn, const unsigned char* __restrict__ image,
+                                           const DenseP& dn, unsigned char* lds0) {
+  dense_clear_wg(dn, lds0);
+  __syncthreads();
+  const uint2* bm = reinterpret_cast<const uint2*>(image + kImageHeaderBytes);
+  const double2* mean = reinterpret_cast<const double2*>(image + image_mean_offset(wn.n_words));
+  const double2* ab = reinterpret_cast<const double2*>(image + image_ab_offset(wn.n_words, wn.rec_cap));
+  const double2* cd = reinterpret_cast<const double2*>(image + image_cd_offset(wn.n_words, wn.rec_cap));
+  for (int w = threadIdx.x; w < wn.n_words; w += blockDim.x) {
+    uint2 e = bm[w];
+    unsigned slot = e.y;
+    while (e.x) {
+      const int b = __ffs(e.x) - 1;
+      e.x &= e.x - 1;
+      const int k = w * 32 + b;
+      if ((int)slot < wn.rec_cap) {
+        const double2 m = mean[slot], r0 = ab[slot], r1 = cd[slot];
+        dense_put(g, dn, lds0, slot, k % wn.w, k / wn.w, m.x, m.y, r0.x, r0.y, r1.x, r1.y);
+      }
+      ++slot;
+    }
+  }
 }
 
 // ---- glibc rand() replay on the device ------------------------------------------------------
@@ -538,21 +824,33 @@ struct PsoShared {  // small control block in static LDS
   RngState rng;
 };
 
-template <int MODE>
-__device__ inline void eval_items(const GridP& g, const WinP& wn, const uint2* bm, const Rec* rec,
-                                  const double2* pts, int n, const Swarm& sw, int S, int first,
+// PATH: 0 = bitmap table, true division by cell_side; 1 = bitmap table, power-of-two cell side; 2 = dense fast path
+struct EvalCtx {
+  GridP g;
+  WinP wn;
+  TableView T;
+  DenseP dn;
+  const unsigned char* lds0;
+};
+
+template <int MODE, int PATH>
+__device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first,
                                   int last /*exclusive*/) {
   const int n_waves = blockDim.x >> 6;
   for (int j = first + wave_id(); j < last; j += n_waves) {
     const double c = sw.tc[j], s = sw.ts[j];
     const double tx = sw.tpos[j], ty = sw.tpos[S + j];
-    const double cost = eval_pose_wave<MODE, false>(g, wn, bm, rec, pts, n, c, s, tx, ty, nullptr);
+    double cost;
+    if constexpr (PATH == 2)
+      cost = eval_pose_wave_dense<false>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
+    else
+      cost = eval_pose_wave<MODE, PATH == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
     if (lane_id() == 0) sw.tcost[j] = cost;
   }
 }
 
-template <int MODE>
-__device__ inline void pso_run_wg(const GridP& g, const WinP& wn, const uint2* bm, const Rec* rec,
+template <int MODE, int PATH>
+__device__ inline void pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
                                   PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats) {
@@ -588,7 +886,7 @@ __device__ inline void pso_run_wg(const GridP& g, const WinP& wn, const uint2* b
     }
   }
   __syncthreads();
-  eval_items<MODE>(g, wn, bm, rec, pts, n, sw, S, 0, S);
+  eval_items<MODE, PATH>(E, pts, n, sw, S, 0, S);
   n_evals += S;
   n_rounds += 1;
   __syncthreads();
@@ -645,7 +943,7 @@ __device__ inline void pso_run_wg(const GridP& g, const WinP& wn, const uint2* b
       }
       if (tid == 0) sh->jstar = P;
       __syncthreads();
-      eval_items<MODE>(g, wn, bm, rec, pts, n, sw, S, lo, P);
+      eval_items<MODE, PATH>(E, pts, n, sw, S, lo, P);
       n_evals += (uint32_t)(P - lo);
       n_rounds += 1;
       __syncthreads();
