@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--score", choices=["f32", "f64"], default="f32")
     ap.add_argument("--cpu-sample", type=int, default=96, help="pairs timed on the host oracle (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency measurement")
+    ap.add_argument("--identical", action="store_true", help="diagnostic: replicate pair 0 (no load imbalance)")
     args = ap.parse_args()
 
     import torch
@@ -61,6 +62,11 @@ def main():
     B, P, I = args.pairs, args.particles, args.iterations
     mode = capi.SCORE_F32 if args.score == "f32" else capi.SCORE_F64
     pairs = synth.make_pairs(B, seed=2024, first_pair=rank * B, total_pairs=world * B)
+    if args.identical:
+        pairs.ref_ranges[:] = pairs.ref_ranges[0]
+        pairs.new_ranges[:] = pairs.new_ranges[0]
+        pairs.seeds[:] = pairs.seeds[0]
+        pairs.delta[:] = pairs.delta[0]
     geom = capi.ScanGeom(pairs.n_beams, float(pairs.angle_min), float(pairs.angle_inc), float(pairs.range_max), 0.1)
     grid = capi.Grid(FRAME_M, FRAME_M, CELL_SIDE)
     cfg = capi.PSOConfig.make(I, P)
@@ -160,6 +166,10 @@ def main():
                 "mean_replay_overhead": float(stats["cost_evals"].mean()) / evals_nominal - 1.0,
                 "mean_abs_err_vs_truth": np.abs(pose - pairs.delta).mean(axis=0).tolist(),
                 "status_nonzero": int((stats["status"] != 0).sum()),
+                "cost_evals_min_max": [int(stats["cost_evals"].min()), int(stats["cost_evals"].max())],
+                "rounds_min_max": [int(stats["rounds"].min()), int(stats["rounds"].max())],
+                "n_built_min_max": [int(stats["n_built"].min()), int(stats["n_built"].max())],
+                "n_points_min_max": [int(stats["n_points"].min()), int(stats["n_points"].max())],
             },
         }
 

@@ -228,8 +228,11 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
 }
 
 // ---- fused scan pairs: K3a(ref) + K3b + K3a(new) + K2, everything in LDS -------------------------
+#ifndef NDTPSO_PAIRS_MIN_WAVES
+#define NDTPSO_PAIRS_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
+#endif
 template <int MODE, int PATH>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(1024, NDTPSO_PAIRS_MIN_WAVES)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev,
               const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables, size_t table_stride,
@@ -354,10 +357,13 @@ ScanP make_scan(const ndtpso_scan_geom* s) {
   return p;
 }
 
-PsoP make_pso(const ndtpso_pso_config* c) {
+PsoP make_pso(const ndtpso_pso_config* c, int waves) {
   PsoP p;
   p.P = c->population;
   p.I = c->iterations;
+  int k = 2;  // particles per evaluation round = k x waves
+  if (const char* e = std::getenv("NDTPSO_GROUP")) k = std::max(1, std::atoi(e));  // tuning knob
+  p.G = std::min(std::max(waves * k, 1), std::max(c->population, 1));
   p.w = c->w;
   p.c1 = c->c1;
   p.c2 = c->c2;
@@ -365,24 +371,17 @@ PsoP make_pso(const ndtpso_pso_config* c) {
   return p;
 }
 
-// waves per workgroup for the PSO kernels: the evaluation round hands one particle to one wave,
-// so pick the wave count (<= 16) that wastes the fewest wave-slots on P particles
-int pick_waves(int P) {
+// Waves per workgroup for the PSO kernels.  The kernels are compiled for <= 128 VGPRs, i.e. 16 waves per CU.
+// With many alignments in flight two 8-wave workgroups per CU (when their LDS fits twice) overlap each other's
+// serial phases; a lone alignment, or one whose LDS needs more than half a CU, gets all 16 waves.
+int pick_waves(int P, int lds_bytes, unsigned n_jobs) {
   if (const char* e = std::getenv("NDTPSO_WAVES")) {  // tuning knob
     const int w = std::atoi(e);
     if (w >= 1 && w <= 16) return w;
   }
-  int best = 4;
-  double best_eff = 0.;
-  for (int w = 4; w <= 16; ++w) {
-    const int rounds = (P + w - 1) / w;
-    const double eff = (double)P / (double)(rounds * w);
-    if (eff > best_eff + 1e-9 || (std::fabs(eff - best_eff) <= 1e-9 && w > best)) {
-      best_eff = eff;
-      best = w;
-    }
-  }
-  return best;
+  int w = (n_jobs > 1 && lds_bytes <= kMaxLds / 2) ? 8 : 16;
+  while (w > 1 && w / 2 >= P) w /= 2;  // never more than ~2 waves per particle
+  return w;
 }
 
 // Which score-loop variant a launch uses, and its LDS layout.
@@ -752,8 +751,8 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
   HIP_TRY(c, hipMemsetAsync(c->out.p, 0, 256, c->stream));
-  const int waves = pick_waves(cfg->population);
-  const PsoP ps = make_pso(cfg);
+  const int waves = pick_waves(cfg->population, L.total, 1);
+  const PsoP ps = make_pso(cfg, waves);
 #define LAUNCH_ALIGN(MODE, PATH)                                                                                   \
   hipLaunchKernelGGL((k_align<MODE, PATH>), dim3(1), dim3(waves * 64), L.total, c->stream,                         \
                      (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, plan.dn,  \
@@ -780,13 +779,14 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
 // ---- fused pairs -----------------------------------------------------------------------------------
 
 static int pairs_plan(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg, int mode,
-                      GridP* g, WinP* wn, Plan* plan, int* waves) {
+                      unsigned n_pairs, GridP* g, WinP* wn, Plan* plan, int* waves) {
   if (!geom || geom->n_beams == 0 || !cfg || cfg->population < 1 || cfg->iterations < 0) return NDTPSO_E_ARG;
   if (make_grid(grid, g) != NDTPSO_OK) return NDTPSO_E_ARG;
   const double r = (double)geom->max_range;
   *wn = make_window(*g, -r, r, -r, r, (int)(geom->n_beams / 3) + 1);
-  *waves = pick_waves(cfg->population);
-  return make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan) ? NDTPSO_OK : NDTPSO_E_CAPACITY;
+  const bool ok = make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan);
+  *waves = pick_waves(cfg->population, plan->L.total, n_pairs);
+  return ok ? NDTPSO_OK : NDTPSO_E_CAPACITY;
 }
 
 int ndtpso_align_pairs_footprint(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg,
@@ -795,7 +795,7 @@ int ndtpso_align_pairs_footprint(const ndtpso_scan_geom* geom, const ndtpso_grid
   WinP wn;
   Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, NDTPSO_SCORE_F32, &g, &wn, &plan, &waves);
+  const int rc = pairs_plan(geom, grid, cfg, NDTPSO_SCORE_F32, 512u, &g, &wn, &plan, &waves);
   if (rc == NDTPSO_E_ARG) return rc;
   if (lds_bytes) *lds_bytes = (rc == NDTPSO_OK) ? (uint32_t)plan.L.total : 0u;
   if (block_threads) *block_threads = (uint32_t)waves * 64u;
@@ -815,12 +815,12 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
   WinP wn;
   Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, mode, &g, &wn, &plan, &waves);
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves);
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
   HIP_TRY(c, hipSetDevice(c->device));
   const ScanP sp = make_scan(geom);
-  const PsoP ps = make_pso(cfg);
+  const PsoP ps = make_pso(cfg, waves);
   const size_t stride = ndtpso_rand_draws(cfg);
 #define LAUNCH_PAIRS(MODE, PATH)                                                                                  \
   hipLaunchKernelGGL((k_align_pairs<MODE, PATH>), dim3(n_pairs), dim3(waves * 64), plan.L.total, c->stream, d_ref,  \

@@ -50,6 +50,7 @@ struct ScanP {
 
 struct PsoP {
   int P, I;
+  int G;  // particles evaluated per round (a multiple of the workgroup's wave count)
   double w, c1, c2, wdamp;
 };
 
@@ -333,12 +334,20 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
     m[u] = *reinterpret_cast<const double2*>(r);
     f[u] = *reinterpret_cast<const float4*>(r + 16);
   }
+  float t[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const float d0 = (float)(gx[u] - m[u].x), d1 = (float)(gy[u] - m[u].y);
     const float a = fmaf(f[u].x, d0, f[u].y * d1), b = f[u].z * d1;
-    acc[u] += (double)__builtin_amdgcn_exp2f(-fmaf(a, a, fmaf(b, b, f[u].w)));  // null record: w = +inf -> 0
+    t[u] = __builtin_amdgcn_exp2f(-fmaf(a, a, fmaf(b, b, f[u].w)));  // null record: w = +inf -> 0
   }
+  // the U terms (each in [0,1]) are summed in fp32 first, then folded into the fp64 lane accumulator
+  if constexpr (U == 4)
+    acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));
+  else if constexpr (U == 2)
+    acc[0] += (double)(t[0] + t[1]);
+  else
+    acc[0] += (double)t[0];
   if (DUMP) {
     const unsigned null16 = (unsigned)dn.rec_off >> 4;
 #pragma unroll
@@ -920,41 +929,50 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
       __syncthreads();
     }
     const int32_t* draws = gen ? sw.raw : (table + 3 * S + (size_t)it * 6 * P);
+    // Particles are evaluated in index order, G at a time.  Every not-yet-committed particle carries a
+    // proposal made against the gbest that was current when it was (re)proposed; when a group contains the
+    // first improver j*, particles up to j* are committed and everything after it is re-proposed -- so only
+    // the tail of one group (< G evaluations) is ever thrown away per gbest update.
     int lo = 0;
+    bool need_propose = true;
     while (lo < P) {
-      // propose: core.cpp:83-90 for every particle not yet committed, against the current gbest
-      for (int j = lo + tid; j < P; j += blockDim.x) {
-        double th = 0.;
+      if (need_propose) {
+        // core.cpp:83-90 for every particle not yet committed, against the current gbest
+        for (int j = lo + tid; j < P; j += blockDim.x) {
+          double th = 0.;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const double r1 = fabs(uniform_pm1(draws[6 * j + 2 * k]));
-          const double r2 = fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
-          const double p = sw.pos[k * S + j];
-          const double v = w * sw.vel[k * S + j] + ps.c1 * r1 * (sw.pb[k * S + j] - p) + ps.c2 * r2 * (sh->gb[k] - p);
-          const double np = p + v;
-          sw.tvel[k * S + j] = v;
-          sw.tpos[k * S + j] = np;
-          if (k == 2) th = np;
+          for (int k = 0; k < 3; ++k) {
+            const double r1 = fabs(uniform_pm1(draws[6 * j + 2 * k]));
+            const double r2 = fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
+            const double p = sw.pos[k * S + j];
+            const double v = w * sw.vel[k * S + j] + ps.c1 * r1 * (sw.pb[k * S + j] - p) + ps.c2 * r2 * (sh->gb[k] - p);
+            const double np = p + v;
+            sw.tvel[k * S + j] = v;
+            sw.tpos[k * S + j] = np;
+            if (k == 2) th = np;
+          }
+          double sn, cn;
+          sincos(th, &sn, &cn);
+          sw.tc[j] = cn;
+          sw.ts[j] = sn;
         }
-        double sn, cn;
-        sincos(th, &sn, &cn);
-        sw.tc[j] = cn;
-        sw.ts[j] = sn;
+        need_propose = false;
       }
       if (tid == 0) sh->jstar = P;
       __syncthreads();
-      eval_items<MODE, PATH>(E, pts, n, sw, S, lo, P);
-      n_evals += (uint32_t)(P - lo);
+      const int hi_g = min(lo + ps.G, P);
+      eval_items<MODE, PATH>(E, pts, n, sw, S, lo, hi_g);
+      n_evals += (uint32_t)(hi_g - lo);
       n_rounds += 1;
       __syncthreads();
       // first particle (index order) whose cost beats gbest: core.cpp:97-104 under single-thread order
       const double gbc = sh->gbc;
-      for (int j = lo + tid; j < P; j += blockDim.x)
+      for (int j = lo + tid; j < hi_g; j += blockDim.x)
         if (sw.tcost[j] < gbc) atomicMin(&sh->jstar, j);
       __syncthreads();
       const int js = sh->jstar;
-      const int hi = (js < P) ? js : (P - 1);
-      for (int j = lo + tid; j <= hi; j += blockDim.x) {
+      const int last = (js < P) ? js : (hi_g - 1);
+      for (int j = lo + tid; j <= last; j += blockDim.x) {
         const double cst = sw.tcost[j];
         const bool better = cst < sw.pbc[j];  // core.cpp:94
 #pragma unroll
@@ -970,8 +988,13 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
           for (int k = 0; k < 3; ++k) sh->gb[k] = sw.tpos[k * S + j];
         }
       }
-      if (js < P) n_gb += 1;
-      lo = js + 1;
+      if (js < P) {
+        n_gb += 1;
+        lo = js + 1;
+        need_propose = true;
+      } else {
+        lo = hi_g;
+      }
       __syncthreads();
     }
     w *= ps.wdamp;  // core.cpp:108

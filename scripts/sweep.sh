@@ -1,7 +1,9 @@
-python -m pytest tests -m gpu -x -q -s 2>&1 | tail -15
-run() { python bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-latency "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$TAG', round(d['value']), round(d['roofline']['kernel_ms'],3), d['extra'].get('parity_sample_max_abs_dpose'))"; }
-for W in 7 8 14 16; do TAG="dense w$W" NDTPSO_WAVES=$W run; done
-for W in 8 14; do TAG="bitmap w$W" NDTPSO_PATH=1 NDTPSO_WAVES=$W run; done
-TAG="f64 w8" NDTPSO_WAVES=8 run --score f64
-TAG="f64 w14" NDTPSO_WAVES=14 run --score f64
-python bench.py --steps 5 --warmup 1 --cpu-sample 64 2>/dev/null | tail -1
+python -m pytest tests -m gpu -x -q -s 2>&1 | tail -12
+run() { python bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-latency "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); e=d['extra']; print('$TAG', round(d['value']), round(d['roofline']['kernel_ms'],3), e['mean_cost_evals_per_alignment'], e['cost_evals_min_max'], e['rounds_min_max'])"; }
+for G in 1 2 3 4; do TAG="dense G$G" NDTPSO_GROUP=$G run; done
+TAG="dense G2 identical" run --identical
+TAG="dense G2 w16" NDTPSO_WAVES=16 run
+TAG="bitmap G2" NDTPSO_PATH=1 run
+TAG="f64 G2" run --score f64
+TAG="dense 2048 pairs" run --pairs 2048
+python bench.py --steps 10 --warmup 2 --cpu-sample 64 2>/dev/null | tail -1
