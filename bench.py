@@ -57,11 +57,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from ndtpso_slam_amd import capi, synth
+    from ndtpso_slam_amd import capi, sharding, synth
 
     B, P, I = args.pairs, args.particles, args.iterations
     mode = capi.SCORE_F32 if args.score == "f32" else capi.SCORE_F64
-    pairs = synth.make_pairs(B, seed=2024, first_pair=rank * B, total_pairs=world * B)
+    first, last = sharding.shard_range(world * B, rank, world)   # weak scaling: B pairs per GPU
+    pairs = synth.make_pairs(last - first, seed=2024, first_pair=first, total_pairs=world * B)
     if args.identical:
         pairs.ref_ranges[:] = pairs.ref_ranges[0]
         pairs.new_ranges[:] = pairs.new_ranges[0]
@@ -83,14 +84,13 @@ def main():
     d_pose = torch.zeros(B, 3, dtype=torch.float64, device=dev)
     d_cost = torch.zeros(B, dtype=torch.float64, device=dev)
     d_stats = torch.zeros(B, 8, dtype=torch.int32, device=dev)
-    gathered = [torch.empty_like(d_pose) for _ in range(world)] if world > 1 else None
 
     def step():
         ctx.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(),
                             cfg, d_seeds.data_ptr(), 0, mode, d_pose.data_ptr(), d_cost.data_ptr(),
                             d_stats.data_ptr())
         if world > 1:
-            dist.all_gather(gathered, d_pose)  # the single RCCL gather of poses over xGMI
+            sharding.gather_poses(d_pose, equal_sizes=True)  # the single RCCL gather of poses over xGMI
 
     for _ in range(args.warmup):
         step()
@@ -109,7 +109,7 @@ def main():
                             d_stats.data_ptr())
         ev[k][1].record(stream)
         if world > 1:
-            dist.all_gather(gathered, d_pose)
+            sharding.gather_poses(d_pose, equal_sizes=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
