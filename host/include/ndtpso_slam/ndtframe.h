@@ -1,0 +1,82 @@
+// NDTFrame of the MI355X build of libndtpso_slam.
+//
+// Source-compatible with the reference's include/ndtpso_slam/ndtframe.h:12-72 -- same constructor
+// arguments, same public data members, same methods -- so ndtpso_slam_node.cpp (call sites :64-78, 110,
+// 155, 167, 186, 194, 198, 202, 206, 229-230) builds against it unchanged.  The frame keeps the points
+// and the window state; every number is produced on the GPU through the C-ABI in include/ndtpso_hip.h:
+//   loadLaser -> ndtpso_scan_to_points + ndtpso_points_to_cells     update -> ndtpso_points_to_cells
+//   build     -> ndtpso_cells_build_windowed                        align  -> ndtpso_ref_set_cells + ndtpso_align
+#ifndef NDTPSO_SLAM_AMD_NDTFRAME_H
+#define NDTPSO_SLAM_AMD_NDTFRAME_H
+
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "ndtpso_slam/ndtcell.h"
+
+using namespace Eigen;
+using std::vector;
+
+// Creates the process-wide device context now instead of at the first frame operation (optional).  Call it
+// before srand() when the std::rand() stream must be reproducible: runtime start-up may itself call rand().
+extern "C" void ndtpso_slam_device_init(void);
+
+class NDTFrame {
+ public:
+  uint16_t width, height, widthNumOfCells, heightNumOfCells;
+  vector<NDTCell> cells;
+  bool built;
+  unsigned int numOfCells;
+  double cell_side;
+
+  NDTFrame(Vector3d trans, unsigned short width = 20, unsigned short height = 20, double cell_side = 1.0,
+           bool calculate_cells_params = true, NDTPSOConfig config = NDTPSOConfig()
+#if BUILD_OCCUPANCY_GRID
+               ,
+           double occupancy_grid_cell_size = .0
+#endif
+  );
+
+  void loadLaser(const vector<float>& laser_data, const float& min_angle, const float& angle_increment,
+                 const float& max_range);
+  void update(Vector3d trans, NDTFrame* new_frame);
+  void addPoint(Vector2d& point);
+  inline void setTrans(Vector3d trans) { s_trans = std::move(trans); }
+  void transform(Vector3d trans);
+  void build();
+  int getCellIndex(Vector2d point, int grid_width, double cell_side);
+  Vector3d align(Vector3d initial_guess, const NDTFrame* const new_frame);
+  void dumpMap(const char* filename, bool save_poses = true, bool save_points = true, bool save_image = true,
+               short density = 50
+#if BUILD_OCCUPANCY_GRID
+               ,
+               bool save_occupancy_grid = true
+#endif
+  );
+  void addPose(double timestamp, const Vector3d& pose, const Vector3d& odom = Vector3d::Zero());
+  void resetCells();
+
+  // ---- additions of this build (not in the reference) ----
+  // new-frame points in the order cost_function visits them (cells, then insertion; core.cpp:33-36)
+  void collectPoints(std::vector<double>& xy) const;
+  const NDTPSOConfig& config() const { return s_config; }
+  // pso_optimization against this frame (used by align() and by the free function in core.h)
+  Vector3d optimize(const Vector3d& guess, const NDTFrame* new_frame, const Vector3d& deviation, const PSOConfig& cfg);
+  double cost(const Vector3d& trans, const NDTFrame* new_frame);
+
+ private:
+  Vector3d s_trans{Vector3d::Zero()}, s_prev_pose{Vector3d::Zero()}, s_pose_diff{Vector3d::Zero()};
+  vector<Vector3d> s_poses, s_odoms;
+  vector<double> s_timestamps;
+  double s_x_min, s_x_max, s_y_min, s_y_max;
+  NDTPSOConfig s_config;
+  int s_iter{0};
+  double s_og_cell_size{0.};
+  std::vector<uint32_t> s_created;  // indices of created cells, in creation order
+  bool s_table_dirty{true};         // the device reference table must be re-uploaded before the next align
+  void append(const double* xy, const int32_t* idx, uint32_t n);
+  void uploadTable();
+};
+
+#endif

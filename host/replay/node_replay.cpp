@@ -1,0 +1,59 @@
+// ROS-free replay of NDTPSONode::scan_matcher_ (reference src/ndtpso_slam_node.cpp:177-244) against the drop-in
+// library: same call sequence -- loadLaser, align (except on the first scan), update, re-allocation of the
+// per-scan frame as a one-cell frame (:229-230).  Reads a binary scan file, prints one pose per scan.
+//
+//   file: int32 n_scans, int32 n_beams, float angle_min, float angle_inc, float range_max, then n_scans*n_beams floats
+//   usage: node_replay scans.bin frame_size cell_side iterations population [srand_seed]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "ndtpso_slam/core.h"
+#include "ndtpso_slam/ndtframe.h"
+
+int main(int argc, char** argv) {
+  if (argc < 6) {
+    std::fprintf(stderr, "usage: %s scans.bin frame_size cell_side iterations population [seed]\n", argv[0]);
+    return 2;
+  }
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 2;
+  int32_t n_scans = 0, n_beams = 0;
+  float amin = 0, ainc = 0, rmax = 0;
+  if (std::fread(&n_scans, 4, 1, f) != 1 || std::fread(&n_beams, 4, 1, f) != 1 || std::fread(&amin, 4, 1, f) != 1 ||
+      std::fread(&ainc, 4, 1, f) != 1 || std::fread(&rmax, 4, 1, f) != 1)
+    return 2;
+  const unsigned short frame_size = (unsigned short)std::atoi(argv[2]);
+  const double cell_side = std::atof(argv[3]);
+  NDTPSOConfig conf;
+  conf.psoConfig.iterations = std::atoi(argv[4]);
+  conf.psoConfig.populationSize = std::atoi(argv[5]);
+  ndtpso_slam_device_init();  // before srand(): keep runtime start-up out of the rand() stream
+  if (argc > 6) std::srand((unsigned)std::atoi(argv[6]));
+
+  const Vector3d initial_pose = Vector3d::Zero();
+  // ndtpso_slam_node.cpp:64-78
+  NDTFrame* ref_frame = new NDTFrame(Vector3d::Zero(), frame_size, frame_size, cell_side, true, conf);
+  NDTFrame* current_frame = new NDTFrame(initial_pose, frame_size, frame_size, cell_side, false);
+  Vector3d previous_pose = initial_pose, current_pose = initial_pose;
+  bool first_iteration = true;
+  std::vector<float> ranges((size_t)n_beams);
+  for (int k = 0; k < n_scans; ++k) {
+    if (std::fread(ranges.data(), 4, (size_t)n_beams, f) != (size_t)n_beams) return 2;
+    current_frame->loadLaser(ranges, amin, ainc, rmax);                       // :186
+    if (first_iteration)
+      current_pose = previous_pose;                                            // :188-189
+    else
+      current_pose = ref_frame->align(previous_pose, current_frame);           // :194
+    previous_pose = current_pose;
+    ref_frame->update(current_pose, current_frame);                            // :198
+    std::printf("%d %.17g %.17g %.17g\n", k, current_pose.x(), current_pose.y(), current_pose.z());
+    delete current_frame;                                                      // :228-230
+    current_frame = new NDTFrame(initial_pose, frame_size, frame_size, frame_size, false);
+    first_iteration = false;
+  }
+  std::fclose(f);
+  delete current_frame;
+  delete ref_frame;
+  return 0;
+}

@@ -1,0 +1,15 @@
+// Process-wide device context of the host library.  No CPU fallback: if the HIP library cannot create a
+// context the process reports the error and aborts.
+#ifndef NDTPSO_HOST_DEVICE_H
+#define NDTPSO_HOST_DEVICE_H
+
+#include "../../include/ndtpso_hip.h"
+
+namespace ndtpso_host {
+ndtpso_ctx* device();                 // lazily created on HIP device $NDTPSO_DEVICE (default 0)
+int score_mode();                     // $NDTPSO_SCORE = f32 (default) | f64
+void check(int rc, const char* what); // abort with the C-ABI error text unless rc == NDTPSO_OK
+const void*& table_owner();           // which frame's cell table currently sits in the device context
+}  // namespace ndtpso_host
+
+#endif

@@ -112,6 +112,33 @@ int ndtpso_ref_set_cells(ndtpso_ctx *ctx, const ndtpso_grid *grid, uint32_t n_ce
 /* created cells of the table built by ndtpso_ref_from_points/_scan (parity inspection) */
 int ndtpso_ref_get_cells(ndtpso_ctx *ctx, ndtpso_cell_row *rows, uint32_t max_rows, uint32_t *n_rows);
 
+/* NDTFrame::update / NDTFrame::addPoint binning for a list of points (ndtframe.cpp:187-198, 215-235):
+ * xy_out[i] = transform_point(xy[i], trans) (trans == NULL: identity, the loadLaser case),
+ * cell_idx[i] = getCellIndex(xy_out[i]) or -1.  xy_out may alias xy. */
+int ndtpso_points_to_cells(ndtpso_ctx *ctx, const ndtpso_grid *grid, const double *xy, uint32_t n_points,
+                           const double trans[3], double *xy_out, int32_t *cell_idx);
+
+/* The sliding-window state of one NDTCell that NDTCell::build reads and writes (ndtcell.h:65-68,
+ * ndtcell.cpp:36-68); the host frame keeps it, the device does the arithmetic. */
+typedef struct {
+  double global_sum[2];       /* s_global_sum */
+  double global_covar_sum[4]; /* s_global_covar_sum, row-major */
+  double slot_sum[2];         /* s_partial_sums[s_current_window_id] */
+  double slot_covar[4];       /* s_partial_covars[s_current_window_id] */
+  double mean[2];             /* NDTCell::mean (out) */
+  double icov[4];             /* s_inv_covar (out) */
+  int32_t global_count;       /* s_global_count */
+  int32_t slot_count;         /* s_partial_counts[s_current_window_id] */
+  int32_t current_count;      /* s_current_count (in) */
+  int32_t built;              /* NDTCell::built (in: before, out: after) */
+} ndtpso_cell_window;
+
+/* NDTCell::build + s_calc_covar_inverse for n_cells created cells at once (NDTFrame::build's loop,
+ * ndtframe.cpp:73-76).  pts_offset[n_cells+1] delimits each cell's CURRENT-slot points (insertion order) in
+ * pts_xy; cells[] is updated in place.  The slot advance (ndtcell.cpp:61-65) is bookkeeping left to the host. */
+int ndtpso_cells_build_windowed(ndtpso_ctx *ctx, uint32_t n_cells, ndtpso_cell_window *cells,
+                                const uint32_t *pts_offset, const double *pts_xy);
+
 /* ---- K1: cost_function (core.cpp:26-48) for M candidate poses ---------- */
 /* xy: n_points new-frame points; poses: 3*M; costs: M; cell_idx (optional, M*n_points):
  * linear cell index scored against, -1 outside frame, -2 cell not built. */

@@ -48,6 +48,19 @@ class CellRow(C.Structure):
                 ("mean", C.c_double * 2), ("icov", C.c_double * 4)]
 
 
+class CellWindow(C.Structure):
+    """ndtpso_cell_window: the NDTCell sliding-window state crossing the boundary (ndtcell.h:65-68)."""
+    _fields_ = [("global_sum", C.c_double * 2), ("global_covar_sum", C.c_double * 4), ("slot_sum", C.c_double * 2),
+                ("slot_covar", C.c_double * 4), ("mean", C.c_double * 2), ("icov", C.c_double * 4),
+                ("global_count", C.c_int32), ("slot_count", C.c_int32), ("current_count", C.c_int32),
+                ("built", C.c_int32)]
+
+
+CELL_WINDOW_DTYPE = np.dtype([("global_sum", "<f8", (2,)), ("global_covar_sum", "<f8", (4,)), ("slot_sum", "<f8", (2,)),
+                              ("slot_covar", "<f8", (4,)), ("mean", "<f8", (2,)), ("icov", "<f8", (4,)),
+                              ("global_count", "<i4"), ("slot_count", "<i4"), ("current_count", "<i4"), ("built", "<i4")])
+
+
 class AlignStats(C.Structure):
     _fields_ = [("n_points", C.c_uint32), ("n_built", C.c_uint32), ("cost_evals", C.c_uint32),
                 ("rounds", C.c_uint32), ("gbest_updates", C.c_uint32), ("status", C.c_uint32),
@@ -57,11 +70,12 @@ class AlignStats(C.Structure):
 STATS_DTYPE = np.dtype([("n_points", "<u4"), ("n_built", "<u4"), ("cost_evals", "<u4"), ("rounds", "<u4"),
                         ("gbest_updates", "<u4"), ("status", "<u4"), ("reserved", "<u4", (2,))])
 assert STATS_DTYPE.itemsize == C.sizeof(AlignStats)
+assert CELL_WINDOW_DTYPE.itemsize == C.sizeof(CellWindow) == 160
 
 EXPORTS = [
     "ndtpso_ctx_create", "ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_set_stream", "ndtpso_synchronize",
     "ndtpso_rand_draws", "ndtpso_scan_to_points", "ndtpso_ref_from_points", "ndtpso_ref_from_scan",
-    "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
+    "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_cells_build_windowed", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint",
 ]
 
@@ -99,6 +113,8 @@ def load(build_if_missing: bool = True):
     L.ndtpso_ref_from_scan.argtypes = [vp, C.POINTER(Grid), fp, C.POINTER(ScanGeom), dp]
     L.ndtpso_ref_set_cells.argtypes = [vp, C.POINTER(Grid), C.c_uint32, ip, dp, dp]
     L.ndtpso_ref_get_cells.argtypes = [vp, C.POINTER(CellRow), C.c_uint32, up]
+    L.ndtpso_points_to_cells.argtypes = [vp, C.POINTER(Grid), dp, C.c_uint32, dp, dp, ip]
+    L.ndtpso_cells_build_windowed.argtypes = [vp, C.c_uint32, vp, up, dp]
     L.ndtpso_cost_batch.argtypes = [vp, dp, C.c_uint32, dp, C.c_uint32, C.c_int, dp, ip]
     L.ndtpso_align.argtypes = [vp, dp, C.c_uint32, dp, dp, C.POINTER(PSOConfig), C.c_uint32, ip, C.c_int, dp, dp,
                                C.POINTER(AlignStats)]
@@ -191,6 +207,27 @@ class Context:
         self._chk(self._lib.ndtpso_ref_get_cells(self._h, rows, n.value, C.byref(n)))
         return [dict(index=r.index, count=r.count, built=bool(r.built), mean=np.array(r.mean[:]),
                      icov=np.array(r.icov[:])) for r in rows[:n.value]]
+
+    def points_to_cells(self, grid: Grid, xy, trans=None):
+        """transform_point + getCellIndex for a point list (NDTFrame::update / addPoint)."""
+        xy = _f64(xy).reshape(-1, 2)
+        out = np.empty_like(xy)
+        idx = np.empty(xy.shape[0], dtype=np.int32)
+        t = _f64(trans, 3) if trans is not None else None
+        self._chk(self._lib.ndtpso_points_to_cells(self._h, C.byref(grid), _p(xy, C.c_double), xy.shape[0],
+                                                   _p(t, C.c_double) if t is not None else None,
+                                                   _p(out, C.c_double), _p(idx, C.c_int32)))
+        return out, idx
+
+    def cells_build_windowed(self, cells: np.ndarray, pts_offset, pts_xy):
+        """NDTCell::build with window state for many cells; `cells` (CELL_WINDOW_DTYPE) is updated in place."""
+        assert cells.dtype == CELL_WINDOW_DTYPE and cells.flags.c_contiguous
+        off = np.ascontiguousarray(pts_offset, dtype=np.uint32)
+        xy = _f64(pts_xy).reshape(-1, 2)
+        assert off.size == cells.size + 1 and off[-1] == xy.shape[0]
+        self._chk(self._lib.ndtpso_cells_build_windowed(self._h, cells.size, cells.ctypes.data_as(C.c_void_p),
+                                                        _p(off, C.c_uint32), _p(xy, C.c_double)))
+        return cells
 
     # ---- K1 ----
     def cost_batch(self, xy, poses, mode=SCORE_F32, want_cells=False):

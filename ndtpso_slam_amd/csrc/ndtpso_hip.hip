@@ -177,6 +177,107 @@ k_build_table(const double2* __restrict__ xy, int n, GridP g, WinP wn, Layout L,
   copy16(image_out, g_lds + L.hdr_off, image_bytes(wn.n_words, wn.rec_cap));
 }
 
+// ---- K3c: transform + bin a point list (NDTFrame::update / addPoint, ndtframe.cpp:187-198,215-235) ---------
+__global__ void __launch_bounds__(256)
+k_points_to_cells(const double2* __restrict__ xy, int n, GridP g, int do_trans, double tc, double ts, double ttx,
+                  double tty, double2* __restrict__ xy_out, int32_t* __restrict__ idx_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double2 p = xy[i];
+  if (do_trans) {  // transform_point, core.h:28-31 (separate roundings)
+    const double x = p.x * tc - p.y * ts + ttx;
+    const double y = p.x * ts + p.y * tc + tty;
+    p.x = x;
+    p.y = y;
+  }
+  int idx = -1;
+  if (fabs(p.x) < g.hw && fabs(p.y) < g.hh) {  // NDTFrame::getCellIndex, ndtframe.cpp:240-249
+    int ix, iy;
+    cell_coords_rt(g, p.x, p.y, ix, iy);
+    idx = ix + g.W * iy;
+    if (idx >= g.W * g.H) idx = -1;  // fl(y + h/2) == h: out-of-range access in the reference, dropped here
+  }
+  xy_out[i] = p;
+  idx_out[i] = idx;
+}
+
+// ---- K3d: NDTCell::build with sliding-window state, one thread per created cell (ndtcell.cpp:36-68,93-111) ----
+struct CellWindow {  // == ndtpso_cell_window
+  double global_sum[2], global_covar_sum[4], slot_sum[2], slot_covar[4], mean[2], icov[4];
+  int32_t global_count, slot_count, current_count, built;
+};
+static_assert(sizeof(CellWindow) == sizeof(ndtpso_cell_window), "cell window ABI");
+
+__global__ void __launch_bounds__(256)
+k_cells_build_windowed(CellWindow* __restrict__ cells, int n_cells, const uint32_t* __restrict__ off,
+                       const double2* __restrict__ pts) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cells) return;
+  CellWindow w = cells[c];
+  const uint32_t p0 = off[c], p1 = off[c + 1];
+  // s_current_partial_sum: running sum of the current slot's points in insertion order (ndtcell.cpp:30)
+  double cx = 0., cy = 0.;
+  for (uint32_t i = p0; i < p1; ++i) {
+    cx += pts[i].x;
+    cy += pts[i].y;
+  }
+  // WINDOW_ADD (ndtcell.h:13-15): global = (global + partial) - partials[idx]; partials[idx] = partial
+  w.global_sum[0] = (w.global_sum[0] + cx) - w.slot_sum[0];
+  w.global_sum[1] = (w.global_sum[1] + cy) - w.slot_sum[1];
+  w.slot_sum[0] = cx;
+  w.slot_sum[1] = cy;
+  w.global_count = (w.global_count + w.current_count) - w.slot_count;
+  w.slot_count = w.current_count;
+  if (w.global_count > 2) {
+    const double mx = w.global_sum[0] / (double)w.global_count;  // ndtcell.cpp:44
+    const double my = w.global_sum[1] / (double)w.global_count;
+    double c00 = 0., c01 = 0., c10 = 0., c11 = 0.;
+    for (uint32_t i = p0; i < p1; ++i) {  // ndtcell.cpp:49-52
+      const double d0 = pts[i].x - mx, d1 = pts[i].y - my;
+      c00 += d0 * d0;
+      c01 += d0 * d1;
+      c10 += d1 * d0;
+      c11 += d1 * d1;
+    }
+    const double cov[4] = {c00, c01, c10, c11};
+    for (int k = 0; k < 4; ++k) {  // ndtcell.cpp:54-55
+      w.global_covar_sum[k] = (w.global_covar_sum[k] + cov[k]) - w.slot_covar[k];
+      w.slot_covar[k] = cov[k];
+    }
+    // s_calc_covar_inverse, ndtcell.cpp:93-111 (eigenvalues of the 2x2 in closed form)
+    const double nn = (double)w.global_count;
+    const double v00 = w.global_covar_sum[0] / nn, v01 = w.global_covar_sum[1] / nn;
+    const double v10 = w.global_covar_sum[2] / nn, v11 = w.global_covar_sum[3] / nn;
+    const double hp = 0.5 * (v00 - v11);
+    const double q = sqrt(hp * hp + v01 * v10);
+    const double mid = 0.5 * (v00 + v11);
+    const double e0 = mid + q, e1 = mid - q;
+    const double large_val = (e0 > e1) ? e0 : e1;
+    const double small_val = (e0 < e1) ? e0 : e1;
+    const double det = (small_val < .001 * large_val) ? .001 * large_val * large_val : v00 * v11 - v10 * v01;
+    w.mean[0] = mx;
+    w.mean[1] = my;
+    w.icov[0] = v11 / det;
+    w.icov[1] = -v01 / det;
+    w.icov[2] = -v10 / det;
+    w.icov[3] = v00 / det;
+    w.built = 1;
+  }
+  cells[c] = w;
+}
+
+// fp32 Cholesky records of a table image whose mean/ab/cd arrays were uploaded by the host
+__global__ void __launch_bounds__(256)
+k_fill_chol(unsigned char* __restrict__ image, int n_words, int rec_cap, int n_cells) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_cells) return;
+  const double2 ab = reinterpret_cast<const double2*>(image + image_ab_offset(n_words, rec_cap))[s];
+  const double2 cd = reinterpret_cast<const double2*>(image + image_cd_offset(n_words, rec_cap))[s];
+  float l[4];
+  make_chol(ab.x, ab.y, cd.x, cd.y, l);
+  reinterpret_cast<float4*>(image + image_chol_offset(n_words, rec_cap))[s] = make_float4(l[0], l[1], l[2], l[3]);
+}
+
 // ---- K1 --------------------------------------------------------------------------------------
 template <int MODE, int PATH, bool DUMP>
 __global__ void __launch_bounds__(1024)
@@ -636,7 +737,6 @@ int ndtpso_ref_set_cells(ndtpso_ctx* c, const ndtpso_grid* grid, uint32_t n_cell
   double2* t_mean = reinterpret_cast<double2*>(img.data() + image_mean_offset(wn.n_words));
   double2* t_ab = reinterpret_cast<double2*>(img.data() + image_ab_offset(wn.n_words, wn.rec_cap));
   double2* t_cd = reinterpret_cast<double2*>(img.data() + image_cd_offset(wn.n_words, wn.rec_cap));
-  float4* t_chol = reinterpret_cast<float4*>(img.data() + image_chol_offset(wn.n_words, wn.rec_cap));
   std::vector<std::pair<int, uint32_t>> order(n_cells);
   for (uint32_t i = 0; i < n_cells; ++i) {
     const int ix = index[i] % g.W, iy = index[i] / g.W;
@@ -656,14 +756,16 @@ int ndtpso_ref_set_cells(ndtpso_ctx* c, const ndtpso_grid* grid, uint32_t n_cell
     t_mean[s] = make_double2(mean[2 * i], mean[2 * i + 1]);
     t_ab[s] = make_double2(icov[4 * i], icov[4 * i + 1]);
     t_cd[s] = make_double2(icov[4 * i + 2], icov[4 * i + 3]);
-    float l[4];
-    make_chol(icov[4 * i], icov[4 * i + 1], icov[4 * i + 2], icov[4 * i + 3], l);
-    t_chol[s] = make_float4(l[0], l[1], l[2], l[3]);
   }
   hdr->n_built = n_cells;
   hdr->n_created = n_cells;
   HIP_TRY(c, c->image.reserve(bytes));
   HIP_TRY(c, hipMemcpyAsync(c->image.p, img.data(), bytes, hipMemcpyHostToDevice, c->stream));
+  if (n_cells) {
+    hipLaunchKernelGGL(k_fill_chol, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, (unsigned char*)c->image.p,
+                       wn.n_words, wn.rec_cap, (int)n_cells);
+    HIP_TRY(c, hipGetLastError());
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   c->grid = *grid;
   c->g = g;
@@ -682,6 +784,51 @@ int ndtpso_ref_get_cells(ndtpso_ctx* c, ndtpso_cell_row* rows, uint32_t max_rows
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpy(rows, c->rows.p, sizeof(CellRow) * (size_t)n, hipMemcpyDeviceToHost));
   }
+  return NDTPSO_OK;
+}
+
+int ndtpso_points_to_cells(ndtpso_ctx* c, const ndtpso_grid* grid, const double* xy, uint32_t n, const double trans[3],
+                           double* xy_out, int32_t* cell_idx) {
+  if (!c || (n && (!xy || !xy_out || !cell_idx))) return fail(c, NDTPSO_E_ARG, "null argument");
+  GridP g;
+  if (make_grid(grid, &g) != NDTPSO_OK) return fail(c, NDTPSO_E_ARG, "bad grid");
+  if (n == 0) return NDTPSO_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->xy.reserve((size_t)n * 16));
+  HIP_TRY(c, c->xy2.reserve((size_t)n * 16));
+  HIP_TRY(c, c->dump.reserve((size_t)n * 4));
+  HIP_TRY(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  const int do_trans = trans ? 1 : 0;
+  const double tc = trans ? std::cos(trans[2]) : 1., ts = trans ? std::sin(trans[2]) : 0.;
+  hipLaunchKernelGGL(k_points_to_cells, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double2*)c->xy.p, (int)n,
+                     g, do_trans, tc, ts, trans ? trans[0] : 0., trans ? trans[1] : 0., (double2*)c->xy2.p,
+                     (int32_t*)c->dump.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(xy_out, c->xy2.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(cell_idx, c->dump.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NDTPSO_OK;
+}
+
+int ndtpso_cells_build_windowed(ndtpso_ctx* c, uint32_t n_cells, ndtpso_cell_window* cells, const uint32_t* pts_offset,
+                                const double* pts_xy) {
+  if (!c || (n_cells && (!cells || !pts_offset))) return fail(c, NDTPSO_E_ARG, "null argument");
+  if (n_cells == 0) return NDTPSO_OK;
+  const size_t n_pts = pts_offset[n_cells];
+  if (n_pts && !pts_xy) return fail(c, NDTPSO_E_ARG, "null points");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->rows.reserve(sizeof(CellWindow) * (size_t)n_cells));
+  HIP_TRY(c, c->seeds.reserve(4 * ((size_t)n_cells + 1)));
+  HIP_TRY(c, c->xy.reserve(std::max<size_t>(n_pts, 1) * 16));
+  HIP_TRY(c, hipMemcpyAsync(c->rows.p, cells, sizeof(CellWindow) * (size_t)n_cells, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->seeds.p, pts_offset, 4 * ((size_t)n_cells + 1), hipMemcpyHostToDevice, c->stream));
+  if (n_pts) HIP_TRY(c, hipMemcpyAsync(c->xy.p, pts_xy, n_pts * 16, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_cells_build_windowed, dim3((n_cells + 255) / 256), dim3(256), 0, c->stream, (CellWindow*)c->rows.p,
+                     (int)n_cells, (const uint32_t*)c->seeds.p, (const double2*)c->xy.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(cells, c->rows.p, sizeof(CellWindow) * (size_t)n_cells, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->n_rows = 0;  // rows buffer reused
   return NDTPSO_OK;
 }
 
