@@ -143,8 +143,9 @@ __device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
 // lanes (quad xor 1, quad xor 2, half-row mirror, row mirror), then the four row sums via readlane.
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  const int l = __double2loint(v), h = __double2hiint(v);  // every lane is a valid source for these controls
+  const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -323,16 +324,25 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
     const bool ok = (int)(rx < (unsigned)dn.dw) & (int)(ry < (unsigned)dn.dh);
     lin[u] = ok ? __umul24(ry, (unsigned)dn.dw) + rx : 0u;  // cell 0 is a border cell: always the null record
   }
+  // the dense table starts at LDS address 0 and records are addressed absolutely: plain shifts, no base add
+  typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef float v4f_t __attribute__((ext_vector_type(4)));
+  typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+  typedef const v4f_t __attribute__((address_space(3))) * lds_f4_t;
+  (void)lds0;
   unsigned e[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) e[u] = reinterpret_cast<const unsigned short*>(lds0)[lin[u]];
+  for (int u = 0; u < U; ++u) e[u] = *(lds_u16_t)(uintptr_t)(lin[u] << 1);
   double2 m[U];
   float4 f[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const unsigned char* r = lds0 + (e[u] << 4);
-    m[u] = *reinterpret_cast<const double2*>(r);
-    f[u] = *reinterpret_cast<const float4*>(r + 16);
+    const unsigned r = e[u] << 4;
+    const v2d_t mm = *(lds_d2_t)(uintptr_t)r;
+    const v4f_t ff = *(lds_f4_t)(uintptr_t)(r + 16u);
+    m[u] = make_double2(mm.x, mm.y);
+    f[u] = make_float4(ff.x, ff.y, ff.z, ff.w);
   }
   float t[U];
 #pragma unroll
@@ -825,10 +835,10 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P) {
   return sw;
 }
 
-struct PsoShared {  // small control block in static LDS
+struct PsoShared {  // small control block in LDS
   double gb[3];
   double gbc;
-  int jstar;
+  int jstar[3];  // first improver of a group, rotating by group number (see pso_run_wg)
   int pad;
   RngState rng;
 };
@@ -842,9 +852,11 @@ struct EvalCtx {
   const unsigned char* lds0;
 };
 
+// One wave per item.  `improver` (optional): the evaluating wave itself records the lowest item index whose
+// cost beats `gbc` (core.cpp:97 under single-thread order), so no separate detection pass is needed.
 template <int MODE, int PATH>
 __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first,
-                                  int last /*exclusive*/) {
+                                  int last /*exclusive*/, double gbc, int* improver) {
   const int n_waves = blockDim.x >> 6;
   for (int j = first + wave_id(); j < last; j += n_waves) {
     const double c = sw.tc[j], s = sw.ts[j];
@@ -854,7 +866,10 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       cost = eval_pose_wave_dense<false>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
     else
       cost = eval_pose_wave<MODE, PATH == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
-    if (lane_id() == 0) sw.tcost[j] = cost;
+    if (lane_id() == 0) {
+      sw.tcost[j] = cost;
+      if (improver && cost < gbc) atomicMin(improver, j);
+    }
   }
 }
 
@@ -895,7 +910,7 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
     }
   }
   __syncthreads();
-  eval_items<MODE, PATH>(E, pts, n, sw, S, 0, S);
+  eval_items<MODE, PATH>(E, pts, n, sw, S, 0, S, 0., nullptr);
   n_evals += S;
   n_rounds += 1;
   __syncthreads();
@@ -923,6 +938,9 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
 
   // ---- iterations: core.cpp:78-109 ----
   double w = ps.w;
+  unsigned grp = 0;
+  if (tid == 0) sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
+  __syncthreads();
   for (int it = 0; it < ps.I; ++it) {
     if (gen) {
       if (wave_id() == 0) rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 6 * P);
@@ -933,6 +951,11 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
     // proposal made against the gbest that was current when it was (re)proposed; when a group contains the
     // first improver j*, particles up to j* are committed and everything after it is re-proposed -- so only
     // the tail of one group (< G evaluations) is ever thrown away per gbest update.
+    //
+    // Synchronisation: ONE workgroup barrier per group in the common case.  The evaluating wave records a
+    // gbest improver itself (atomicMin into jstar[group % 3]; slot (g+2)%3 is reset after group g's barrier,
+    // two barriers ahead of its next use).  Committing a group touches only pos/vel/pbest of that group,
+    // which no evaluation reads, so waves run on into the next group without waiting for it.
     int lo = 0;
     bool need_propose = true;
     while (lo < P) {
@@ -957,20 +980,17 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
           sw.ts[j] = sn;
         }
         need_propose = false;
+        __syncthreads();  // proposals (and the commits before them) visible to every wave
       }
-      if (tid == 0) sh->jstar = P;
-      __syncthreads();
+      const int slot = (int)(grp % 3u);
       const int hi_g = min(lo + ps.G, P);
-      eval_items<MODE, PATH>(E, pts, n, sw, S, lo, hi_g);
+      eval_items<MODE, PATH>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot]);
       n_evals += (uint32_t)(hi_g - lo);
       n_rounds += 1;
       __syncthreads();
-      // first particle (index order) whose cost beats gbest: core.cpp:97-104 under single-thread order
-      const double gbc = sh->gbc;
-      for (int j = lo + tid; j < hi_g; j += blockDim.x)
-        if (sw.tcost[j] < gbc) atomicMin(&sh->jstar, j);
-      __syncthreads();
-      const int js = sh->jstar;
+      const int js = sh->jstar[slot];
+      if (tid == 0) sh->jstar[(grp + 2u) % 3u] = P;
+      ++grp;
       const int last = (js < P) ? js : (hi_g - 1);
       for (int j = lo + tid; j <= last; j += blockDim.x) {
         const double cst = sw.tcost[j];
@@ -983,20 +1003,24 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
           if (better) sw.pb[k * S + j] = np;
         }
         if (better) sw.pbc[j] = cst;
-        if (j == js) {
-          sh->gbc = cst;
-          for (int k = 0; k < 3; ++k) sh->gb[k] = sw.tpos[k * S + j];
-        }
       }
       if (js < P) {
+        // gbest moves (core.cpp:97-104): every thread has read the old gbc above (eval_items), so one more
+        // barrier orders those reads before the update, and the re-proposal barrier publishes it
+        __syncthreads();
+        if (tid == 0) {
+          sh->gbc = sw.tcost[js];
+          for (int k = 0; k < 3; ++k) sh->gb[k] = sw.tpos[k * S + js];
+        }
+        __syncthreads();
         n_gb += 1;
         lo = js + 1;
         need_propose = true;
       } else {
         lo = hi_g;
       }
-      __syncthreads();
     }
+    __syncthreads();  // all commits of this iteration done before the next draws/proposals
     w *= ps.wdamp;  // core.cpp:108
   }
 
