@@ -30,12 +30,15 @@ constexpr int kCtrlBytes = 512;      // control block (PsoShared + compaction co
 struct Layout {
   int ctrl_off, hdr_off, bm_off, mean_off, ab_off, cd_off, chol_off, drec_off, pts_off, region_off, total;
   int key_off, cellkey_off, cnt_off, bm2_off;  // build scratch inside region
+  int swarm_global;  // 1: the swarm does not fit in LDS and lives in an HBM workspace (large-swarm configs)
 };
 
 // fmt: kScoreF32 -> mean+chol, kScoreF64 -> mean+ab+cd, 2 -> everything (table build kernel);
 // ddw > 0: dense form with a ddw x ddh cell table (fp32 score only)
-Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw = 0, int ddh = 0) {
+Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw = 0, int ddh = 0,
+                   bool swarm_global = false) {
   Layout L;
+  L.swarm_global = swarm_global ? 1 : 0;
   const bool dense = ddw > 0;
   int off = dense ? dense_tab_bytes(ddw, ddh) : 0;
   L.ctrl_off = off;
@@ -76,7 +79,7 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
     L.bm_off = L.region_off + scratch;
     scratch += align16(n_words * 8);
   }
-  const int swarm = (P > 0) ? swarm_bytes(P) : 0;
+  const int swarm = (P > 0 && !swarm_global) ? swarm_bytes(P) : 0;
   L.total = L.region_off + std::max(scratch, swarm);
   return L;
 }
@@ -311,15 +314,15 @@ template <int MODE, int PATH>
 __global__ void __launch_bounds__(1024)
 k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n, GridP g, WinP wn, Layout L,
         DenseP dn, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
-        const int32_t* __restrict__ table, double* __restrict__ out_pose, double* __restrict__ out_cost,
-        AlignStats* __restrict__ stats) {
+        const int32_t* __restrict__ table, unsigned char* __restrict__ ws, double* __restrict__ out_pose,
+        double* __restrict__ out_cost, AlignStats* __restrict__ stats) {
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   stage_image<MODE, PATH>(image, g, wn, L, dn);
   copy16(pts, xy, n * 16);
   pad_points_wg(pts, n);
   __syncthreads();
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
-  const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
+  const Swarm sw = swarm_carve(L.swarm_global ? ws : g_lds + L.region_off, ps.P);
   pso_run_wg<MODE, PATH>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost, stats);
   if (threadIdx.x == 0 && stats) {
     const ImageHeader* h = reinterpret_cast<const ImageHeader*>(g_lds + L.hdr_off);
@@ -337,7 +340,8 @@ __global__ void __launch_bounds__(1024, NDTPSO_PAIRS_MIN_WAVES)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev,
               const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables, size_t table_stride,
-              double* __restrict__ out_pose, double* __restrict__ out_cost, AlignStats* __restrict__ stats) {
+              unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
+              double* __restrict__ out_cost, AlignStats* __restrict__ stats) {
   const size_t b = blockIdx.x;
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   ImageHeader* hdr = reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off);
@@ -354,7 +358,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   __syncthreads();
 
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
-  const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
+  const Swarm sw = swarm_carve(L.swarm_global ? ws + b * ws_stride : g_lds + L.region_off, ps.P);
   pso_run_wg<MODE, PATH>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                          tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off), out_pose + 3 * b,
                          out_cost ? out_cost + b : nullptr, stats ? stats + b : nullptr);
@@ -397,7 +401,7 @@ struct ndtpso_ctx {
   GridP g{};
   WinP wn{};
   uint32_t n_rows = 0;
-  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds;
+  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws;
 };
 
 namespace {
@@ -511,6 +515,11 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
       plan->dn = make_dense(wn, Ld);
     }
   }
+  if (plan->L.total > kMaxLds && P > 0) {  // large swarm: keep the table + points in LDS, the swarm in HBM (L2)
+    plan->path = bitmap_path;
+    plan->dn = DenseP{0, 0, 0, 0, 0};
+    plan->L = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, 0, 0, true);
+  }
   return plan->L.total <= kMaxLds;
 }
 
@@ -573,7 +582,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
-                    &c->small, &c->table, &c->out, &c->seeds})
+                    &c->small, &c->table, &c->out, &c->seeds, &c->ws})
     b->release();
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -898,13 +907,15 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
   HIP_TRY(c, hipMemsetAsync(c->out.p, 0, 256, c->stream));
+  if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population)));
   const int waves = pick_waves(cfg->population, L.total, 1);
   const PsoP ps = make_pso(cfg, waves);
 #define LAUNCH_ALIGN(MODE, PATH)                                                                                   \
   hipLaunchKernelGGL((k_align<MODE, PATH>), dim3(1), dim3(waves * 64), L.total, c->stream,                         \
                      (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, plan.dn,  \
                      ps, (const double*)c->small.p, (const double*)c->small.p + 3, seed,                           \
-                     rand_table ? (const int32_t*)c->table.p : nullptr, d_out, d_out + 3, d_stats)
+                     rand_table ? (const int32_t*)c->table.p : nullptr, (unsigned char*)c->ws.p, d_out, d_out + 3,         \
+                     d_stats)
   if (mode == NDTPSO_SCORE_F32) {
     if (plan.path == 2) LAUNCH_ALIGN(kScoreF32, 2); else if (plan.path == 1) LAUNCH_ALIGN(kScoreF32, 1); else LAUNCH_ALIGN(kScoreF32, 0);
   } else {
@@ -969,10 +980,12 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
   const ScanP sp = make_scan(geom);
   const PsoP ps = make_pso(cfg, waves);
   const size_t stride = ndtpso_rand_draws(cfg);
+  const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population) : 0;
+  if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs));
 #define LAUNCH_PAIRS(MODE, PATH)                                                                                  \
   hipLaunchKernelGGL((k_align_pairs<MODE, PATH>), dim3(n_pairs), dim3(waves * 64), plan.L.total, c->stream, d_ref,  \
-                     d_new, sp, g, wn, plan.L, plan.dn, ps, d_guess, d_dev, d_seeds, d_tables, stride, d_pose,     \
-                     d_cost, reinterpret_cast<AlignStats*>(d_stats))
+                     d_new, sp, g, wn, plan.L, plan.dn, ps, d_guess, d_dev, d_seeds, d_tables, stride,             \
+                     (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, reinterpret_cast<AlignStats*>(d_stats))
   if (mode == NDTPSO_SCORE_F32) {
     if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
   } else {

@@ -44,8 +44,12 @@ def test_rand_draws_and_footprint_without_gpu():
     assert rc == 0 and 0 < lds <= 80 * 1024 and thr % 64 == 0      # two workgroups per CU
     rc, lds, thr = capi.align_pairs_footprint(geom, capi.Grid(60, 60, 0.3), cfg)   # non power-of-two cells
     assert rc == 0 and 0 < lds <= 160 * 1024
-    big = capi.PSOConfig.make(200, 4096)
-    rc, lds, _ = capi.align_pairs_footprint(capi.ScanGeom(2048, -2.3, 0.002, 30.0, 0.1), capi.Grid(60, 60, 0.25), big)
+    # BASELINE config 5 (2048 particles, 2048 beams, 0.25 m cells): table + points in LDS, swarm in HBM, 1 WG/CU
+    big = capi.PSOConfig.make(200, 2048)
+    rc, lds, thr = capi.align_pairs_footprint(capi.ScanGeom(2048, -2.3, 0.002, 30.0, 0.1), capi.Grid(60, 60, 0.25), big)
+    assert rc == 0 and 80 * 1024 < lds <= 160 * 1024 and thr == 1024
+    # a scan whose points alone exceed LDS is refused, loudly
+    rc, lds, _ = capi.align_pairs_footprint(capi.ScanGeom(12000, -2.3, 0.0004, 30.0, 0.1), capi.Grid(60, 60, 0.25), big)
     assert rc == capi.E_CAPACITY and lds == 0
 
 

@@ -155,3 +155,24 @@ def test_align_pairs_fused_matches_oracle(ctx, oracle, pairs8):
             assert np.abs(cost - want_cost).max() < 1e-9
     # accuracy vs ground truth is the reference's own (a few mm)
     assert np.abs(got - p.delta).max() < 2e-2
+
+
+def test_large_swarm_config5_shape(ctx, oracle):
+    """BASELINE config 5 geometry (2048 particles, 2048-beam scan, 0.25 m cells) with a short iteration count:
+    the swarm lives in an HBM workspace, the table uses the bitmap form; pose parity as for the small swarm."""
+    from ndtpso_slam_amd import capi, synth
+    p = synth.make_pairs(2, n_beams=2048, seed=21)
+    P, I, cs = 2048, 3, 0.25
+    geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+    want, want_cost, _ = oracle.align_pairs(p.ref_ranges, p.new_ranges, p.angle_min, p.angle_inc, p.range_max, 0.1,
+                                            FRAME_M, FRAME_M, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P),
+                                            p.seeds)
+    for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        got, cost, stats = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, capi.Grid(FRAME_M, FRAME_M, cs), (0, 0, 0),
+                                           DEVIATION, capi.PSOConfig.make(I, P), seeds=p.seeds, mode=mode)
+        assert (stats["status"] == 0).all()
+        d = np.abs(got - want)
+        print("config-5 shape, mode", mode, "max |dpose|", d.max(axis=0), "evals", stats["cost_evals"], "built", stats["n_built"])
+        assert (d < 1e-3).all()
+        if mode == capi.SCORE_F64:
+            assert d.max() < 1e-9 and np.abs(cost - want_cost).max() < 1e-8
