@@ -305,6 +305,9 @@ k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict_
       cost = eval_pose_wave_dense<DUMP>(E.g, E.dn, E.lds0, pts, n, cn, sn, tx, ty, dp);
     else
       cost = eval_pose_wave_t<MODE, PATH == 1, DUMP>(E.g, E.wn, E.T, pts, n, cn, sn, tx, ty, dp);
+    if constexpr (MODE == kScoreF32) {
+      if (cost > -kTinyCost) cost = eval_pose_wave_tiny<PATH>(E, pts, n, cn, sn, tx, ty);  // underflow regime
+    }
     if (lane_id() == 0) costs[k] = cost;
   }
 }
@@ -327,22 +330,20 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   if (threadIdx.x == 0 && stats) {
     const ImageHeader* h = reinterpret_cast<const ImageHeader*>(g_lds + L.hdr_off);
     stats->n_built = h->n_built;
-    stats->status = h->status;
+    stats->status = (stats->status & kStatusNeedsF64) | h->status;
   }
 }
 
 // ---- fused scan pairs: K3a(ref) + K3b + K3a(new) + K2, everything in LDS -------------------------
-#ifndef NDTPSO_PAIRS_MIN_WAVES
-#define NDTPSO_PAIRS_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for
-#endif
 template <int MODE, int PATH>
-__global__ void __launch_bounds__(1024, NDTPSO_PAIRS_MIN_WAVES)
+__global__ void __launch_bounds__(1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev,
               const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables, size_t table_stride,
               unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
-              double* __restrict__ out_cost, AlignStats* __restrict__ stats) {
+              double* __restrict__ out_cost, AlignStats* __restrict__ stats, int gated) {
   const size_t b = blockIdx.x;
+  if (gated && !(stats[b].status & kStatusNeedsF64)) return;  // redo launch: only alignments the fp32 pass flagged
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   ImageHeader* hdr = reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off);
 
@@ -364,7 +365,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
                          out_cost ? out_cost + b : nullptr, stats ? stats + b : nullptr);
   if (threadIdx.x == 0 && stats) {
     stats[b].n_built = hdr->n_built;
-    stats[b].status = hdr->status;
+    stats[b].status = (gated ? 0u : (stats[b].status & kStatusNeedsF64)) | hdr->status;
   }
 }
 
@@ -401,7 +402,7 @@ struct ndtpso_ctx {
   GridP g{};
   WinP wn{};
   uint32_t n_rows = 0;
-  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws;
+  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate;
 };
 
 namespace {
@@ -582,7 +583,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
-                    &c->small, &c->table, &c->out, &c->seeds, &c->ws})
+                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate})
     b->release();
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -883,27 +884,12 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
 
 // ---- K2 ------------------------------------------------------------------------------------------
 
-int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess[3], const double deviation[3],
-                 const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
-                 double* out_cost, ndtpso_align_stats* stats) {
-  if (!c || (!xy && n) || !guess || !deviation || !out_pose) return fail(c, NDTPSO_E_ARG, "null argument");
-  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
-  if (int rc = check_pso(c, cfg)) return rc;
-  if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
-  HIP_TRY(c, hipSetDevice(c->device));
+static int align_once(ndtpso_ctx* c, uint32_t n, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table, int mode,
+                      double host[4 + sizeof(AlignStats) / 8]) {
   Plan plan;
   if (!make_plan(mode, c->g, c->wn, std::max<int>((int)n, 1), cfg->population, &plan))
     return fail(c, NDTPSO_E_CAPACITY, "table + points + swarm do not fit in LDS");
   const Layout& L = plan.L;
-  const size_t n_draw = ndtpso_rand_draws(cfg);
-  HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
-  HIP_TRY(c, c->small.reserve(256));
-  HIP_TRY(c, c->out.reserve(256));
-  if (rand_table) HIP_TRY(c, c->table.reserve(n_draw * 4));
-  if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
-  double gd[6] = {guess[0], guess[1], guess[2], deviation[0], deviation[1], deviation[2]};
-  HIP_TRY(c, hipMemcpyAsync(c->small.p, gd, sizeof(gd), hipMemcpyHostToDevice, c->stream));
-  if (rand_table) HIP_TRY(c, hipMemcpyAsync(c->table.p, rand_table, n_draw * 4, hipMemcpyHostToDevice, c->stream));
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
   HIP_TRY(c, hipMemsetAsync(c->out.p, 0, 256, c->stream));
@@ -914,7 +900,7 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   hipLaunchKernelGGL((k_align<MODE, PATH>), dim3(1), dim3(waves * 64), L.total, c->stream,                         \
                      (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, plan.dn,  \
                      ps, (const double*)c->small.p, (const double*)c->small.p + 3, seed,                           \
-                     rand_table ? (const int32_t*)c->table.p : nullptr, (unsigned char*)c->ws.p, d_out, d_out + 3,         \
+                     have_table ? (const int32_t*)c->table.p : nullptr, (unsigned char*)c->ws.p, d_out, d_out + 3, \
                      d_stats)
   if (mode == NDTPSO_SCORE_F32) {
     if (plan.path == 2) LAUNCH_ALIGN(kScoreF32, 2); else if (plan.path == 1) LAUNCH_ALIGN(kScoreF32, 1); else LAUNCH_ALIGN(kScoreF32, 0);
@@ -923,9 +909,38 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   }
 #undef LAUNCH_ALIGN
   HIP_TRY(c, hipGetLastError());
-  double host[4 + sizeof(AlignStats) / 8];
-  HIP_TRY(c, hipMemcpyAsync(host, c->out.p, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(host, c->out.p, (4 + sizeof(AlignStats) / 8) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NDTPSO_OK;
+}
+
+int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess[3], const double deviation[3],
+                 const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
+                 double* out_cost, ndtpso_align_stats* stats) {
+  if (!c || (!xy && n) || !guess || !deviation || !out_pose) return fail(c, NDTPSO_E_ARG, "null argument");
+  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
+  if (int rc = check_pso(c, cfg)) return rc;
+  if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t n_draw = ndtpso_rand_draws(cfg);
+  HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
+  HIP_TRY(c, c->small.reserve(256));
+  HIP_TRY(c, c->out.reserve(256));
+  if (rand_table) HIP_TRY(c, c->table.reserve(n_draw * 4));
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  double gd[6] = {guess[0], guess[1], guess[2], deviation[0], deviation[1], deviation[2]};
+  HIP_TRY(c, hipMemcpyAsync(c->small.p, gd, sizeof(gd), hipMemcpyHostToDevice, c->stream));
+  if (rand_table) HIP_TRY(c, hipMemcpyAsync(c->table.p, rand_table, n_draw * 4, hipMemcpyHostToDevice, c->stream));
+  double host[4 + sizeof(AlignStats) / 8];
+  int rc = align_once(c, n, cfg, seed, rand_table != nullptr, mode, host);
+  if (rc != NDTPSO_OK) return rc;
+  AlignStats st;
+  std::memcpy(&st, host + 4, sizeof(st));
+  if (mode == NDTPSO_SCORE_F32 && (st.status & kStatusNeedsF64)) {
+    // fp32 underflow regime (see ndtpso_kernels.hpp): this alignment is redone with the fp64 score
+    rc = align_once(c, n, cfg, seed, rand_table != nullptr, NDTPSO_SCORE_F64, host);
+    if (rc != NDTPSO_OK) return rc;
+  }
   out_pose[0] = host[0];
   out_pose[1] = host[1];
   out_pose[2] = host[2];
@@ -960,6 +975,36 @@ int ndtpso_align_pairs_footprint(const ndtpso_scan_geom* geom, const ndtpso_grid
   return rc;
 }
 
+static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, const float* d_new,
+                        const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess, const double* d_dev,
+                        const ndtpso_pso_config* cfg, const uint32_t* d_seeds, const int32_t* d_tables, int mode,
+                        double* d_pose, double* d_cost, AlignStats* d_stats, int gated) {
+  GridP g;
+  WinP wn;
+  Plan plan;
+  int waves = 0;
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves);
+  if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
+  if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
+  const ScanP sp = make_scan(geom);
+  const PsoP ps = make_pso(cfg, waves);
+  const size_t stride = ndtpso_rand_draws(cfg);
+  const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population) : 0;
+  if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs));
+#define LAUNCH_PAIRS(MODE, PATH)                                                                                  \
+  hipLaunchKernelGGL((k_align_pairs<MODE, PATH>), dim3(n_pairs), dim3(waves * 64), plan.L.total, c->stream, d_ref,  \
+                     d_new, sp, g, wn, plan.L, plan.dn, ps, d_guess, d_dev, d_seeds, d_tables, stride,             \
+                     (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gated)
+  if (mode == NDTPSO_SCORE_F32) {
+    if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
+  } else {
+    if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
+  }
+#undef LAUNCH_PAIRS
+  HIP_TRY(c, hipGetLastError());
+  return NDTPSO_OK;
+}
+
 int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, const float* d_new,
                            const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess,
                            const double* d_dev, const ndtpso_pso_config* cfg, const uint32_t* d_seeds,
@@ -969,31 +1014,23 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
     return fail(c, NDTPSO_E_ARG, "null argument");
   if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
   if (n_pairs == 0) return NDTPSO_OK;
-  GridP g;
-  WinP wn;
-  Plan plan;
-  int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves);
-  if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
-  if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
   HIP_TRY(c, hipSetDevice(c->device));
-  const ScanP sp = make_scan(geom);
-  const PsoP ps = make_pso(cfg, waves);
-  const size_t stride = ndtpso_rand_draws(cfg);
-  const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population) : 0;
-  if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs));
-#define LAUNCH_PAIRS(MODE, PATH)                                                                                  \
-  hipLaunchKernelGGL((k_align_pairs<MODE, PATH>), dim3(n_pairs), dim3(waves * 64), plan.L.total, c->stream, d_ref,  \
-                     d_new, sp, g, wn, plan.L, plan.dn, ps, d_guess, d_dev, d_seeds, d_tables, stride,             \
-                     (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, reinterpret_cast<AlignStats*>(d_stats))
-  if (mode == NDTPSO_SCORE_F32) {
-    if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
-  } else {
-    if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
+  AlignStats* st = reinterpret_cast<AlignStats*>(d_stats);
+  if (!st) {  // the fp32 pass reports underflowed alignments through the stats block: keep one internally
+    HIP_TRY(c, c->gate.reserve(sizeof(AlignStats) * (size_t)n_pairs));
+    st = reinterpret_cast<AlignStats*>(c->gate.p);
   }
-#undef LAUNCH_PAIRS
-  HIP_TRY(c, hipGetLastError());
-  return NDTPSO_OK;
+  HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(AlignStats) * (size_t)n_pairs, c->stream));
+  int rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
+                        st, 0);
+  if (rc != NDTPSO_OK || mode != NDTPSO_SCORE_F32) return rc;
+  if (std::getenv("NDTPSO_NO_F64_REDO")) return rc;  // diagnostics only
+  // second, gated launch: alignments whose fp32 costs underflowed (rare; degenerate overlap) are redone with
+  // the fp64 score; every other workgroup exits on its first instruction.  If the fp64 form does not fit in
+  // LDS the flag (status bit 2) simply stays set.
+  rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose,
+                    d_cost, st, 1);
+  return rc == NDTPSO_E_CAPACITY ? NDTPSO_OK : rc;
 }
 
 int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges, const float* new_ranges,

@@ -839,7 +839,7 @@ struct PsoShared {  // small control block in LDS
   double gb[3];
   double gbc;
   int jstar[3];  // first improver of a group, rotating by group number (see pso_run_wg)
-  int pad;
+  int tiny;      // fp32 score mode: some cost of the current group fell in the underflow regime
   RngState rng;
 };
 
@@ -852,11 +852,80 @@ struct EvalCtx {
   const unsigned char* lds0;
 };
 
+// ---- fp32 score mode, underflow regime ----------------------------------------------------------------
+//
+// v_exp_f32 flushes results below 2^-126 to zero.  That is irrelevant while the score is O(1..N), but when
+// (almost) nothing overlaps -- a reference with a single tiny cell, a guess far off -- the whole sum can be
+// 1e-50 or 1e-200 in the reference's fp64 arithmetic, and its PSO still orders particles by those values.
+// The PSO kernels therefore stop as soon as an fp32 cost lands above -kTinyCost and flag the alignment
+// (kStatusNeedsF64); the host side re-runs flagged alignments with the fp64-score kernel, gated on that flag.
+// ndtpso_cost_batch re-evaluates such a pose in place (eval_pose_wave_tiny: same records, fp64 exponential).
+constexpr uint32_t kStatusNeedsF64 = 4u;
+constexpr double kTinyCost = 1e-28;
+
+template <int PATH>
+__device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const double2* __restrict__ pts, int n, double c,
+                                                   double s, double tx, double ty) {
+  const int lane = lane_id();
+  const int n_pad = round_up(n, kWave);
+  double acc = 0.;
+  if constexpr (PATH == 2) {
+    const DenseItem it = dense_item(E.g, E.dn, c, s, tx, ty);
+    for (int base = 0; base < n_pad; base += kWave) {
+      const double2 p = pts[base + lane];
+      const double gx = fma(p.x, it.C, fma(-p.y, it.S, it.TX));
+      const double gy = fma(p.x, it.S, fma(p.y, it.C, it.TY));
+      const unsigned rx = (unsigned)(int)gx, ry = (unsigned)(int)gy;
+      const bool ok = (rx < (unsigned)E.dn.dw) && (ry < (unsigned)E.dn.dh);
+      const unsigned lin = ok ? ry * (unsigned)E.dn.dw + rx : 0u;
+      const unsigned e = reinterpret_cast<const unsigned short*>(E.lds0)[lin];
+      const DenseRec* r = reinterpret_cast<const DenseRec*>(E.lds0 + (e << 4));
+      const double d0 = gx - r->mgx, d1 = gy - r->mgy;
+      const double a = (double)r->l11 * d0 + (double)r->l21 * d1, b = (double)r->l22 * d1;
+      acc += exp2(-(a * a + b * b + (double)r->w));  // null record: w = +inf -> 0
+    }
+  } else {
+    const GridP& g = E.g;
+    const WinP& wn = E.wn;
+    for (int base = 0; base < n_pad; base += kWave) {
+      const double2 p = pts[base + lane];
+      const double qx = fma(p.x, c, fma(-p.y, s, tx));
+      const double qy = fma(p.x, s, fma(p.y, c, ty));
+      double term = 0.;
+      if (fabs(qx) < g.hw && fabs(qy) < g.hh) {
+        int ix, iy;
+        cell_coords<PATH == 1>(g, qx, qy, ix, iy);
+        if (ix == g.W) {
+          ix = 0;
+          iy += 1;
+        }
+        const unsigned rx = (unsigned)(ix - wn.x0), ry = (unsigned)(iy - wn.y0);
+        if (rx < (unsigned)wn.w && ry < (unsigned)wn.h) {
+          const unsigned lin = ry * (unsigned)wn.w + rx;
+          const uint2 e = E.T.bm[lin >> 5];
+          const unsigned bit = lin & 31u;
+          if ((e.x >> bit) & 1u) {
+            const unsigned slot = e.y + __popc(e.x & ((1u << bit) - 1u));
+            const double2 m = E.T.mean[slot];
+            const float4 f = E.T.chol[slot];
+            const double d0 = qx - m.x, d1 = qy - m.y;
+            const double a = (double)f.x * d0 + (double)f.y * d1, b = (double)f.z * d1;
+            term = exp2(-(a * a + b * b));
+          }
+        }
+      }
+      acc += term;
+    }
+  }
+  return -wave_sum(acc);
+}
+
+
 // One wave per item.  `improver` (optional): the evaluating wave itself records the lowest item index whose
 // cost beats `gbc` (core.cpp:97 under single-thread order), so no separate detection pass is needed.
 template <int MODE, int PATH>
 __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first,
-                                  int last /*exclusive*/, double gbc, int* improver) {
+                                  int last /*exclusive*/, double gbc, int* improver, int* tiny) {
   const int n_waves = blockDim.x >> 6;
   for (int j = first + wave_id(); j < last; j += n_waves) {
     const double c = sw.tc[j], s = sw.ts[j];
@@ -868,13 +937,20 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       cost = eval_pose_wave<MODE, PATH == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
     if (lane_id() == 0) {
       sw.tcost[j] = cost;
-      if (improver && cost < gbc) atomicMin(improver, j);
+      // A cost in the fp32 underflow regime is only ambiguous when what it is compared with is there too: an
+      // outlier particle that left the map scores ~0 against a pbest of -400 and loses in any arithmetic.
+      // improver == nullptr is the swarm initialisation, where the cost becomes the particle's pbest.
+      if (MODE == kScoreF32 && cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))
+        *tiny = 1;  // the alignment is handed to the fp64-score kernel (see pso_run_wg)
+      else if (improver && cost < gbc)
+        atomicMin(improver, j);
     }
   }
 }
 
+// returns false when the alignment was abandoned for the fp64-score kernel (fp32 underflow regime)
 template <int MODE, int PATH>
-__device__ inline void pso_run_wg(const EvalCtx& E,
+__device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
                                   PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats) {
@@ -885,6 +961,7 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
   uint32_t n_evals = 0, n_rounds = 0, n_gb = 0;
 
   // ---- swarm initialisation: core.cpp:58-69 ----
+  if (tid == 0) sh->tiny = 0;
   if (gen && wave_id() == 0) {
     rng_seed_wave0(&sh->rng, seed);
     rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 3 * S);
@@ -910,10 +987,14 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
     }
   }
   __syncthreads();
-  eval_items<MODE, PATH>(E, pts, n, sw, S, 0, S, 0., nullptr);
+  eval_items<MODE, PATH>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny);
   n_evals += S;
   n_rounds += 1;
   __syncthreads();
+  if (MODE == kScoreF32 && sh->tiny) {  // underflow regime: give up, the fp64-score kernel redoes this alignment
+    if (tid == 0 && stats) stats->status |= kStatusNeedsF64;
+    return false;
+  }
   if (tid == 0) {
     double gbc = sw.tcost[P];
     int best = P;
@@ -984,10 +1065,14 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
       }
       const int slot = (int)(grp % 3u);
       const int hi_g = min(lo + ps.G, P);
-      eval_items<MODE, PATH>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot]);
+      eval_items<MODE, PATH>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny);
       n_evals += (uint32_t)(hi_g - lo);
       n_rounds += 1;
       __syncthreads();
+      if (MODE == kScoreF32 && sh->tiny) {
+        if (tid == 0 && stats) stats->status |= kStatusNeedsF64;
+        return false;
+      }
       const int js = sh->jstar[slot];
       if (tid == 0) sh->jstar[(grp + 2u) % 3u] = P;
       ++grp;
@@ -1034,6 +1119,7 @@ __device__ inline void pso_run_wg(const EvalCtx& E,
       stats->gbest_updates = n_gb;
     }
   }
+  return true;
 }
 
 }  // namespace ndtpso

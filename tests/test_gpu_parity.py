@@ -176,3 +176,68 @@ def test_large_swarm_config5_shape(ctx, oracle):
         assert (d < 1e-3).all()
         if mode == capi.SCORE_F64:
             assert d.max() < 1e-9 and np.abs(cost - want_cost).max() < 1e-8
+
+
+def test_edge_cases_empty_and_degenerate(ctx, oracle, pairs8):
+    """Empty / ragged inputs the reference tolerates silently: all-miss scans, a reference with no built cell,
+    new scans with no surviving beam, one particle, zero iterations, off-frame guesses."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    geom, grid = _geom(p, capi), _grid(capi)
+    N = p.n_beams
+    ref = p.ref_ranges[:4].copy()
+    new = p.new_ranges[:4].copy()
+    new[0, :] = 0.0                      # pair 0: new scan has no valid beam -> every cost is 0
+    ref[1, :] = 0.0                      # pair 1: reference scan empty -> no cell, every cost is 0
+    ref[2, 3:] = 0.0                     # pair 2: reference has 3 beams only (at most one built cell)
+    new[3, ::2] = 40.0                   # pair 3: half of the beams beyond max_range
+    for (P, I) in ((1, 0), (1, 3), (5, 2), (70, 1)):
+        want, wcost, _ = oracle.align_pairs(ref, new, p.angle_min, p.angle_inc, p.range_max, 0.1, FRAME_M, FRAME_M,
+                                            CELL_SIDE, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P), p.seeds[:4])
+        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+            got, cost, stats = ctx.align_pairs(ref, new, geom, grid, (0, 0, 0), DEVIATION, capi.PSOConfig.make(I, P),
+                                               seeds=p.seeds[:4], mode=mode)
+            assert (stats["status"] == 0).all()
+            assert stats["n_points"][0] == 0 and stats["n_built"][1] == 0
+            assert np.abs(got - want).max() < (1e-12 if mode == capi.SCORE_F64 else 1e-3), (P, I, mode, got, want)
+            assert np.abs(cost - wcost).max() < (1e-9 if mode == capi.SCORE_F64 else 1e-3)
+            assert cost[0] == 0.0 and cost[1] == 0.0
+    # a guess that throws every point out of the frame: cost 0 everywhere, the first candidate wins
+    far = np.tile(np.array([500.0, -500.0, 0.3]), (4, 1))
+    want, wcost, _ = oracle.align_pairs(p.ref_ranges[:4], p.new_ranges[:4], p.angle_min, p.angle_inc, p.range_max, 0.1,
+                                        FRAME_M, FRAME_M, CELL_SIDE, far, DEVIATION, oracle.PSOConfig.make(3, 6), p.seeds[:4])
+    got, cost, _ = ctx.align_pairs(p.ref_ranges[:4], p.new_ranges[:4], geom, grid, far, DEVIATION,
+                                   capi.PSOConfig.make(3, 6), seeds=p.seeds[:4], mode=capi.SCORE_F32)
+    assert np.array_equal(got, want) and (cost == 0).all() and (wcost == 0).all()
+
+
+def test_non_pow2_cells_and_small_frame(ctx, oracle, pairs8):
+    """0.3 m cells (true division in the index arithmetic, bitmap table) and a 20 m frame that clips the scan."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    for frame, cs in ((FRAME_M, 0.3), (20, 0.5), (20, 0.7)):
+        want, wcost, _ = oracle.align_pairs(p.ref_ranges[:3], p.new_ranges[:3], p.angle_min, p.angle_inc, p.range_max, 0.1,
+                                            frame, frame, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(20, 24), p.seeds[:3])
+        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+            got, cost, stats = ctx.align_pairs(p.ref_ranges[:3], p.new_ranges[:3], _geom(p, capi), capi.Grid(frame, frame, cs),
+                                               (0, 0, 0), DEVIATION, capi.PSOConfig.make(20, 24), seeds=p.seeds[:3], mode=mode)
+            assert (stats["status"] == 0).all()
+            d = np.abs(got - want)
+            print("frame", frame, "cs", cs, "mode", mode, "max |dpose|", d.max())
+            assert d.max() < (1e-9 if mode == capi.SCORE_F64 else 1e-3)
+
+
+def test_bad_arguments_fail_loudly(ctx):
+    from ndtpso_slam_amd import capi
+    import numpy as np
+    geom = capi.ScanGeom(16, -1.0, 0.1, 30.0, 0.1)
+    r = np.ones((1, 16), dtype=np.float32)
+    with pytest.raises(capi.NdtpsoError) as e:
+        ctx.align_pairs(r, r, geom, capi.Grid(60, 60, 0.0), (0, 0, 0), DEVIATION, capi.PSOConfig.make(5, 5), seeds=[1])
+    assert e.value.code == capi.E_ARG
+    with pytest.raises(capi.NdtpsoError) as e:
+        ctx.align_pairs(r, r, geom, capi.Grid(60, 60, 0.5), (0, 0, 0), DEVIATION, capi.PSOConfig.make(5, 0), seeds=[1])
+    assert e.value.code == capi.E_ARG
+    with pytest.raises(capi.NdtpsoError) as e:
+        ctx.cost_batch(np.zeros((4, 2)), np.zeros((1, 3)), mode=7)
+    assert e.value.code == capi.E_ARG
