@@ -174,6 +174,19 @@ int ndtpso_align_pairs_dev(ndtpso_ctx *ctx, uint32_t n_pairs, const float *d_ref
 int ndtpso_align_pairs_footprint(const ndtpso_scan_geom *geom, const ndtpso_grid *grid,
                                  const ndtpso_pso_config *cfg, uint32_t *lds_bytes, uint32_t *block_threads);
 
+/* How ndtpso_align_pairs would run a configuration (LDS cell-table sizing / occupancy study, BASELINE config 5) */
+typedef struct {
+  uint32_t lds_bytes;        /* dynamic LDS per workgroup (0 if the configuration does not fit) */
+  uint32_t block_threads;    /* workgroup size */
+  uint32_t workgroups_per_cu;/* by LDS and by the 16-waves-per-CU register budget */
+  uint32_t table_form;       /* 0 bitmap + true division, 1 bitmap + power-of-two cells, 2 dense u16 table */
+  uint32_t swarm_in_hbm;     /* 1: the swarm state lives in an HBM workspace instead of LDS */
+  uint32_t window_w, window_h; /* staging window in cells */
+  uint32_t table_bytes;      /* LDS bytes of the cell index + records */
+} ndtpso_pairs_plan;
+int ndtpso_align_pairs_describe(const ndtpso_scan_geom *geom, const ndtpso_grid *grid, const ndtpso_pso_config *cfg,
+                                int score_mode, uint32_t n_pairs, ndtpso_pairs_plan *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,12 @@ class AlignStats(C.Structure):
                 ("reserved", C.c_uint32 * 2)]
 
 
+class PairsPlan(C.Structure):
+    _fields_ = [("lds_bytes", C.c_uint32), ("block_threads", C.c_uint32), ("workgroups_per_cu", C.c_uint32),
+                ("table_form", C.c_uint32), ("swarm_in_hbm", C.c_uint32), ("window_w", C.c_uint32),
+                ("window_h", C.c_uint32), ("table_bytes", C.c_uint32)]
+
+
 STATS_DTYPE = np.dtype([("n_points", "<u4"), ("n_built", "<u4"), ("cost_evals", "<u4"), ("rounds", "<u4"),
                         ("gbest_updates", "<u4"), ("status", "<u4"), ("reserved", "<u4", (2,))])
 assert STATS_DTYPE.itemsize == C.sizeof(AlignStats)
@@ -76,7 +82,7 @@ EXPORTS = [
     "ndtpso_ctx_create", "ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_set_stream", "ndtpso_synchronize",
     "ndtpso_rand_draws", "ndtpso_scan_to_points", "ndtpso_ref_from_points", "ndtpso_ref_from_scan",
     "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_cells_build_windowed", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
-    "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint",
+    "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
 ]
 
 _lib = None
@@ -122,6 +128,8 @@ def load(build_if_missing: bool = True):
                   vp, vp, C.c_int, vp, vp, vp]
     L.ndtpso_align_pairs.argtypes = pairs_args
     L.ndtpso_align_pairs_dev.argtypes = pairs_args
+    L.ndtpso_align_pairs_describe.argtypes = [C.POINTER(ScanGeom), C.POINTER(Grid), C.POINTER(PSOConfig), C.c_int,
+                                              C.c_uint32, C.POINTER(PairsPlan)]
     L.ndtpso_align_pairs_footprint.argtypes = [C.POINTER(ScanGeom), C.POINTER(Grid), C.POINTER(PSOConfig), up, up]
     for name in EXPORTS:
         fn = getattr(L, name)
@@ -291,3 +299,11 @@ def align_pairs_footprint(geom: ScanGeom, grid: Grid, cfg: PSOConfig):
     lds, thr = C.c_uint32(), C.c_uint32()
     rc = L.ndtpso_align_pairs_footprint(C.byref(geom), C.byref(grid), C.byref(cfg), C.byref(lds), C.byref(thr))
     return rc, lds.value, thr.value
+
+
+def align_pairs_describe(geom: ScanGeom, grid: Grid, cfg: PSOConfig, mode=SCORE_F32, n_pairs=512):
+    """(rc, dict) -- how the fused kernel would be launched for this configuration (no GPU needed)."""
+    L = load()
+    pl = PairsPlan()
+    rc = L.ndtpso_align_pairs_describe(C.byref(geom), C.byref(grid), C.byref(cfg), mode, n_pairs, C.byref(pl))
+    return rc, {k: getattr(pl, k) for k, _ in PairsPlan._fields_}

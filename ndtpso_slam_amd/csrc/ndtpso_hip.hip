@@ -491,8 +491,7 @@ int pick_waves(int P, int lds_bytes, unsigned n_jobs) {
 }
 
 // Which score-loop variant a launch uses, and its LDS layout.
-//   path 2 (dense fast path): fp32 score, power-of-two cell side, and the dense table fits; preferred when
-//   it still allows two workgroups per CU (<= 80 KiB) or when the bitmap form does not either.
+//   path 2 (dense fast path): fp32 score, power-of-two cell side, and the dense table fits in LDS.
 struct Plan {
   int path;  // 0 division + bitmap, 1 pow2 + bitmap, 2 dense
   Layout L;
@@ -508,9 +507,9 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
   if (const char* e = std::getenv("NDTPSO_PATH")) force = std::atoi(e);  // tuning knob
   if (mode == kScoreF32 && g.cs_pow2 && force != 0 && force != 1) {
     const Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, wn.w + 1, wn.h + 1);
-    const int half = kMaxLds / 2;
-    const bool take = Ld.total <= kMaxLds && (Ld.total <= half || Lb.total > half || force == 2);
-    if (take) {
+    // measured (profiles/r01_occupancy_study.md): the dense form at one workgroup per CU still beats the bitmap
+    // form at two, so it is taken whenever it fits at all
+    if (Ld.total <= kMaxLds) {
       plan->path = 2;
       plan->L = Ld;
       plan->dn = make_dense(wn, Ld);
@@ -973,6 +972,28 @@ int ndtpso_align_pairs_footprint(const ndtpso_scan_geom* geom, const ndtpso_grid
   if (lds_bytes) *lds_bytes = (rc == NDTPSO_OK) ? (uint32_t)plan.L.total : 0u;
   if (block_threads) *block_threads = (uint32_t)waves * 64u;
   return rc;
+}
+
+int ndtpso_align_pairs_describe(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg,
+                                int mode, uint32_t n_pairs, ndtpso_pairs_plan* out) {
+  if (!out || (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64)) return NDTPSO_E_ARG;
+  std::memset(out, 0, sizeof(*out));
+  GridP g;
+  WinP wn;
+  Plan plan;
+  int waves = 0;
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves);
+  if (rc == NDTPSO_E_ARG) return rc;
+  out->block_threads = (uint32_t)waves * 64u;
+  out->window_w = (uint32_t)wn.w;
+  out->window_h = (uint32_t)wn.h;
+  if (rc != NDTPSO_OK) return rc;
+  out->lds_bytes = (uint32_t)plan.L.total;
+  out->table_form = (uint32_t)plan.path;
+  out->swarm_in_hbm = (uint32_t)plan.L.swarm_global;
+  out->workgroups_per_cu = (uint32_t)std::max(1, std::min(kMaxLds / plan.L.total, 16 / waves));
+  out->table_bytes = (uint32_t)(plan.L.pts_off - (plan.path == 2 ? 0 : plan.L.bm_off) - (plan.path == 2 ? kCtrlBytes + kImageHeaderBytes : 0));
+  return NDTPSO_OK;
 }
 
 static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, const float* d_new,
