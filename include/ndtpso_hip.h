@@ -79,7 +79,8 @@ typedef struct {
   uint32_t rounds;        /* evaluation rounds (iterations + replays) */
   uint32_t gbest_updates; /* in-iteration gbest improvements */
   uint32_t status;        /* 0 ok; bit0: a reference point fell outside the staging window; bit1: more built cells
-                             than record capacity; bit2: fp32 costs underflowed and the fp64 redo did not fit */
+                             than record capacity; bit2: fp32 costs underflowed and the
+                             fp64 redo did not fit; bit3: dense-table overflow and the bitmap redo did not fit */
   uint32_t reserved[2];
 } ndtpso_align_stats;
 

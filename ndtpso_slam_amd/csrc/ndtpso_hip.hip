@@ -335,21 +335,38 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
 }
 
 // ---- fused scan pairs: K3a(ref) + K3b + K3a(new) + K2, everything in LDS -------------------------
+//
+// gate == 0: every workgroup runs.  gate != 0: a redo launch -- only alignments an earlier launch flagged with
+// one of those status bits run (the others exit on their first instruction), and the bits are cleared.
+// PATH 2 sizes its staging window per alignment (bounding box of the occupied cells, `dense_cap` table
+// entries provisioned); a box that does not fit flags kStatusNeedsBitmap and leaves the alignment to the
+// bitmap-form kernel, whose window is the static range box.
 template <int MODE, int PATH>
 __global__ void __launch_bounds__(1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
-              Layout L, DenseP dn, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev,
-              const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables, size_t table_stride,
-              unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
-              double* __restrict__ out_cost, AlignStats* __restrict__ stats, int gated) {
+              Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
+              const double* __restrict__ dev, const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables,
+              size_t table_stride, unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
+              double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate) {
   const size_t b = blockIdx.x;
-  if (gated && !(stats[b].status & kStatusNeedsF64)) return;  // redo launch: only alignments the fp32 pass flagged
+  if (gate && !(stats[b].status & gate)) return;
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   ImageHeader* hdr = reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off);
 
   // reference frame <- scan A at identity (ndtpso_slam_node.cpp:186,198 for the first scan), then build
   const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
   __syncthreads();
+  if constexpr (PATH == 2) {
+    wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
+    dn.dw = wn.w + 1;
+    dn.dh = wn.h + 1;
+    dn.ox = wn.x0 - 1;
+    dn.oy = wn.y0 - 1;
+    if (dn.dw * dn.dh > dense_cap) {  // uniform
+      if (threadIdx.x == 0) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
+      return;
+    }
+  }
   build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
                  reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
                  reinterpret_cast<uint2*>(g_lds + L.bm2_off), nullptr, nullptr, PATH == 2 ? &dn : nullptr, g_lds);
@@ -360,12 +377,13 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
 
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
   const Swarm sw = swarm_carve(L.swarm_global ? ws + b * ws_stride : g_lds + L.region_off, ps.P);
+  if (threadIdx.x == 0) stats[b].status &= ~gate;
   pso_run_wg<MODE, PATH>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                          tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off), out_pose + 3 * b,
-                         out_cost ? out_cost + b : nullptr, stats ? stats + b : nullptr);
-  if (threadIdx.x == 0 && stats) {
+                         out_cost ? out_cost + b : nullptr, stats + b);
+  if (threadIdx.x == 0) {
     stats[b].n_built = hdr->n_built;
-    stats[b].status = (gated ? 0u : (stats[b].status & kStatusNeedsF64)) | hdr->status;
+    stats[b].status |= hdr->status;
   }
 }
 
@@ -496,31 +514,64 @@ struct Plan {
   int path;  // 0 division + bitmap, 1 pow2 + bitmap, 2 dense
   Layout L;
   DenseP dn;
+  int dense_cap;  // cell-table entries provisioned (fused kernel: the window is chosen per alignment)
 };
-bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan* plan) {
+// `wn` is the staging window: final for a prebuilt table; for the fused pairs kernel (dynamic_window) it is the
+// static range box -- the worst case the bitmap form must hold -- while the dense form sizes its window per
+// alignment and its table is provisioned as large as still leaves two workgroups per CU (else as large as
+// fits).  Preference: dense over bitmap (measured, profiles/r01_occupancy_study.md: dense at one workgroup per
+// CU still beats bitmap at two), swarm in LDS over swarm in HBM.
+bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan* plan, bool dynamic_window = false,
+               bool allow_dense = true) {
   const int bitmap_path = g.cs_pow2 ? 1 : 0;
-  const Layout Lb = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode);
-  plan->path = bitmap_path;
-  plan->L = Lb;
-  plan->dn = DenseP{0, 0, 0, 0, 0};
   int force = -1;
   if (const char* e = std::getenv("NDTPSO_PATH")) force = std::atoi(e);  // tuning knob
-  if (mode == kScoreF32 && g.cs_pow2 && force != 0 && force != 1) {
-    const Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, wn.w + 1, wn.h + 1);
-    // measured (profiles/r01_occupancy_study.md): the dense form at one workgroup per CU still beats the bitmap
-    // form at two, so it is taken whenever it fits at all
-    if (Ld.total <= kMaxLds) {
-      plan->path = 2;
-      plan->L = Ld;
-      plan->dn = make_dense(wn, Ld);
+  const bool dense_ok = allow_dense && mode == kScoreF32 && force != 0 && force != 1;
+  for (int swarm_global = 0; swarm_global < 2; ++swarm_global) {
+    if (swarm_global && P <= 0) break;
+    if (dense_ok) {
+      const int full_w = wn.w + 1, full_h = wn.h + 1;
+      Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, full_w, full_h, swarm_global != 0);
+      int cap = full_w * full_h;
+      if (dynamic_window && Ld.total > kMaxLds / 2) {
+        // shrink the provisioned (square) table until two workgroups fit per CU, else until one does;
+        // never below 64 x 64 cells
+        for (int limit : {kMaxLds / 2, kMaxLds}) {
+          bool found = false;
+          for (int side = (int)std::sqrt((double)(full_w * full_h)); side >= 64; side -= 4) {
+            const Layout Lt = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0);
+            if (Lt.total <= limit) {
+              Ld = Lt;
+              cap = side * side;
+              found = true;
+              break;
+            }
+          }
+          if (found) break;
+        }
+      }
+      if (Ld.total <= kMaxLds) {
+        plan->path = 2;
+        plan->L = Ld;
+        plan->dn = make_dense(wn, Ld);
+        plan->dense_cap = cap;
+        return true;
+      }
     }
+    const Layout Lb = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, 0, 0, swarm_global != 0);
+    if (Lb.total <= kMaxLds) {
+      plan->path = bitmap_path;
+      plan->L = Lb;
+      plan->dn = DenseP{0, 0, 0, 0, 0};
+      plan->dense_cap = 0;
+      return true;
+    }
+    plan->L = Lb;
   }
-  if (plan->L.total > kMaxLds && P > 0) {  // large swarm: keep the table + points in LDS, the swarm in HBM (L2)
-    plan->path = bitmap_path;
-    plan->dn = DenseP{0, 0, 0, 0, 0};
-    plan->L = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, 0, 0, true);
-  }
-  return plan->L.total <= kMaxLds;
+  plan->path = bitmap_path;
+  plan->dn = DenseP{0, 0, 0, 0, 0};
+  plan->dense_cap = 0;
+  return false;
 }
 
 bool trans_is_zero(const double t[3]) {  // Vector3d::isZero(1e-6), ndtframe.cpp:152
@@ -951,12 +1002,12 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
 // ---- fused pairs -----------------------------------------------------------------------------------
 
 static int pairs_plan(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg, int mode,
-                      unsigned n_pairs, GridP* g, WinP* wn, Plan* plan, int* waves) {
+                      unsigned n_pairs, GridP* g, WinP* wn, Plan* plan, int* waves, bool allow_dense = true) {
   if (!geom || geom->n_beams == 0 || !cfg || cfg->population < 1 || cfg->iterations < 0) return NDTPSO_E_ARG;
   if (make_grid(grid, g) != NDTPSO_OK) return NDTPSO_E_ARG;
   const double r = (double)geom->max_range;
   *wn = make_window(*g, -r, r, -r, r, (int)(geom->n_beams / 3) + 1);
-  const bool ok = make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan);
+  const bool ok = make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan, true, allow_dense);
   *waves = pick_waves(cfg->population, plan->L.total, n_pairs);
   return ok ? NDTPSO_OK : NDTPSO_E_CAPACITY;
 }
@@ -999,12 +1050,14 @@ int ndtpso_align_pairs_describe(const ndtpso_scan_geom* geom, const ndtpso_grid*
 static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, const float* d_new,
                         const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess, const double* d_dev,
                         const ndtpso_pso_config* cfg, const uint32_t* d_seeds, const int32_t* d_tables, int mode,
-                        double* d_pose, double* d_cost, AlignStats* d_stats, int gated) {
+                        double* d_pose, double* d_cost, AlignStats* d_stats, uint32_t gate, bool allow_dense,
+                        int* path_out) {
   GridP g;
   WinP wn;
   Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves);
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves, allow_dense);
+  if (path_out) *path_out = plan.path;
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
   const ScanP sp = make_scan(geom);
@@ -1014,8 +1067,8 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs));
 #define LAUNCH_PAIRS(MODE, PATH)                                                                                  \
   hipLaunchKernelGGL((k_align_pairs<MODE, PATH>), dim3(n_pairs), dim3(waves * 64), plan.L.total, c->stream, d_ref,  \
-                     d_new, sp, g, wn, plan.L, plan.dn, ps, d_guess, d_dev, d_seeds, d_tables, stride,             \
-                     (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gated)
+                     d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev, d_seeds, d_tables,     \
+                     stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate)
   if (mode == NDTPSO_SCORE_F32) {
     if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
   } else {
@@ -1042,15 +1095,22 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
     st = reinterpret_cast<AlignStats*>(c->gate.p);
   }
   HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(AlignStats) * (size_t)n_pairs, c->stream));
+  int path = 0;
   int rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
-                        st, 0);
+                        st, 0u, true, &path);
   if (rc != NDTPSO_OK || mode != NDTPSO_SCORE_F32) return rc;
-  if (std::getenv("NDTPSO_NO_F64_REDO")) return rc;  // diagnostics only
-  // second, gated launch: alignments whose fp32 costs underflowed (rare; degenerate overlap) are redone with
-  // the fp64 score; every other workgroup exits on its first instruction.  If the fp64 form does not fit in
-  // LDS the flag (status bit 2) simply stays set.
+  if (std::getenv("NDTPSO_NO_REDO")) return rc;  // diagnostics only
+  // Gated redo launches (every workgroup whose alignment is not flagged exits on its first instruction):
+  //  - dense form only: alignments whose occupied box exceeded the provisioned cell table -> bitmap form;
+  //  - alignments whose fp32 costs fell in the underflow regime (degenerate overlap) -> fp64 score.
+  // If a redo form does not fit in LDS its flag simply stays set in the stats block.
+  if (path == 2) {
+    rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F32,
+                      d_pose, d_cost, st, kStatusNeedsBitmap, false, nullptr);
+    if (rc != NDTPSO_OK && rc != NDTPSO_E_CAPACITY) return rc;
+  }
   rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose,
-                    d_cost, st, 1);
+                    d_cost, st, kStatusNeedsF64, false, nullptr);
   return rc == NDTPSO_E_CAPACITY ? NDTPSO_OK : rc;
 }
 

@@ -117,8 +117,9 @@ __host__ __device__ inline int image_cd_offset(int n_words, int cap) { return im
 __host__ __device__ inline int image_chol_offset(int n_words, int cap) { return image_mean_offset(n_words) + 48 * cap; }
 __host__ __device__ inline int image_bytes(int n_words, int cap) { return image_mean_offset(n_words) + 64 * cap; }
 
-// Cholesky factor of 0.5*log2(e)*[[a, (b+c)/2], [(b+c)/2, d]] for the fp32 score path
-__host__ __device__ inline void make_chol(double a, double b, double c, double d, float out[4]) {
+// Cholesky factor of 0.5*log2(e)*[[a, (b+c)/2], [(b+c)/2, d]] for the fp32 score path, times `scale`
+// (1 for records in metres, cell_side for records in cell units), rounded to fp32 once
+__host__ __device__ inline void make_chol(double a, double b, double c, double d, float out[4], double scale = 1.) {
   const double k = 0.72134752044448170368;  // 0.5 * log2(e)
   const double A = k * a, B = k * (0.5 * (b + c)), D = k * d;
   double l11 = 0., l21 = 0.;
@@ -128,9 +129,9 @@ __host__ __device__ inline void make_chol(double a, double b, double c, double d
   }
   const double rem = D - l21 * l21;
   const double l22 = rem > 0. ? sqrt(rem) : 0.;
-  out[0] = (float)l11;
-  out[1] = (float)l21;
-  out[2] = (float)l22;
+  out[0] = (float)(l11 * scale);
+  out[1] = (float)(l21 * scale);
+  out[2] = (float)(l22 * scale);
   out[3] = 0.f;
 }
 
@@ -286,13 +287,14 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
 
 // ---- fp32-score fast path: dense table, folded index arithmetic ------------------------------------------
 //
-// For a power-of-two cell side, floor((x + w/2)/cs) is floor(fl(x + w/2) * 2^k) and scaling by 2^k commutes
-// with rounding, so the window-relative cell coordinates come straight out of the transform:
+// The window-relative cell coordinates come straight out of the transform:
 //   gx = x*C - y*S + TX,  C = cos/cs, S = sin/cs, TX = (tx + w/2)/cs - ox      (2 fp64 FMAs per axis)
 // and the Mahalanobis form is evaluated in cell units against DenseRec.  Per point: 4 FMA, 2 cvt, 2 cmp,
-// mad, select, 3 LDS reads, 2 sub, 2 cvt, 5 fp32, exp2, cvt, add.  (The transform is a single-rounded FMA
-// chain, so a point within 1 ulp of a cell edge may bin differently from the reference; the fp64 score
-// path keeps the reference's rounding step by step.)
+// mul+add, select, 3 LDS reads, 2 sub, 2 cvt, 5 fp32, exp2, and per four points one cvt + add.
+// For a power-of-two cell side floor((x + w/2)/cs) = floor(fl(x + w/2) * 2^k) and the scaling commutes with
+// rounding; for any other cell side 1/cs is rounded once more.  Either way gx is within ~1e-14 cells of the
+// reference's value, so only a point that close to a cell edge can bin differently (probability ~1e-7 per
+// alignment); the fp64 score mode keeps the reference's rounding step by step and has no such caveat.
 struct DenseItem {  // per-pose constants
   double C, S, TX, TY;
 };
@@ -499,6 +501,46 @@ __device__ inline void prefix_words_wave0(uint2* bm, int n_words, uint32_t* tota
   if (lane == 0) *total_out = tot;
 }
 
+// frame cell of a point as NDTFrame::addPoint bins it (ndtframe.cpp:215-235); false = dropped
+__device__ __forceinline__ bool point_cell(const GridP& g, double2 p, int& ix, int& iy) {
+  if (!(fabs(p.x) < g.hw && fabs(p.y) < g.hh)) return false;
+  cell_coords_rt(g, p.x, p.y, ix, iy);
+  if (ix == g.W) {  // reference linear-index wrap (see score_point)
+    ix = 0;
+    iy += 1;
+  }
+  return iy < g.H;
+}
+
+// Staging window of one alignment = bounding box of the cells its reference points fall in (workgroup
+// cooperative; box[4] = {min x, max x, min y, max y} in LDS).  Empty input gives the 1 x 1 window at (0, 0).
+__device__ inline WinP dynamic_window_wg(const GridP& g, const double2* pts, int n, int* box, int rec_cap) {
+  if (threadIdx.x == 0) {
+    box[0] = box[2] = 0x7fffffff;
+    box[1] = box[3] = -1;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int ix, iy;
+    if (point_cell(g, pts[i], ix, iy)) {
+      atomicMin(&box[0], ix);
+      atomicMax(&box[1], ix);
+      atomicMin(&box[2], iy);
+      atomicMax(&box[3], iy);
+    }
+  }
+  __syncthreads();
+  WinP w;
+  const bool any = box[1] >= 0;
+  w.x0 = any ? box[0] : 0;
+  w.y0 = any ? box[2] : 0;
+  w.w = any ? box[1] - box[0] + 1 : 1;
+  w.h = any ? box[3] - box[2] + 1 : 1;
+  w.n_words = (w.w * w.h + 31) / 32;
+  w.rec_cap = rec_cap;
+  return w;
+}
+
 __device__ __forceinline__ unsigned bm_slot(const uint2* bm, int k) {
   const uint2 e = bm[k >> 5];
   return e.y + __popc(e.x & ((1u << (k & 31)) - 1u));
@@ -525,14 +567,13 @@ __device__ inline void dense_clear_wg(const DenseP& dn, unsigned char* lds0) {
 __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsigned char* lds0, unsigned slot, int rx,
                                           int ry, double mx, double my, double ia, double ib, double ic, double id) {
   float l[4];
-  make_chol(ia, ib, ic, id, l);
+  make_chol(ia, ib, ic, id, l, g.cs);  // Cholesky factor in cell units
   DenseRec r;
   r.mgx = (mx + g.hw) * g.inv_cs - (double)dn.ox;
   r.mgy = (my + g.hh) * g.inv_cs - (double)dn.oy;
-  const float csf = (float)g.cs;  // exact: the dense path requires a power-of-two cell side
-  r.l11 = l[0] * csf;
-  r.l21 = l[1] * csf;
-  r.l22 = l[2] * csf;
+  r.l11 = l[0];
+  r.l21 = l[1];
+  r.l22 = l[2];
   r.w = 0.f;
   reinterpret_cast<DenseRec*>(lds0 + dn.rec_off)[slot + 1] = r;
   reinterpret_cast<unsigned short*>(lds0)[(ry + 1) * dn.dw + (rx + 1)] =
@@ -861,6 +902,7 @@ struct EvalCtx {
 // (kStatusNeedsF64); the host side re-runs flagged alignments with the fp64-score kernel, gated on that flag.
 // ndtpso_cost_batch re-evaluates such a pose in place (eval_pose_wave_tiny: same records, fp64 exponential).
 constexpr uint32_t kStatusNeedsF64 = 4u;
+constexpr uint32_t kStatusNeedsBitmap = 8u;  // dense form: the occupied box exceeds the provisioned cell table
 constexpr double kTinyCost = 1e-28;
 
 template <int PATH>
