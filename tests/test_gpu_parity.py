@@ -241,3 +241,22 @@ def test_bad_arguments_fail_loudly(ctx):
     with pytest.raises(capi.NdtpsoError) as e:
         ctx.cost_batch(np.zeros((4, 2)), np.zeros((1, 3)), mode=7)
     assert e.value.code == capi.E_ARG
+
+
+def test_dense_window_overflow_falls_back_to_bitmap_form(ctx, oracle, pairs8):
+    """0.125 m cells: the occupied box (room 24 m x 18 m = 192 x 144 cells) exceeds the provisioned dense table,
+    the fp32 kernel flags those alignments and the gated bitmap-form launch redoes them; results as usual."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    cs, P, I = 0.125, 24, 10
+    geom = _geom(p, capi)
+    rc, plan = capi.align_pairs_describe(geom, capi.Grid(FRAME_M, FRAME_M, cs), capi.PSOConfig.make(I, P), capi.SCORE_F32, 3)
+    assert rc == 0 and plan["table_form"] == 2
+    want, wcost, _ = oracle.align_pairs(p.ref_ranges[:3], p.new_ranges[:3], p.angle_min, p.angle_inc, p.range_max, 0.1,
+                                        FRAME_M, FRAME_M, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P), p.seeds[:3])
+    got, cost, stats = ctx.align_pairs(p.ref_ranges[:3], p.new_ranges[:3], geom, capi.Grid(FRAME_M, FRAME_M, cs), (0, 0, 0),
+                                       DEVIATION, capi.PSOConfig.make(I, P), seeds=p.seeds[:3], mode=capi.SCORE_F32)
+    print("status", stats["status"], "built", stats["n_built"], "max |dpose|", np.abs(got - want).max())
+    assert (stats["status"] == 0).all()
+    assert np.abs(got - want).max() < 1e-3
+    assert np.abs(cost - wcost).max() < 1e-3
