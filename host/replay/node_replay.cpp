@@ -4,6 +4,7 @@
 //
 //   file: int32 n_scans, int32 n_beams, float angle_min, float angle_inc, float range_max, then n_scans*n_beams floats
 //   usage: node_replay scans.bin frame_size cell_side iterations population [srand_seed]
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -38,8 +39,10 @@ int main(int argc, char** argv) {
   Vector3d previous_pose = initial_pose, current_pose = initial_pose;
   bool first_iteration = true;
   std::vector<float> ranges((size_t)n_beams);
+  double busy_s = 0.;
   for (int k = 0; k < n_scans; ++k) {
     if (std::fread(ranges.data(), 4, (size_t)n_beams, f) != (size_t)n_beams) return 2;
+    const auto t0 = std::chrono::steady_clock::now();
     current_frame->loadLaser(ranges, amin, ainc, rmax);                       // :186
     if (first_iteration)
       current_pose = previous_pose;                                            // :188-189
@@ -47,12 +50,15 @@ int main(int argc, char** argv) {
       current_pose = ref_frame->align(previous_pose, current_frame);           // :194
     previous_pose = current_pose;
     ref_frame->update(current_pose, current_frame);                            // :198
+    if (k > 0) busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("%d %.17g %.17g %.17g\n", k, current_pose.x(), current_pose.y(), current_pose.z());
     delete current_frame;                                                      // :228-230
     current_frame = new NDTFrame(initial_pose, frame_size, frame_size, frame_size, false);
     first_iteration = false;
   }
   std::fclose(f);
+  if (n_scans > 1)  // the node's own metric ("matching rate", ndtpso_slam_node.cpp:239): loadLaser + align + update per scan
+    std::fprintf(stderr, "matching rate: %.1f Hz (%.3f ms per scan)\n", (n_scans - 1) / busy_s, 1e3 * busy_s / (n_scans - 1));
   delete current_frame;
   delete ref_frame;
   return 0;
