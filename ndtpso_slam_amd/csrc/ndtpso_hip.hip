@@ -84,8 +84,9 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
   return L;
 }
 
-DenseP make_dense(const WinP& wn, const Layout& L) {
+DenseP make_dense(const GridP& g, const WinP& wn, const Layout& L) {
   DenseP d;
+  d.clip = ((double)g.W * g.cs - 2. * g.hw > 1e-9 * g.hw || (double)g.H * g.cs - 2. * g.hh > 1e-9 * g.hh) ? 1 : 0;
   d.dw = wn.w + 1;
   d.dh = wn.h + 1;
   d.ox = wn.x0 - 1;
@@ -370,8 +371,9 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
                  reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
                  reinterpret_cast<uint2*>(g_lds + L.bm2_off), nullptr, nullptr, PATH == 2 ? &dn : nullptr, g_lds);
-  // new frame <- scan B (one-cell frame: just the point list, ndtpso_slam_node.cpp:229-230)
-  const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
+  // new frame <- scan B (one-cell frame of the same size: the point list inside the frame, ndtpso_slam_node.cpp:229-230)
+  const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
+                                      g.hw, g.hh);
   pad_points_wg(pts, n_new);
   __syncthreads();
 
@@ -553,7 +555,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
       if (Ld.total <= kMaxLds) {
         plan->path = 2;
         plan->L = Ld;
-        plan->dn = make_dense(wn, Ld);
+        plan->dn = make_dense(g, wn, Ld);
         plan->dense_cap = cap;
         return true;
       }
@@ -562,14 +564,14 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
     if (Lb.total <= kMaxLds) {
       plan->path = bitmap_path;
       plan->L = Lb;
-      plan->dn = DenseP{0, 0, 0, 0, 0};
+      plan->dn = DenseP{0, 0, 0, 0, 0, 0};
       plan->dense_cap = 0;
       return true;
     }
     plan->L = Lb;
   }
   plan->path = bitmap_path;
-  plan->dn = DenseP{0, 0, 0, 0, 0};
+  plan->dn = DenseP{0, 0, 0, 0, 0, 0};
   plan->dense_cap = 0;
   return false;
 }

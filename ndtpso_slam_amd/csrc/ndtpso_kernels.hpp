@@ -89,6 +89,7 @@ struct DenseP {
   int dw, dh;    // dense window size in cells, = wn.w + 1, wn.h + 1
   int ox, oy;    // grid coordinates of dense cell (0,0), = wn.x0 - 1, wn.y0 - 1
   int rec_off;   // LDS byte offset of DenseRec[rec_cap + 1] (record 0 = null), 16-byte aligned
+  int clip;      // 1: W*cs > width or H*cs > height -- the last cells overhang the frame, test the upper bounds
 };
 __host__ __device__ inline int dense_tab_bytes(int dw, int dh) { return align16_c(dw * dh * 2); }
 constexpr int kRecImageBytes = 64;  // per record in the HBM image: mean, ab, cd, chol
@@ -297,6 +298,7 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
 // alignment); the fp64 score mode keeps the reference's rounding step by step and has no such caveat.
 struct DenseItem {  // per-pose constants
   double C, S, TX, TY;
+  double XMAX, YMAX;  // frame's upper bounds in window cell coordinates (used when DenseP::clip)
 };
 __device__ __forceinline__ DenseItem dense_item(const GridP& g, const DenseP& dn, double c, double s, double tx,
                                                 double ty) {
@@ -305,10 +307,12 @@ __device__ __forceinline__ DenseItem dense_item(const GridP& g, const DenseP& dn
   it.S = s * g.inv_cs;
   it.TX = (tx + g.hw) * g.inv_cs - (double)dn.ox;
   it.TY = (ty + g.hh) * g.inv_cs - (double)dn.oy;
+  it.XMAX = (2. * g.hw) * g.inv_cs - (double)dn.ox;
+  it.YMAX = (2. * g.hh) * g.inv_cs - (double)dn.oy;
   return it;
 }
 
-template <int U, bool DUMP>
+template <int U, bool DUMP, bool CLIP>
 __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                  const double2* __restrict__ pts, int base, int n,
                                                  const DenseItem& it, double (&acc)[4], int32_t* __restrict__ dump) {
@@ -323,7 +327,11 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
     gx[u] = fma(p[u].x, it.C, fma(-p[u].y, it.S, it.TX));
     gy[u] = fma(p[u].x, it.S, fma(p[u].y, it.C, it.TY));
     const unsigned rx = (unsigned)(int)gx[u], ry = (unsigned)(int)gy[u];
-    const bool ok = (int)(rx < (unsigned)dn.dw) & (int)(ry < (unsigned)dn.dh);
+    bool ok = (int)(rx < (unsigned)dn.dw) & (int)(ry < (unsigned)dn.dh);
+    // A grid whose last cells overhang the frame (width/cs not an integer): points past the frame's upper
+    // bound are rejected by NDTFrame::getCellIndex (ndtframe.cpp:242) although a cell exists there.  (Below the
+    // lower bound the cell coordinate is negative or lands in the empty border column.)
+    if constexpr (CLIP) ok = (int)ok & (int)(gx[u] < it.XMAX) & (int)(gy[u] < it.YMAX);
     lin[u] = ok ? __umul24(ry, (unsigned)dn.dw) + rx : 0u;  // cell 0 is a border cell: always the null record
   }
   // the dense table starts at LDS address 0 and records are addressed absolutely: plain shifts, no base add
@@ -373,19 +381,26 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   }
 }
 
-template <bool DUMP>
-__device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
-                                                       const double2* __restrict__ pts, int n, double c, double s,
-                                                       double tx, double ty, int32_t* __restrict__ dump) {
+template <bool DUMP, bool CLIP>
+__device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const DenseP& dn, const unsigned char* lds0,
+                                                         const double2* __restrict__ pts, int n, double c, double s,
+                                                         double tx, double ty, int32_t* __restrict__ dump) {
   constexpr int U = NDTPSO_UNROLL;
   const DenseItem it = dense_item(g, dn, c, s, tx, ty);
   double acc[4] = {0., 0., 0., 0.};
   const int n_pad = round_up(n, kWave);
   int base = 0;
   for (; base + U * kWave <= n_pad; base += U * kWave)
-    score_trip_dense<U, DUMP>(g, dn, lds0, pts, base, n, it, acc, dump);
-  for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP>(g, dn, lds0, pts, base, n, it, acc, dump);
+    score_trip_dense<U, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
+  for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
   return -wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+template <bool DUMP>
+__device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
+                                                       const double2* __restrict__ pts, int n, double c, double s,
+                                                       double tx, double ty, int32_t* __restrict__ dump) {
+  if (dn.clip) return eval_pose_wave_dense_c<DUMP, true>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
+  return eval_pose_wave_dense_c<DUMP, false>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
 }
 
 // pts must be padded to a multiple of kPointPad with out-of-frame sentinels (pad_points_wg)
@@ -426,9 +441,11 @@ __device__ inline void pad_points_wg(double2* pts, int n) {
 //
 // Workgroup-cooperative, order preserving.  ranges: global; out: LDS or global (generic).
 // Returns the number of surviving points (uniform).  `s_cnt` is a >= 17-int LDS scratch.
+// clip_hw/clip_hh > 0: additionally drop points outside that frame, as NDTFrame::addPoint does when the scan is
+// loaded into a frame of that size (ndtframe.cpp:215-235; the node's per-scan frame has the map's frame size).
 __device__ inline int scan_to_points_wg(const float* __restrict__ ranges, const ScanP& sp, bool do_trans,
                                         double tc, double ts, double ttx, double tty, double2* out,
-                                        int* s_cnt) {
+                                        int* s_cnt, double clip_hw = 0., double clip_hh = 0.) {
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id(), n_waves = blockDim.x >> 6;
   int base = 0;
   for (int start = 0; start < sp.n_beams; start += blockDim.x) {
@@ -451,6 +468,9 @@ __device__ inline int scan_to_points_wg(const float* __restrict__ ranges, const 
           p.x = x;
           p.y = y;
         }
+        if (clip_hw > 0.)  // getCellIndex != -1 for the one-cell frame (strict bounds; fl(x + w/2) == w indexes past it)
+          valid = fabs(p.x) < clip_hw && fabs(p.y) < clip_hh && (p.x + clip_hw) < 2. * clip_hw &&
+                  (p.y + clip_hh) < 2. * clip_hh;
       }
     }
     const unsigned long long bal = __ballot(valid);
@@ -918,7 +938,7 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
       const double gx = fma(p.x, it.C, fma(-p.y, it.S, it.TX));
       const double gy = fma(p.x, it.S, fma(p.y, it.C, it.TY));
       const unsigned rx = (unsigned)(int)gx, ry = (unsigned)(int)gy;
-      const bool ok = (rx < (unsigned)E.dn.dw) && (ry < (unsigned)E.dn.dh);
+      const bool ok = (rx < (unsigned)E.dn.dw) && (ry < (unsigned)E.dn.dh) && (!E.dn.clip || (gx < it.XMAX && gy < it.YMAX));
       const unsigned lin = ok ? ry * (unsigned)E.dn.dw + rx : 0u;
       const unsigned e = reinterpret_cast<const unsigned short*>(E.lds0)[lin];
       const DenseRec* r = reinterpret_cast<const DenseRec*>(E.lds0 + (e << 4));

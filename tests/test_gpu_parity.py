@@ -260,3 +260,42 @@ def test_dense_window_overflow_falls_back_to_bitmap_form(ctx, oracle, pairs8):
     assert (stats["status"] == 0).all()
     assert np.abs(got - want).max() < 1e-3
     assert np.abs(cost - wcost).max() < 1e-3
+
+
+def test_randomised_configurations(ctx, oracle):
+    """40 random configurations (frame 20..120 m, cell side 0.2..1.5 m incl. non power-of-two, 3..90 particles,
+    0..25 iterations, 90..1500 beams, off-centre guesses, random deviations, dropped beams) against the oracle:
+    fp64 score reproduces the pose to 1e-9, fp32 score to 1e-3 (BASELINE tolerance)."""
+    from ndtpso_slam_amd import capi, synth
+    rng = np.random.default_rng(20240928)
+    worst32 = 0.0
+    n32_exact = 0
+    for case in range(40):
+        n_beams = int(rng.choice([90, 181, 361, 720, 1081, 1500]))
+        frame = int(rng.choice([20, 40, 60, 100, 120]))
+        cs = float(rng.choice([0.2, 0.25, 0.3, 0.5, 0.75, 1.0, 1.5]))
+        P = int(rng.integers(3, 91))
+        I = int(rng.integers(0, 26))
+        B = 2
+        p = synth.make_pairs(B, n_beams=n_beams, seed=int(rng.integers(1, 10**6)))
+        ref, new = p.ref_ranges.copy(), p.new_ranges.copy()
+        drop = rng.random(ref.shape) < rng.uniform(0.0, 0.3)
+        ref[drop] = 0.0
+        new[rng.random(new.shape) < 0.1] = 0.0
+        guess = rng.uniform(-1, 1, (B, 3)) * np.array([0.05, 0.05, 0.01])
+        dev = np.abs(rng.normal(0, 1, (B, 3))) * np.array([0.1, 0.1, 5e-3]) + 1e-6
+        geom = capi.ScanGeom(n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+        want, wcost, _ = oracle.align_pairs(ref, new, p.angle_min, p.angle_inc, p.range_max, 0.1, frame, frame, cs,
+                                            guess, dev, oracle.PSOConfig.make(I, P), p.seeds)
+        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+            got, cost, stats = ctx.align_pairs(ref, new, geom, capi.Grid(frame, frame, cs), guess, dev,
+                                               capi.PSOConfig.make(I, P), seeds=p.seeds, mode=mode)
+            assert (stats["status"] == 0).all(), (case, mode, stats["status"])
+            d = np.abs(got - want).max()
+            if mode == capi.SCORE_F64:
+                assert d < 1e-9 and np.abs(cost - wcost).max() < 1e-8, (case, n_beams, frame, cs, P, I, d)
+            else:
+                worst32 = max(worst32, d)
+                n32_exact += int(d == 0.0)
+                assert d < 1e-3, (case, n_beams, frame, cs, P, I, d)
+    print("fp32 score: worst |dpose| %.3e, bit-identical in %d/40 configurations" % (worst32, n32_exact))
