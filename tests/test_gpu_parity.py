@@ -299,3 +299,50 @@ def test_randomised_configurations(ctx, oracle):
                 n32_exact += int(d == 0.0)
                 assert d < 1e-3, (case, n_beams, frame, cs, P, I, d)
     print("fp32 score: worst |dpose| %.3e, bit-identical in %d/40 configurations" % (worst32, n32_exact))
+
+
+def test_randomised_staged_tables(ctx, oracle):
+    """Same idea for the host-table route (ndtpso_ref_set_cells / ndtpso_ref_from_points + ndtpso_align +
+    ndtpso_cost_batch): accumulated two-scan reference maps at a random pose, random grids."""
+    from ndtpso_slam_amd import capi, synth
+    rng = np.random.default_rng(77)
+    exact32 = 0
+    for case in range(24):
+        n_beams = int(rng.choice([181, 361, 1081]))
+        frame = int(rng.choice([30, 60, 100]))
+        cs = float(rng.choice([0.25, 0.3, 0.5, 1.0]))
+        P, I = int(rng.integers(4, 60)), int(rng.integers(1, 20))
+        p = synth.make_pairs(2, n_beams=n_beams, seed=int(rng.integers(1, 10**6)))
+        # reference map: scan A at identity + scan A' of the next pair re-binned at a small offset (NDTFrame::update)
+        ref = oracle.Frame((0, 0, 0), frame, frame, cs)
+        ref.load_laser(p.ref_ranges[0], p.angle_min, p.angle_inc, p.range_max)
+        extra = oracle.Frame((0, 0, 0), frame, frame, float(frame))
+        extra.load_laser(p.ref_ranges[1], p.angle_min, p.angle_inc, p.range_max)
+        ref.update(rng.uniform(-1, 1, 3) * np.array([0.3, 0.3, 0.05]), extra)
+        ref.build()
+        new = oracle.Frame((0, 0, 0), frame, frame, float(frame))
+        new.load_laser(p.new_ranges[0], p.angle_min, p.angle_inc, p.range_max)
+        xy = new.points()
+        cells = [c for c in ref.cells() if c["built"]]
+        grid = capi.Grid(frame, frame, cs)
+        order = rng.permutation(len(cells))          # the entry point accepts any order
+        ctx.ref_set_cells(grid, [cells[k]["index"] for k in order], [cells[k]["mean"] for k in order],
+                          [cells[k]["icov"] for k in order])
+        guess = rng.uniform(-1, 1, 3) * np.array([0.05, 0.05, 0.01])
+        dev = np.abs(rng.normal(0, 1, 3)) * np.array([0.1, 0.1, 5e-3]) + 1e-6
+        seed = int(p.seeds[0])
+        want, wcost, _ = ref.pso(guess, new, dev, oracle.PSOConfig.make(I, P), seed=seed)
+        poses = guess + rng.uniform(-1, 1, (50, 3)) * np.array([0.2, 0.2, 0.02])
+        wc = np.array([ref.cost(q, new) for q in poses])
+        assert np.abs(ctx.cost_batch(xy, poses, capi.SCORE_F64) - wc).max() < 1e-9
+        assert np.abs(ctx.cost_batch(xy, poses, capi.SCORE_F32) - wc).max() < 1e-4 * max(len(xy), 1)
+        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+            got, cost, st = ctx.align(xy, guess, dev, capi.PSOConfig.make(I, P), seed=seed, mode=mode)
+            d = np.abs(got - want).max()
+            assert st["status"] == 0
+            if mode == capi.SCORE_F64:
+                assert d < 1e-9 and abs(cost - wcost) < 1e-8, (case, n_beams, frame, cs, P, I, d)
+            else:
+                exact32 += int(d == 0.0)
+                assert d < 1e-3, (case, n_beams, frame, cs, P, I, d)
+    print("staged tables, fp32 score: bit-identical in %d/24 configurations" % exact32)
