@@ -92,6 +92,7 @@ DenseP make_dense(const GridP& g, const WinP& wn, const Layout& L) {
   d.ox = wn.x0 - 1;
   d.oy = wn.y0 - 1;
   d.rec_off = L.drec_off;
+  dense_set_limits(d, g.hw, g.hh, g.inv_cs);
   return d;
 }
 
@@ -363,6 +364,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     dn.dh = wn.h + 1;
     dn.ox = wn.x0 - 1;
     dn.oy = wn.y0 - 1;
+    dense_set_limits(dn, g.hw, g.hh, g.inv_cs);
     if (dn.dw * dn.dh > dense_cap) {  // uniform
       if (threadIdx.x == 0) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
       return;
@@ -564,14 +566,14 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
     if (Lb.total <= kMaxLds) {
       plan->path = bitmap_path;
       plan->L = Lb;
-      plan->dn = DenseP{0, 0, 0, 0, 0, 0};
+      plan->dn = DenseP{0, 0, 0, 0, 0, 0, 0., 0.};
       plan->dense_cap = 0;
       return true;
     }
     plan->L = Lb;
   }
   plan->path = bitmap_path;
-  plan->dn = DenseP{0, 0, 0, 0, 0, 0};
+  plan->dn = DenseP{0, 0, 0, 0, 0, 0, 0., 0.};
   plan->dense_cap = 0;
   return false;
 }

@@ -90,7 +90,12 @@ struct DenseP {
   int ox, oy;    // grid coordinates of dense cell (0,0), = wn.x0 - 1, wn.y0 - 1
   int rec_off;   // LDS byte offset of DenseRec[rec_cap + 1] (record 0 = null), 16-byte aligned
   int clip;      // 1: W*cs > width or H*cs > height -- the last cells overhang the frame, test the upper bounds
+  double xmax, ymax;  // frame's upper bounds in window cell coordinates: width/cs - ox, height/cs - oy
 };
+__host__ __device__ inline void dense_set_limits(DenseP& d, double hw, double hh, double inv_cs) {
+  d.xmax = (2. * hw) * inv_cs - (double)d.ox;
+  d.ymax = (2. * hh) * inv_cs - (double)d.oy;
+}
 __host__ __device__ inline int dense_tab_bytes(int dw, int dh) { return align16_c(dw * dh * 2); }
 constexpr int kRecImageBytes = 64;  // per record in the HBM image: mean, ab, cd, chol
 
@@ -307,8 +312,8 @@ __device__ __forceinline__ DenseItem dense_item(const GridP& g, const DenseP& dn
   it.S = s * g.inv_cs;
   it.TX = (tx + g.hw) * g.inv_cs - (double)dn.ox;
   it.TY = (ty + g.hh) * g.inv_cs - (double)dn.oy;
-  it.XMAX = (2. * g.hw) * g.inv_cs - (double)dn.ox;
-  it.YMAX = (2. * g.hh) * g.inv_cs - (double)dn.oy;
+  it.XMAX = dn.xmax;
+  it.YMAX = dn.ymax;
   return it;
 }
 
@@ -387,13 +392,13 @@ __device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const D
                                                          double tx, double ty, int32_t* __restrict__ dump) {
   constexpr int U = NDTPSO_UNROLL;
   const DenseItem it = dense_item(g, dn, c, s, tx, ty);
-  double acc[4] = {0., 0., 0., 0.};
+  double acc[4] = {0., 0., 0., 0.};  // the dense trips fold their U terms in fp32 and use acc[0] only
   const int n_pad = round_up(n, kWave);
   int base = 0;
   for (; base + U * kWave <= n_pad; base += U * kWave)
     score_trip_dense<U, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
   for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
-  return -wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  return -wave_sum(acc[0]);
 }
 template <bool DUMP>
 __device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
