@@ -188,6 +188,9 @@ __device__ __forceinline__ void cell_coords_rt(const GridP& g, double qx, double
 #ifndef NDTPSO_UNROLL
 #define NDTPSO_UNROLL 4
 #endif
+#ifndef NDTPSO_ALTERNATE_PRIO
+#define NDTPSO_ALTERNATE_PRIO 1
+#endif
 
 // ---- K1: NDT score of one candidate pose, one wave --------------------------
 //
@@ -1130,6 +1133,19 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         need_propose = false;
         __syncthreads();  // proposals (and the commits before them) visible to every wave
       }
+#if NDTPSO_ALTERNATE_PRIO
+      // Two workgroups share a CU.  VALU issue is arbitrated by priority, then age, so the earlier-dispatched
+      // partner otherwise starves the other, finishes ~25 % early and leaves the CU half empty (measured with
+      // per-workgroup timestamps: residency 0.84 -> 0.95, +6 % throughput with this).  The partners (blocks b and
+      // b + grid/2 by dispatch order -- an assumption that only affects speed) take turns holding the higher
+      // priority; the turn comes from the shared 100 MHz real-time counter (5 us slices), so the two are
+      // complementary at all times, and the later-dispatched one gets 9 of 16 slices, which is what equalises
+      // their finishing times.
+      if ((((unsigned)(wall_clock64() >> 9) & 15u) < 9u) == (blockIdx.x >= (gridDim.x >> 1)))
+        __builtin_amdgcn_s_setprio(1);
+      else
+        __builtin_amdgcn_s_setprio(0);
+#endif
       const int slot = (int)(grp % 3u);
       const int hi_g = min(lo + ps.G, P);
       eval_items<MODE, PATH>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny);
