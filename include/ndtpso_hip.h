@@ -81,7 +81,8 @@ typedef struct {
   uint32_t status;        /* 0 ok; bit0: a reference point fell outside the staging window; bit1: more built cells
                              than record capacity; bit2: fp32 costs underflowed and the
                              fp64 redo did not fit; bit3: dense-table overflow and the bitmap redo did not fit */
-  uint32_t reserved[2];
+  uint32_t t_start, t_end; /* low 32 bits of the device's 100 MHz real-time counter when the alignment's workgroup
+                              started / finished (fused pairs kernel; load-balance diagnostics) */
 } ndtpso_align_stats;
 
 /* ---- context --------------------------------------------------------- */

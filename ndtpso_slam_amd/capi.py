@@ -64,7 +64,7 @@ CELL_WINDOW_DTYPE = np.dtype([("global_sum", "<f8", (2,)), ("global_covar_sum", 
 class AlignStats(C.Structure):
     _fields_ = [("n_points", C.c_uint32), ("n_built", C.c_uint32), ("cost_evals", C.c_uint32),
                 ("rounds", C.c_uint32), ("gbest_updates", C.c_uint32), ("status", C.c_uint32),
-                ("reserved", C.c_uint32 * 2)]
+                ("t_start", C.c_uint32), ("t_end", C.c_uint32)]
 
 
 class PairsPlan(C.Structure):
@@ -74,7 +74,7 @@ class PairsPlan(C.Structure):
 
 
 STATS_DTYPE = np.dtype([("n_points", "<u4"), ("n_built", "<u4"), ("cost_evals", "<u4"), ("rounds", "<u4"),
-                        ("gbest_updates", "<u4"), ("status", "<u4"), ("reserved", "<u4", (2,))])
+                        ("gbest_updates", "<u4"), ("status", "<u4"), ("t_start", "<u4"), ("t_end", "<u4")])
 assert STATS_DTYPE.itemsize == C.sizeof(AlignStats)
 assert CELL_WINDOW_DTYPE.itemsize == C.sizeof(CellWindow) == 160
 
@@ -262,7 +262,7 @@ class Context:
                                          _p(_f64(deviation, 3), C.c_double), C.byref(cfg), C.c_uint32(int(seed)),
                                          _p(tab, C.c_int32) if tab is not None else None, mode,
                                          _p(pose, C.c_double), C.byref(cost), C.byref(st)))
-        stats = {k: getattr(st, k) for k, _ in AlignStats._fields_ if k != "reserved"}
+        stats = {k: getattr(st, k) for k, _ in AlignStats._fields_}
         return pose, cost.value, stats
 
     # ---- fused pairs ----

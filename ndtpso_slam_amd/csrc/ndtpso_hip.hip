@@ -352,6 +352,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
               double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate) {
   const size_t b = blockIdx.x;
   if (gate && !(stats[b].status & gate)) return;
+  const uint32_t t_start = (uint32_t)wall_clock64();
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   ImageHeader* hdr = reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off);
 
@@ -388,6 +389,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if (threadIdx.x == 0) {
     stats[b].n_built = hdr->n_built;
     stats[b].status |= hdr->status;
+    stats[b].t_start = t_start;
+    stats[b].t_end = (uint32_t)wall_clock64();
   }
 }
 

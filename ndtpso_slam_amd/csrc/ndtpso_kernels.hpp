@@ -111,7 +111,7 @@ struct CellRow {  // == ndtpso_cell_row
 };
 
 struct AlignStats {  // == ndtpso_align_stats
-  uint32_t n_points, n_built, cost_evals, rounds, gbest_updates, status, reserved[2];
+  uint32_t n_points, n_built, cost_evals, rounds, gbest_updates, status, t_start, t_end;
 };
 
 
