@@ -26,10 +26,10 @@ constexpr int kCtrlBytes = 512;      // control block (PsoShared + compaction co
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
 //                header..chol are contiguous exactly as in the HBM image
 //   dense form : [u16 cell table @0 | ctrl | DenseRec[cap+1] | header | points | region]
-//   region = max(table-build scratch {key, cellkey, cnt, bm2, (bm)}, swarm)
+//   region = max(table-build scratch {key, cellkey, cnt, bm2, plist, (bm)}, swarm)
 struct Layout {
   int ctrl_off, hdr_off, bm_off, mean_off, ab_off, cd_off, chol_off, drec_off, pts_off, region_off, total;
-  int key_off, cellkey_off, cnt_off, bm2_off;  // build scratch inside region
+  int key_off, cellkey_off, cnt_off, bm2_off, plist_off;  // build scratch inside region
   int swarm_global;  // 1: the swarm does not fit in LDS and lives in an HBM workspace (large-swarm configs)
 };
 
@@ -74,7 +74,8 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
   L.cellkey_off = L.key_off + ints;
   L.cnt_off = L.cellkey_off + ints;
   L.bm2_off = L.cnt_off + ints;
-  int scratch = 3 * ints + align16(n_words * 8);
+  L.plist_off = L.bm2_off + align16(n_words * 8);
+  int scratch = 3 * ints + align16(n_words * 8) + align16(n_max * 2);
   if (dense) {  // the built-cell bitmap is only needed while the table is being built
     L.bm_off = L.region_off + scratch;
     scratch += align16(n_words * 8);
@@ -176,8 +177,8 @@ k_build_table(const double2* __restrict__ xy, int n, GridP g, WinP wn, Layout L,
   __syncthreads();
   build_table_wg(g, wn, pts, n, reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off), lds_table_out(L),
                  reinterpret_cast<int*>(g_lds + L.key_off), reinterpret_cast<int*>(g_lds + L.cellkey_off),
-                 reinterpret_cast<int*>(g_lds + L.cnt_off), reinterpret_cast<uint2*>(g_lds + L.bm2_off), rows, n_rows,
-                 nullptr, nullptr);
+                 reinterpret_cast<int*>(g_lds + L.cnt_off), reinterpret_cast<uint2*>(g_lds + L.bm2_off),
+                 reinterpret_cast<unsigned short*>(g_lds + L.plist_off), rows, n_rows, nullptr, nullptr);
   // LDS -> HBM image (fmt 2 layout == image layout)
   copy16(image_out, g_lds + L.hdr_off, image_bytes(wn.n_words, wn.rec_cap));
 }
@@ -373,7 +374,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   }
   build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
                  reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
-                 reinterpret_cast<uint2*>(g_lds + L.bm2_off), nullptr, nullptr, PATH == 2 ? &dn : nullptr, g_lds);
+                 reinterpret_cast<uint2*>(g_lds + L.bm2_off), reinterpret_cast<unsigned short*>(g_lds + L.plist_off),
+                 nullptr, nullptr, PATH == 2 ? &dn : nullptr, g_lds);
   // new frame <- scan B (one-cell frame of the same size: the point list inside the frame, ndtpso_slam_node.cpp:229-230)
   const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
                                       g.hw, g.hh);

@@ -574,7 +574,7 @@ __device__ __forceinline__ unsigned bm_slot(const uint2* bm, int k) {
   return e.y + __popc(e.x & ((1u << (k & 31)) - 1u));
 }
 
-// scratch: key[n], cellkey[n], cnt[n] ints and bm2[n_words] uint2
+// scratch: key[n], cellkey[n], cnt[n] ints (rounded up to 4), plist[n] u16 and bm2[n_words] uint2
 // hdr/out: where the table goes (LDS); out.ab/out.cd or out.chol may be null when a kernel needs one score form
 // dn/lds0 (optional): also emit the dense form (u16 table at lds0, DenseRec[] at lds0 + dn->rec_off)
 __device__ inline void dense_clear_wg(const DenseP& dn, unsigned char* lds0) {
@@ -610,8 +610,8 @@ __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsi
 
 __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const double2* pts, int n,
                                       ImageHeader* hdr, const TableOut& out, int* key, int* cellkey, int* cnt,
-                                      uint2* bm2, CellRow* rows, uint32_t* n_rows_out, const DenseP* dn,
-                                      unsigned char* lds0) {
+                                      uint2* bm2, unsigned short* plist, CellRow* rows, uint32_t* n_rows_out,
+                                      const DenseP* dn, unsigned char* lds0) {
   const int tid = threadIdx.x, nt = blockDim.x;
   uint2* bm = out.bm;
   if (dn) dense_clear_wg(*dn, lds0);
@@ -650,6 +650,7 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
     }
     key[i] = k;
   }
+  if (tid < 4 && n + tid < ((n + 3) & ~3)) key[n + tid] = -1;  // pad the key array to a multiple of 4 entries
   __syncthreads();
 
   // 2. created cells -> dense slots in ascending cell order
@@ -669,52 +670,84 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   }
   __syncthreads();
 
-  // 3. points per cell (integer atomics: order independent)
+  // 3. points per cell (integer atomics: order independent); key[i] becomes the point's cell slot
   for (int i = tid; i < n; i += nt) {
     const int k = key[i];
-    if (k >= 0) atomicAdd(&cnt[bm_slot(bm2, k)], 1);
+    if (k >= 0) {
+      const int slot = (int)bm_slot(bm2, k);
+      atomicAdd(&cnt[slot], 1);
+      key[i] = slot;
+    }
   }
   __syncthreads();
 
-  // 4. built cells (count > 2, ndtcell.cpp:43) -> final record slots
+  // 4. built cells (count > 2, ndtcell.cpp:43) -> final record slots; per-cell offsets into the point lists
   for (int s = tid; s < n_created; s += nt)
     if (cnt[s] > 2) {
       const int k = cellkey[s];
       atomicOr(&bm[k >> 5].x, 1u << (k & 31));
     }
   __syncthreads();
-  if (wave_id() == 0) prefix_words_wave0(bm, wn.n_words, &hdr->n_built);
+  if (wave_id() == 0) {
+    prefix_words_wave0(bm, wn.n_words, &hdr->n_built);
+    // exclusive prefix of the counts, kept in the upper half of cnt[] (count and offset are both <= n < 65536)
+    const int lane = lane_id();
+    const int per = (n_created + kWave - 1) / kWave;
+    const int s0 = lane * per, s1 = min(n_created, s0 + per);
+    int sum = 0;
+    for (int q = s0; q < s1; ++q) sum += cnt[q];
+    int incl = sum;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+      const int t = __shfl_up(incl, d, kWave);
+      if (lane >= d) incl += t;
+    }
+    int run = incl - sum;
+    for (int q = s0; q < s1; ++q) {
+      const int c = cnt[q];
+      cnt[q] = c | (run << 16);
+      run += c;
+    }
+  }
   __syncthreads();
   if (tid == 0 && (int)hdr->n_built > wn.rec_cap) atomicOr(&hdr->status, 2u);
 
-  // 5. statistics: one owner thread per created cell; points are visited in beam order, as the
-  //    reference's per-cell vectors are, so sums round identically.
+  // 5. statistics: one owner thread per created cell.  The owner first gathers the indices of its points
+  //    (vectorised scan of the slot keys, ascending = beam order), then visits only those: sums round exactly
+  //    as the reference's per-cell vectors do (insertion order).
+  const int n4 = (n + 3) >> 2;
   for (int s = tid; s < n_created; s += nt) {
     const int mykey = cellkey[s];
-    const int c = cnt[s];
+    const int c = cnt[s] & 0xffff;
+    const int off = (int)((unsigned)cnt[s] >> 16);
     const bool built = c > 2;
     double mx = 0., my = 0., ia = 0., ib = 0., ic = 0., id = 0.;
     if (built) {
+      unsigned short* mine = plist + off;
+      int w = 0;
+      for (int q = 0; q < n4; ++q) {
+        const int4 kk = reinterpret_cast<const int4*>(key)[q];
+        if (kk.x == s) mine[w++] = (unsigned short)(4 * q);
+        if (kk.y == s) mine[w++] = (unsigned short)(4 * q + 1);
+        if (kk.z == s) mine[w++] = (unsigned short)(4 * q + 2);
+        if (kk.w == s) mine[w++] = (unsigned short)(4 * q + 3);
+      }
       double sx = 0., sy = 0.;
-      for (int i = 0; i < n; ++i) {
-        if (key[i] == mykey) {
-          const double2 p = pts[i];
-          sx += p.x;  // s_current_partial_sum += point, ndtcell.cpp:30
-          sy += p.y;
-        }
+      for (int t = 0; t < c; ++t) {
+        const double2 p = pts[mine[t]];
+        sx += p.x;  // s_current_partial_sum += point, ndtcell.cpp:30
+        sy += p.y;
       }
       mx = sx / (double)c;  // ndtcell.cpp:44
       my = sy / (double)c;
       double c00 = 0., c01 = 0., c10 = 0., c11 = 0.;
-      for (int i = 0; i < n; ++i) {
-        if (key[i] == mykey) {
-          const double2 p = pts[i];
-          const double d0 = p.x - mx, d1 = p.y - my;  // ndtcell.cpp:49-52
-          c00 += d0 * d0;
-          c01 += d0 * d1;
-          c10 += d1 * d0;
-          c11 += d1 * d1;
-        }
+      for (int t = 0; t < c; ++t) {
+        const double2 p = pts[mine[t]];
+        const double d0 = p.x - mx, d1 = p.y - my;  // ndtcell.cpp:49-52
+        c00 += d0 * d0;
+        c01 += d0 * d1;
+        c10 += d1 * d0;
+        c11 += d1 * d1;
       }
       // s_calc_covar_inverse, ndtcell.cpp:93-111 (eigenvalues of the 2x2 in closed form)
       const double nn = (double)c;
