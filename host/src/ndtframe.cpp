@@ -73,9 +73,8 @@ void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle
   std::vector<double> xy(2 * (size_t)n);
   std::vector<int32_t> idx(n);
   uint32_t kept = 0;
-  ndtpso_host::check(ndtpso_scan_to_points(dev, laser_data.data(), &geom, t, xy.data(), &kept), "loadLaser");
   const ndtpso_grid grid = grid_of(*this);
-  ndtpso_host::check(ndtpso_points_to_cells(dev, &grid, xy.data(), kept, nullptr, xy.data(), idx.data()), "loadLaser");
+  ndtpso_host::check(ndtpso_scan_to_cells(dev, laser_data.data(), &geom, t, &grid, xy.data(), idx.data(), &kept), "loadLaser");
   append(xy.data(), idx.data(), kept);
 }
 

@@ -121,6 +121,11 @@ int ndtpso_ref_get_cells(ndtpso_ctx *ctx, ndtpso_cell_row *rows, uint32_t max_ro
 int ndtpso_points_to_cells(ndtpso_ctx *ctx, const ndtpso_grid *grid, const double *xy, uint32_t n_points,
                            const double trans[3], double *xy_out, int32_t *cell_idx);
 
+/* NDTFrame::loadLaser in one launch: beam filter + polar->xy (+ s_trans) as ndtpso_scan_to_points, then the
+ * binning of ndtpso_points_to_cells for every surviving point.  xy_out: 2*n_beams doubles, cell_idx: n_beams. */
+int ndtpso_scan_to_cells(ndtpso_ctx *ctx, const float *ranges, const ndtpso_scan_geom *geom, const double trans[3],
+                         const ndtpso_grid *grid, double *xy_out, int32_t *cell_idx, uint32_t *n_out);
+
 /* The sliding-window state of one NDTCell that NDTCell::build reads and writes (ndtcell.h:65-68,
  * ndtcell.cpp:36-68); the host frame keeps it, the device does the arithmetic. */
 typedef struct {

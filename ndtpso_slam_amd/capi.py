@@ -81,7 +81,7 @@ assert CELL_WINDOW_DTYPE.itemsize == C.sizeof(CellWindow) == 160
 EXPORTS = [
     "ndtpso_ctx_create", "ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_set_stream", "ndtpso_synchronize",
     "ndtpso_rand_draws", "ndtpso_scan_to_points", "ndtpso_ref_from_points", "ndtpso_ref_from_scan",
-    "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_cells_build_windowed", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
+    "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_scan_to_cells", "ndtpso_cells_build_windowed", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
 ]
 
@@ -120,6 +120,7 @@ def load(build_if_missing: bool = True):
     L.ndtpso_ref_set_cells.argtypes = [vp, C.POINTER(Grid), C.c_uint32, ip, dp, dp]
     L.ndtpso_ref_get_cells.argtypes = [vp, C.POINTER(CellRow), C.c_uint32, up]
     L.ndtpso_points_to_cells.argtypes = [vp, C.POINTER(Grid), dp, C.c_uint32, dp, dp, ip]
+    L.ndtpso_scan_to_cells.argtypes = [vp, fp, C.POINTER(ScanGeom), dp, C.POINTER(Grid), dp, ip, up]
     L.ndtpso_cells_build_windowed.argtypes = [vp, C.c_uint32, vp, up, dp]
     L.ndtpso_cost_batch.argtypes = [vp, dp, C.c_uint32, dp, C.c_uint32, C.c_int, dp, ip]
     L.ndtpso_align.argtypes = [vp, dp, C.c_uint32, dp, dp, C.POINTER(PSOConfig), C.c_uint32, ip, C.c_int, dp, dp,
@@ -226,6 +227,16 @@ class Context:
                                                    _p(t, C.c_double) if t is not None else None,
                                                    _p(out, C.c_double), _p(idx, C.c_int32)))
         return out, idx
+
+    def scan_to_cells(self, ranges, geom: ScanGeom, grid: Grid, trans=(0.0, 0.0, 0.0)):
+        """NDTFrame::loadLaser in one launch: surviving points (beam order) and the cell each falls in."""
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        xy = np.empty((r.size, 2))
+        idx = np.empty(r.size, dtype=np.int32)
+        n = C.c_uint32()
+        self._chk(self._lib.ndtpso_scan_to_cells(self._h, _p(r, C.c_float), C.byref(geom), _p(_f64(trans, 3), C.c_double),
+                                                 C.byref(grid), _p(xy, C.c_double), _p(idx, C.c_int32), C.byref(n)))
+        return xy[:n.value].copy(), idx[:n.value].copy()
 
     def cells_build_windowed(self, cells: np.ndarray, pts_offset, pts_xy):
         """NDTCell::build with window state for many cells; `cells` (CELL_WINDOW_DTYPE) is updated in place."""

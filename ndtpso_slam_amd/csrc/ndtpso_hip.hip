@@ -207,6 +207,23 @@ k_points_to_cells(const double2* __restrict__ xy, int n, GridP g, int do_trans, 
   idx_out[i] = idx;
 }
 
+// ---- K3a+K3c fused: NDTFrame::loadLaser (ndtframe.cpp:144-185) -> points and their cells, one workgroup ----
+__global__ void __launch_bounds__(1024)
+k_scan_to_cells(const float* __restrict__ ranges, ScanP sp, int do_trans, double tc, double ts, double ttx, double tty,
+                GridP g, double2* __restrict__ out_xy, int32_t* __restrict__ out_idx, uint32_t* __restrict__ out_n) {
+  const int n = scan_to_points_wg(ranges, sp, do_trans != 0, tc, ts, ttx, tty, out_xy, lds_cnt(0));
+  __syncthreads();  // out_xy was written by this workgroup (global memory, workgroup scope)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    int ix, iy, idx = -1;
+    if (point_cell(g, out_xy[i], ix, iy)) {
+      // point_cell folds the reference's row wrap (fl(x + w/2) == w -> next row, column 0): same linear index
+      idx = ix + g.W * iy;
+    }
+    out_idx[i] = idx;
+  }
+  if (threadIdx.x == 0) out_n[0] = (uint32_t)n;
+}
+
 // ---- K3d: NDTCell::build with sliding-window state, one thread per created cell (ndtcell.cpp:36-68,93-111) ----
 struct CellWindow {  // == ndtpso_cell_window
   double global_sum[2], global_covar_sum[4], slot_sum[2], slot_covar[4], mean[2], icov[4];
@@ -875,6 +892,34 @@ int ndtpso_points_to_cells(ndtpso_ctx* c, const ndtpso_grid* grid, const double*
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(xy_out, c->xy2.p, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(cell_idx, c->dump.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NDTPSO_OK;
+}
+
+int ndtpso_scan_to_cells(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_geom* geom, const double trans[3],
+                         const ndtpso_grid* grid, double* xy_out, int32_t* cell_idx, uint32_t* n_out) {
+  if (!c || !ranges || !geom || !xy_out || !cell_idx || !n_out || geom->n_beams == 0)
+    return fail(c, NDTPSO_E_ARG, "null argument");
+  GridP g;
+  if (make_grid(grid, &g) != NDTPSO_OK) return fail(c, NDTPSO_E_ARG, "bad grid");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t nb = geom->n_beams;
+  HIP_TRY(c, c->ranges.reserve(nb * 4));
+  HIP_TRY(c, c->xy.reserve(nb * 16));
+  HIP_TRY(c, c->dump.reserve(nb * 4));
+  HIP_TRY(c, c->small.reserve(256));
+  HIP_TRY(c, hipMemcpyAsync(c->ranges.p, ranges, nb * 4, hipMemcpyHostToDevice, c->stream));
+  const double zero[3] = {0., 0., 0.};
+  const double* t = trans ? trans : zero;
+  const int do_trans = trans_is_zero(t) ? 0 : 1;
+  hipLaunchKernelGGL(k_scan_to_cells, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p, make_scan(geom),
+                     do_trans, std::cos(t[2]), std::sin(t[2]), t[0], t[1], g, (double2*)c->xy.p, (int32_t*)c->dump.p,
+                     (uint32_t*)c->small.p);
+  HIP_TRY(c, hipGetLastError());
+  // one synchronisation: the count travels with the (full-size) payload
+  HIP_TRY(c, hipMemcpyAsync(n_out, c->small.p, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(xy_out, c->xy.p, nb * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(cell_idx, c->dump.p, nb * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NDTPSO_OK;
 }

@@ -92,3 +92,17 @@ def test_windowed_build_matches_oracle(ctx, oracle, pairs8):
                 np.testing.assert_allclose(st["icov"], w["icov"], rtol=1e-12, atol=0)
         print("round", rnd, "cells", len(keys), "with advanced slots", advanced)
     assert advanced > 0
+
+
+def test_scan_to_cells_equals_two_step_route(ctx, oracle, pairs8):
+    """The fused loadLaser entry gives the same points and cells as scan_to_points + points_to_cells."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+    for grid, trans in ((capi.Grid(60, 60, 0.5), (0, 0, 0)), (capi.Grid(20, 20, 0.3), (0.4, -0.2, 0.05))):
+        xy, idx = ctx.scan_to_cells(p.new_ranges[1], geom, grid, trans)
+        xy2 = ctx.scan_to_points(p.new_ranges[1], geom, trans)
+        _, idx2 = ctx.points_to_cells(grid, xy2, None)
+        assert np.array_equal(xy, xy2) and np.array_equal(idx, idx2)
+        f = oracle.Frame((0, 0, 0), grid.width, grid.height, grid.cell_side)
+        assert np.array_equal(idx, np.array([f.get_cell_index(x, y) for x, y in xy], dtype=np.int32))
