@@ -4,8 +4,8 @@
 // arguments, same public data members, same methods -- so ndtpso_slam_node.cpp (call sites :64-78, 110,
 // 155, 167, 186, 194, 198, 202, 206, 229-230) builds against it unchanged.  The frame keeps the points
 // and the window state; every number is produced on the GPU through the C-ABI in include/ndtpso_hip.h:
-//   loadLaser -> ndtpso_scan_to_points + ndtpso_points_to_cells     update -> ndtpso_points_to_cells
-//   build     -> ndtpso_cells_build_windowed                        align  -> ndtpso_ref_set_cells + ndtpso_align
+//   loadLaser -> ndtpso_scan_to_cells                               update -> ndtpso_points_to_cells
+//   build     -> ndtpso_cells_build_windowed (+ ndtpso_occupancy_values) align  -> ndtpso_ref_set_cells + ndtpso_align
 #ifndef NDTPSO_SLAM_AMD_NDTFRAME_H
 #define NDTPSO_SLAM_AMD_NDTFRAME_H
 
@@ -61,6 +61,11 @@ class NDTFrame {
   // new-frame points in the order cost_function visits them (cells, then insertion; core.cpp:33-36)
   void collectPoints(std::vector<double>& xy) const;
   const NDTPSOConfig& config() const { return s_config; }
+#if BUILD_OCCUPANCY_GRID
+  // the occupancy grid as the reference stores it (og[x + height * y]) and its extent {min_x, max_x, min_y, max_y}
+  const vector<int8_t>& occupancyGrid(uint32_t* og_width = nullptr, uint32_t* og_height = nullptr,
+                                      uint32_t extent[4] = nullptr) const;
+#endif
   // pso_optimization against this frame (used by align() and by the free function in core.h)
   Vector3d optimize(const Vector3d& guess, const NDTFrame* new_frame, const Vector3d& deviation, const PSOConfig& cfg);
   double cost(const Vector3d& trans, const NDTFrame* new_frame);
@@ -72,7 +77,14 @@ class NDTFrame {
   double s_x_min, s_x_max, s_y_min, s_y_max;
   NDTPSOConfig s_config;
   int s_iter{0};
-  double s_og_cell_size{0.};
+#if BUILD_OCCUPANCY_GRID
+  struct {  // reference: s_occupancy_grid, ndtframe.h:22-29
+    uint32_t count{0}, width{0}, height{0}, max_x_ind{0}, max_y_ind{0}, min_x_ind{UINT32_MAX}, min_y_ind{UINT32_MAX};
+    double cell_size{0.};
+    vector<int8_t> og;
+  } s_occupancy_grid;
+  void rasteriseOccupancy();
+#endif
   std::vector<uint32_t> s_created;  // indices of created cells, in creation order
   bool s_table_dirty{true};         // the device reference table must be re-uploaded before the next align
   void append(const double* xy, const int32_t* idx, uint32_t n);

@@ -3,7 +3,11 @@
 // per-scan frame as a one-cell frame (:229-230).  Reads a binary scan file, prints one pose per scan.
 //
 //   file: int32 n_scans, int32 n_beams, float angle_min, float angle_inc, float range_max, then n_scans*n_beams floats
-//   usage: node_replay scans.bin frame_size cell_side iterations population [srand_seed]
+//   usage: node_replay scans.bin frame_size cell_side iterations population [srand_seed [og_cell_size dump_prefix
+//          [pixels_per_metre]]]
+// With a dump prefix the shutdown export of the node (:141-172) runs too: a one-cell global map collects every scan
+// and pose and is dumped as <prefix>.{pose.csv,map.csv,gnuplot,png}; the reference frame (with its occupancy grid) as
+// <prefix>-ref-frame.*, plus the raw grid as <prefix>-ref-frame.og.bin for the tests.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -32,9 +36,14 @@ int main(int argc, char** argv) {
   ndtpso_slam_device_init();  // before srand(): keep runtime start-up out of the rand() stream
   if (argc > 6) std::srand((unsigned)std::atoi(argv[6]));
 
+  const double og_cell_size = argc > 8 ? std::atof(argv[7]) : 0.;
+  const char* dump_prefix = argc > 8 ? argv[8] : nullptr;
+  const short density = argc > 9 ? (short)std::atoi(argv[9]) : 100;
+
   const Vector3d initial_pose = Vector3d::Zero();
   // ndtpso_slam_node.cpp:64-78
-  NDTFrame* ref_frame = new NDTFrame(Vector3d::Zero(), frame_size, frame_size, cell_side, true, conf);
+  NDTFrame* ref_frame = new NDTFrame(Vector3d::Zero(), frame_size, frame_size, cell_side, true, conf, og_cell_size);
+  NDTFrame* global_map = dump_prefix ? new NDTFrame(Vector3d::Zero(), frame_size, frame_size, frame_size, false) : nullptr;
   NDTFrame* current_frame = new NDTFrame(initial_pose, frame_size, frame_size, cell_side, false);
   Vector3d previous_pose = initial_pose, current_pose = initial_pose;
   bool first_iteration = true;
@@ -51,6 +60,10 @@ int main(int argc, char** argv) {
     previous_pose = current_pose;
     ref_frame->update(current_pose, current_frame);                            // :198
     if (k > 0) busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (global_map) {                                                          // :200-206
+      global_map->update(current_pose, current_frame);
+      global_map->addPose(0.025 * k, current_pose);
+    }
     std::printf("%d %.17g %.17g %.17g\n", k, current_pose.x(), current_pose.y(), current_pose.z());
     delete current_frame;                                                      // :228-230
     current_frame = new NDTFrame(initial_pose, frame_size, frame_size, frame_size, false);
@@ -59,6 +72,21 @@ int main(int argc, char** argv) {
   std::fclose(f);
   if (n_scans > 1)  // the node's own metric ("matching rate", ndtpso_slam_node.cpp:239): loadLaser + align + update per scan
     std::fprintf(stderr, "matching rate: %.1f Hz (%.3f ms per scan)\n", (n_scans - 1) / busy_s, 1e3 * busy_s / (n_scans - 1));
+  if (dump_prefix) {  // :141-172
+    char name[1024];
+    global_map->dumpMap(dump_prefix, true, true, true, density, true);
+    std::snprintf(name, sizeof(name), "%s-ref-frame", dump_prefix);
+    ref_frame->dumpMap(name, false, true, true, density, true);
+    uint32_t dims[6] = {0, 0, 0, 0, 0, 0};
+    const std::vector<int8_t>& og = ref_frame->occupancyGrid(&dims[0], &dims[1], &dims[2]);
+    std::snprintf(name, sizeof(name), "%s-ref-frame.og.bin", dump_prefix);
+    if (FILE* o = std::fopen(name, "wb")) {
+      std::fwrite(dims, 4, 6, o);
+      std::fwrite(og.data(), 1, og.size(), o);
+      std::fclose(o);
+    }
+    delete global_map;
+  }
   delete current_frame;
   delete ref_frame;
   return 0;

@@ -2,6 +2,7 @@
 // Reference behaviour cited as lib/ndtpso_slam/ndtframe.cpp:LINE.
 #include "ndtpso_slam/ndtframe.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,7 @@
 
 #include "device.h"
 #include "ndtpso_slam/core.h"
+#include "raster.h"
 
 namespace {
 ndtpso_grid grid_of(const NDTFrame& f) { return ndtpso_grid{f.width, f.height, f.cell_side}; }
@@ -45,7 +47,13 @@ NDTFrame::NDTFrame(Vector3d trans, unsigned short width_, unsigned short height_
   s_y_min = -height / 2.;
   s_y_max = height / 2.;
 #if BUILD_OCCUPANCY_GRID
-  s_og_cell_size = occupancy_grid_cell_size;  // map export only (out of scope); remembered, not rasterised
+  s_occupancy_grid.cell_size = occupancy_grid_cell_size;  // ndtframe.cpp:32-46; 0 = no grid (intermediate frames)
+  if (occupancy_grid_cell_size > 0.) {
+    s_occupancy_grid.width = uint32_t(std::ceil(width / occupancy_grid_cell_size));
+    s_occupancy_grid.height = uint32_t(std::ceil(height / occupancy_grid_cell_size));
+    s_occupancy_grid.count = s_occupancy_grid.width * s_occupancy_grid.height;
+    s_occupancy_grid.og = vector<int8_t>(s_occupancy_grid.count, 0);
+  }
 #endif
 }
 
@@ -181,9 +189,66 @@ void NDTFrame::build() {
       }
     }
   }
+#if BUILD_OCCUPANCY_GRID
+  if (s_occupancy_grid.cell_size > 0.) rasteriseOccupancy();
+#endif
   built = true;
   s_table_dirty = true;
 }
+
+#if BUILD_OCCUPANCY_GRID
+// reference: the occupancy-grid branch of build(), ndtframe.cpp:79-112.  The Gaussians are evaluated on the device
+// (ndtpso_occupancy_values); the scatter keeps the reference's order (ascending cell index, j outer, k inner) and
+// its indexing, including row = index / heightNumOfCells and og[x + height * y].
+void NDTFrame::rasteriseOccupancy() {
+  auto& g = s_occupancy_grid;
+  const uint32_t per_cell = (uint32_t)std::floor(cell_side / g.cell_size);
+  if (per_cell == 0) return;
+  std::vector<uint32_t> order(s_created);
+  std::sort(order.begin(), order.end());
+  std::vector<int32_t> index;
+  std::vector<double> mean, icov;
+  for (uint32_t i : order) {
+    const NDTCell& c = cells[i];
+    if (!c.built) continue;  // normalDistribution of an un-built cell is 0: nothing is written (ndtcell.cpp:70-78)
+    index.push_back((int32_t)i);
+    mean.push_back(c.mean.x());
+    mean.push_back(c.mean.y());
+    for (int j = 0; j < 4; ++j) icov.push_back(c.win_->inv_covar[j]);
+  }
+  if (index.empty()) return;
+  std::vector<int8_t> v(index.size() * per_cell * per_cell);
+  const ndtpso_grid grid = grid_of(*this);
+  ndtpso_host::check(ndtpso_occupancy_values(ndtpso_host::device(), &grid, g.cell_size, (uint32_t)index.size(),
+                                             index.data(), mean.data(), icov.data(), v.data()),
+                     "occupancy grid");
+  size_t t = 0;
+  for (int32_t i : index) {
+    const uint32_t cx = (uint32_t)i % widthNumOfCells, cy = (uint32_t)i / heightNumOfCells;
+    for (uint32_t j = 0; j < per_cell; ++j)
+      for (uint32_t k = 0; k < per_cell; ++k, ++t) {
+        if (v[t] < 0) continue;  // p == 0
+        const uint32_t ox = cx * per_cell + j, oy = cy * per_cell + k;
+        g.min_x_ind = std::min(ox, g.min_x_ind);
+        g.max_x_ind = std::max(ox, g.max_x_ind);
+        g.min_y_ind = std::min(oy, g.min_y_ind);
+        g.max_y_ind = std::max(oy, g.max_y_ind);
+        const size_t at = (size_t)ox + (size_t)g.height * oy;
+        if (at < g.og.size()) g.og[at] = v[t];  // (the reference writes unchecked)
+      }
+  }
+}
+
+const vector<int8_t>& NDTFrame::occupancyGrid(uint32_t* og_width, uint32_t* og_height, uint32_t extent[4]) const {
+  if (og_width) *og_width = s_occupancy_grid.width;
+  if (og_height) *og_height = s_occupancy_grid.height;
+  if (extent) {
+    extent[0] = s_occupancy_grid.min_x_ind, extent[1] = s_occupancy_grid.max_x_ind;
+    extent[2] = s_occupancy_grid.min_y_ind, extent[3] = s_occupancy_grid.max_y_ind;
+  }
+  return s_occupancy_grid.og;
+}
+#endif
 
 // built cells -> device reference table (LDS image packed by ndtpso_ref_set_cells)
 void NDTFrame::uploadTable() {
@@ -236,12 +301,17 @@ double NDTFrame::cost(const Vector3d& trans, const NDTFrame* new_frame) {
   return c;
 }
 
-// reference: align, ndtframe.cpp:251-266.  Unlike the reference (which passes no config, :257, so always runs
-// 30 x 50) the frame's own PSOConfig is honoured; with the default NDTPSOConfig the two coincide.
+// reference: align, ndtframe.cpp:251-266.  The reference passes no config to pso_optimization (:257), so the
+// frame's own PSOConfig is never used and every alignment runs the default 30 x 50.  That is what happens here
+// too; NDTPSO_ALIGN_FRAME_CONFIG=1 in the environment makes align() honour the frame's PSOConfig instead.
 Vector3d NDTFrame::align(Vector3d initial_guess, const NDTFrame* const new_frame) {
   Vector3d deviation = s_iter < 2 ? Vector3d(.1, .1, 3.1415E-3) : Vector3d((s_pose_diff * 2.).array().abs());
   ++s_iter;
-  Vector3d pose = optimize(initial_guess, new_frame, deviation, s_config.psoConfig);
+  static const bool frame_config = [] {
+    const char* e = std::getenv("NDTPSO_ALIGN_FRAME_CONFIG");
+    return e && e[0] == '1';
+  }();
+  Vector3d pose = optimize(initial_guess, new_frame, deviation, frame_config ? s_config.psoConfig : PSOConfig());
 #if TRANSFORM_POSE_AFTER_ALIGN
   pose -= s_trans;
 #endif
@@ -285,37 +355,112 @@ void NDTFrame::transform(Vector3d trans) {
   built = false;
 }
 
-// reference: dumpMap, ndtframe.cpp:268-422 (CSV / gnuplot / PNG export at shutdown) -- out of scope of the
-// accelerated path; the poses and points are written as plain CSV so a run can still be inspected.
-void NDTFrame::dumpMap(const char* filename, bool save_poses, bool save_points, bool, short
+// reference: dumpMap, ndtframe.cpp:268-422 -- <name>.pose.csv, <name>.map.csv, <name>.gnuplot, the map image and
+// the occupancy-grid image, same file names and text formats.  The reference draws the images with OpenCV when it
+// was found at build time; here they are always drawn (raster.h), so pixel-level equality with OpenCV's line and
+// circle primitives is not claimed.  Shutdown-time export, not on the alignment path.
+void NDTFrame::dumpMap(const char* filename, bool save_poses, bool save_points, bool save_image, short density
 #if BUILD_OCCUPANCY_GRID
                        ,
-                       bool
+                       bool save_occupancy_grid
 #endif
 ) {
-  char name[1024];
+  using ndtpso_host::Raster;
+  using ndtpso_host::Rgb;
+  FILE *poses = nullptr, *points = nullptr;
+  char name[1280];
   if (save_poses) {
     std::snprintf(name, sizeof(name), "%s.pose.csv", filename);
-    if (FILE* f = std::fopen(name, "w")) {
-      std::fprintf(f, "timestamp,xP,yP,thP,xO,yO,thO\n");
-      for (size_t i = 0; i < s_poses.size(); ++i)
-        std::fprintf(f, "%.5f,%.5f,%.5f,%.5f,%.5f,%.5f,%.5f\n", s_timestamps[i], s_poses[i].x(), s_poses[i].y(),
-                     s_poses[i].z(), s_odoms[i].x(), s_odoms[i].y(), s_odoms[i].z());
-      std::fclose(f);
-    } else {
-      std::printf("Cannot open file: %s\n", name);
-    }
+    if ((poses = std::fopen(name, "w"))) std::fprintf(poses, "timestamp,xP,yP,thP,xO,yO,thO\n");
   }
   if (save_points) {
     std::snprintf(name, sizeof(name), "%s.map.csv", filename);
-    if (FILE* f = std::fopen(name, "w")) {
-      std::fprintf(f, "x,y\n");
-      for (uint32_t i : s_created)
-        for (const auto& slot : cells[i].win_->points)
-          for (const Vector2d& p : slot) std::fprintf(f, "%.5f,%.5f\n", p.x(), p.y());
-      std::fclose(f);
-    } else {
-      std::printf("Cannot open file: %s\n", name);
+    if ((points = std::fopen(name, "w"))) std::fprintf(points, "x,y\n");
+  }
+  if ((save_poses && !poses) || (save_points && !points)) {  // ndtframe.cpp:294-297
+    std::printf("%s: Cannot open files, cannot save!\n ", __func__);
+    if (poses) std::fclose(poses);
+    if (points) std::fclose(points);
+    return;
+  }
+
+  const int size_x = width * density, size_y = height * density;  // density in pixels per metre
+  Raster img(save_image ? size_x : 1, save_image ? size_y : 1, 3, 255);  // cv::Mat(rows = size_x, cols = size_y), :304
+  if (save_image && density > 0)
+    for (int i = 0; i < size_x; i += density) {  // one grid line per metre
+      img.line(i, 0, i, size_y, Rgb{180, 180, 180});
+      img.line(0, i, size_x, i, Rgb{180, 180, 180});
+    }
+
+  // every stored point, in cell order then window-slot order then insertion order (ndtframe.cpp:314-328)
+  for (const NDTCell& c : cells) {
+    if (!c.win_) continue;
+    for (const auto& slot : c.win_->points)
+      for (const Vector2d& p : slot) {
+        if (save_image)
+          img.circle(size_x / 2 + static_cast<int>(p.x() * density), size_y / 2 - static_cast<int>(p.y() * density), 1,
+                     Rgb{0, 0, 0});
+        if (save_points) std::fprintf(points, "%.5f,%.5f\n", p.x(), p.y());
+      }
+  }
+
+  int counter = 0;
+  for (size_t i = 0; i < s_poses.size(); ++i) {  // ndtframe.cpp:331-350
+    if (save_image) {
+      const int x = size_x / 2 + static_cast<int>(s_poses[i].x() * density);
+      const int y = size_y / 2 - static_cast<int>(s_poses[i].y() * density);
+      const int dx = static_cast<int>(.5 * std::cos(-s_poses[i].z()) * density);
+      const int dy = static_cast<int>(.5 * std::sin(-s_poses[i].z()) * density);
+      if (counter == 0) img.line(x, y, x + dx, y + dy, Rgb{80, 40, 40});  // cv::Scalar is BGR
+      img.circle(x, y, 2, Rgb{255, 0, 0});
+      counter = (counter + 1) % 5;
+    }
+    // the reference guards the pose rows with save_points (:347); they go to the pose file, four columns
+    if (save_points && poses)
+      std::fprintf(poses, "%.6f,%.5f,%.5f,%.5f\n", s_timestamps[i], s_poses[i].x(), s_poses[i].y(), s_poses[i].z());
+  }
+  if (poses) std::fclose(poses);
+  if (points) std::fclose(points);
+
+  if (save_poses || save_points) {  // ndtframe.cpp:358-390
+    std::snprintf(name, sizeof(name), "%s.gnuplot", filename);
+    if (FILE* gp = std::fopen(name, "w")) {
+      std::fprintf(gp, "set datafile separator ','\nset key autotitle columnhead\nset size ratio -1\nplot ");
+      if (save_points)
+        std::fprintf(gp, "'%s.map.csv' title 'Map' with points pointsize 0.2 pointtype 5 linecolor rgb '#555555'",
+                     filename);
+      if (save_poses)
+        std::fprintf(gp,
+                     ", \\\n'%s.pose.csv' using 2:3 title 'Pose (LiDAR)' with linespoints linewidth 0.7 "
+                     "pointtype 6 pointsize 0.7 linecolor rgb '#ff0000'",
+                     filename);
+      std::fprintf(gp, "\npause 1000\n");
+      std::fclose(gp);
     }
   }
+
+  if (save_image) {  // ndtframe.cpp:393-398
+    std::snprintf(name, sizeof(name), "%s-w%d-%dp%di-%dx%d-c%.2f-%dppm.png", filename, NDT_WINDOW_SIZE,
+                  s_config.psoConfig.populationSize, s_config.psoConfig.iterations, width, height, cell_side, density);
+    if (!img.writePng(name)) std::printf("%s: cannot write %s\n", __func__, name);
+  }
+
+#if BUILD_OCCUPANCY_GRID
+  const auto& g = s_occupancy_grid;
+  if (save_occupancy_grid && g.cell_size > 0. && g.min_x_ind <= g.max_x_ind && g.min_y_ind <= g.max_y_ind) {
+    // ndtframe.cpp:401-420.  The reference sizes the image (max - min) and then addresses row (max - min) and
+    // column (max - min), one past the end; this image has the extra row and column instead.
+    const uint32_t real_width = g.max_x_ind - g.min_x_ind, real_height = g.max_y_ind - g.min_y_ind;
+    Raster og_img((int)real_height + 1, (int)real_width + 1, 1, 255);
+    for (uint32_t i = g.min_x_ind; i <= g.max_x_ind; ++i)
+      for (uint32_t j = g.min_y_ind; j <= g.max_y_ind; ++j) {
+        const size_t ind = (size_t)i + (size_t)g.height * j;
+        if (ind < g.og.size() && g.og[ind] > 0)
+          og_img.put(int(i - g.min_x_ind), int(real_height - (j - g.min_y_ind)),
+                     Rgb{uint8_t(255.0 - g.og[ind] * 2.55), 0, 0});
+      }
+    std::snprintf(name, sizeof(name), "%s-%dx%d-cell%.2fm-occupancy-grid.png", filename, g.width, g.height, g.cell_size);
+    if (!og_img.writePng(name)) std::printf("%s: cannot write %s\n", __func__, name);
+  }
+#endif
 }

@@ -147,6 +147,14 @@ typedef struct {
 int ndtpso_cells_build_windowed(ndtpso_ctx *ctx, uint32_t n_cells, ndtpso_cell_window *cells,
                                 const uint32_t *pts_offset, const double *pts_xy);
 
+/* Occupancy-grid rasterisation of NDTFrame::build (ndtframe.cpp:69-71,79-112; map export): for each
+ * of n_cells BUILT cells and each of its k x k sub-cells (k = floor(cell_side / og_cell_size), j outer, k inner as
+ * the reference loops), values[c*k*k + j*k + kk] = int8(100 * normalDistribution(sub-cell centre)), or -1 when the
+ * Gaussian is exactly 0 there (the reference then leaves the grid untouched).  The row index of a cell is
+ * index / heightNumOfCells, as in the reference (:81). */
+int ndtpso_occupancy_values(ndtpso_ctx *ctx, const ndtpso_grid *grid, double og_cell_size, uint32_t n_cells,
+                            const int32_t *index, const double *mean, const double *icov, int8_t *values);
+
 /* ---- K1: cost_function (core.cpp:26-48) for M candidate poses ---------- */
 /* xy: n_points new-frame points; poses: 3*M; costs: M; cell_idx (optional, M*n_points):
  * linear cell index scored against, -1 outside frame, -2 cell not built. */

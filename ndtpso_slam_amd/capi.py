@@ -81,7 +81,7 @@ assert CELL_WINDOW_DTYPE.itemsize == C.sizeof(CellWindow) == 160
 EXPORTS = [
     "ndtpso_ctx_create", "ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_set_stream", "ndtpso_synchronize",
     "ndtpso_rand_draws", "ndtpso_scan_to_points", "ndtpso_ref_from_points", "ndtpso_ref_from_scan",
-    "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_scan_to_cells", "ndtpso_cells_build_windowed", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
+    "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_scan_to_cells", "ndtpso_cells_build_windowed", "ndtpso_occupancy_values", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
 ]
 
@@ -122,6 +122,7 @@ def load(build_if_missing: bool = True):
     L.ndtpso_points_to_cells.argtypes = [vp, C.POINTER(Grid), dp, C.c_uint32, dp, dp, ip]
     L.ndtpso_scan_to_cells.argtypes = [vp, fp, C.POINTER(ScanGeom), dp, C.POINTER(Grid), dp, ip, up]
     L.ndtpso_cells_build_windowed.argtypes = [vp, C.c_uint32, vp, up, dp]
+    L.ndtpso_occupancy_values.argtypes = [vp, C.POINTER(Grid), C.c_double, C.c_uint32, ip, dp, dp, C.POINTER(C.c_int8)]
     L.ndtpso_cost_batch.argtypes = [vp, dp, C.c_uint32, dp, C.c_uint32, C.c_int, dp, ip]
     L.ndtpso_align.argtypes = [vp, dp, C.c_uint32, dp, dp, C.POINTER(PSOConfig), C.c_uint32, ip, C.c_int, dp, dp,
                                C.POINTER(AlignStats)]
@@ -247,6 +248,18 @@ class Context:
         self._chk(self._lib.ndtpso_cells_build_windowed(self._h, cells.size, cells.ctypes.data_as(C.c_void_p),
                                                         _p(off, C.c_uint32), _p(xy, C.c_double)))
         return cells
+
+    def occupancy_values(self, grid: Grid, og_cell_size, index, mean, icov):
+        """int8(100 p) at the k x k sub-cell centres of each built cell ([n_cells, k, k]; -1 where p == 0)."""
+        index = np.ascontiguousarray(index, dtype=np.int32)
+        mean = _f64(mean).reshape(-1, 2)
+        icov = _f64(icov).reshape(-1, 4)
+        k = int(np.floor(grid.cell_side / og_cell_size))
+        out = np.empty((index.size, k, k), dtype=np.int8)
+        self._chk(self._lib.ndtpso_occupancy_values(self._h, C.byref(grid), float(og_cell_size), index.size,
+                                                    _p(index, C.c_int32), _p(mean, C.c_double), _p(icov, C.c_double),
+                                                    out.ctypes.data_as(C.POINTER(C.c_int8))))
+        return out
 
     # ---- K1 ----
     def cost_batch(self, xy, poses, mode=SCORE_F32, want_cells=False):

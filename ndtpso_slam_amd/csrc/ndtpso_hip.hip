@@ -224,6 +224,28 @@ k_scan_to_cells(const float* __restrict__ ranges, ScanP sp, int do_trans, double
   if (threadIdx.x == 0) out_n[0] = (uint32_t)n;
 }
 
+// ---- occupancy-grid values of built cells (NDTFrame::build, ndtframe.cpp:79-112) ----------------------------
+__global__ void __launch_bounds__(256)
+k_occupancy_values(int n_cells, int per_cell, double og_cs, double hw, double hh, int W, int H,
+                   const int32_t* __restrict__ index, const double2* __restrict__ mean, const double4* __restrict__ icov,
+                   int8_t* __restrict__ values) {
+  const int kk2 = per_cell * per_cell;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (long)n_cells * kk2) return;
+  const int c = (int)(t / kk2), r = (int)(t % kk2), j = r / per_cell, k = r % per_cell;
+  const unsigned i = (unsigned)index[c];
+  const unsigned cx = i % (unsigned)W, cy = i / (unsigned)H;  // sic (ndtframe.cpp:81)
+  const double x_c = ((double)(cx * (unsigned)per_cell + (unsigned)j) * og_cs + og_cs / 2.) - hw;
+  const double y_c = ((double)(cy * (unsigned)per_cell + (unsigned)k) * og_cs + og_cs / 2.) - hh;
+  const double2 m = mean[c];
+  const double4 ic = icov[c];
+  const double d0 = x_c - m.x, d1 = y_c - m.y;  // NDTCell::normalDistribution, ndtcell.cpp:70-78
+  const double r0 = d0 * ic.x + d1 * ic.z;
+  const double r1 = d0 * ic.y + d1 * ic.w;
+  const double p = exp(-(r0 * d0 + r1 * d1) / 2.);
+  values[t] = (p > 0.) ? (int8_t)(p * 100.) : (int8_t)-1;
+}
+
 // ---- K3d: NDTCell::build with sliding-window state, one thread per created cell (ndtcell.cpp:36-68,93-111) ----
 struct CellWindow {  // == ndtpso_cell_window
   double global_sum[2], global_covar_sum[4], slot_sum[2], slot_covar[4], mean[2], icov[4];
@@ -920,6 +942,32 @@ int ndtpso_scan_to_cells(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_g
   HIP_TRY(c, hipMemcpyAsync(n_out, c->small.p, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(xy_out, c->xy.p, nb * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipMemcpyAsync(cell_idx, c->dump.p, nb * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return NDTPSO_OK;
+}
+
+int ndtpso_occupancy_values(ndtpso_ctx* c, const ndtpso_grid* grid, double og_cell_size, uint32_t n_cells,
+                            const int32_t* index, const double* mean, const double* icov, int8_t* values) {
+  if (!c || !(og_cell_size > 0.) || (n_cells && (!index || !mean || !icov || !values)))
+    return fail(c, NDTPSO_E_ARG, "null argument");
+  GridP g;
+  if (make_grid(grid, &g) != NDTPSO_OK) return fail(c, NDTPSO_E_ARG, "bad grid");
+  const int per_cell = (int)std::floor(grid->cell_side / og_cell_size);  // ndtframe.cpp:70
+  if (n_cells == 0 || per_cell <= 0) return NDTPSO_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t total = (size_t)n_cells * per_cell * per_cell;
+  HIP_TRY(c, c->seeds.reserve((size_t)n_cells * 4));
+  HIP_TRY(c, c->xy.reserve((size_t)n_cells * 16));
+  HIP_TRY(c, c->xy2.reserve((size_t)n_cells * 32));
+  HIP_TRY(c, c->dump.reserve(total));
+  HIP_TRY(c, hipMemcpyAsync(c->seeds.p, index, (size_t)n_cells * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->xy.p, mean, (size_t)n_cells * 16, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->xy2.p, icov, (size_t)n_cells * 32, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_occupancy_values, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, (int)n_cells,
+                     per_cell, og_cell_size, g.hw, g.hh, g.W, g.H, (const int32_t*)c->seeds.p, (const double2*)c->xy.p,
+                     (const double4*)c->xy2.p, (int8_t*)c->dump.p);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpyAsync(values, c->dump.p, total, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NDTPSO_OK;
 }

@@ -53,6 +53,10 @@ struct orc_frame {
   double cell_side;
   int built;
   orc_cell **cells; /* dense grid of lazily allocated cells (the reference allocates all, ndtframe.cpp:30) */
+  /* s_occupancy_grid, ndtframe.h:22-29 */
+  double og_cell_size;
+  uint32_t og_width, og_height, og_count, og_min_x, og_max_x, og_min_y, og_max_y;
+  int8_t *og;
 };
 
 void orc_pso_config_default(orc_pso_config *c) {
@@ -243,6 +247,7 @@ orc_frame *orc_frame_create(const double trans[3], unsigned short width, unsigne
 void orc_frame_destroy(orc_frame *f) {
   unsigned i;
   if (!f) return;
+  free(f->og);
   for (i = 0; i < f->num_cells; ++i) cell_free(f->cells[i]);
   free(f->cells);
   free(f);
@@ -325,10 +330,59 @@ void orc_frame_update(orc_frame *ref, const double trans[3], const orc_frame *nf
   }
 }
 
+void orc_frame_enable_occupancy_grid(orc_frame *f, double og_cell_size) {
+  /* ndtframe.cpp:32-46 */
+  f->og_cell_size = og_cell_size;
+  free(f->og);
+  f->og = NULL;
+  f->og_min_x = f->og_min_y = UINT32_MAX;
+  f->og_max_x = f->og_max_y = 0;
+  if (og_cell_size > 0.) {
+    f->og_width = (uint32_t)ceil(f->width / og_cell_size);
+    f->og_height = (uint32_t)ceil(f->height / og_cell_size);
+    f->og_count = f->og_width * f->og_height;
+    f->og = (int8_t *)calloc(f->og_count ? f->og_count : 1, 1);
+  }
+}
+
+const int8_t *orc_frame_occupancy_grid(const orc_frame *f, uint32_t *w, uint32_t *h, uint32_t minmax[4]) {
+  *w = f->og_width;
+  *h = f->og_height;
+  minmax[0] = f->og_min_x;
+  minmax[1] = f->og_max_x;
+  minmax[2] = f->og_min_y;
+  minmax[3] = f->og_max_y;
+  return f->og;
+}
+
 void orc_frame_build(orc_frame *f) {
   unsigned i;
-  for (i = 0; i < f->num_cells; ++i)
-    if (f->cells[i] && f->cells[i]->created) cell_build(f->cells[i]);
+  /* ndtframe.cpp:69-71 */
+  uint32_t per_cell = (f->og && f->og_cell_size > 0.) ? (uint32_t)floor(f->cell_side / f->og_cell_size) : 0;
+  for (i = 0; i < f->num_cells; ++i) {
+    orc_cell *c = f->cells[i];
+    if (!(c && c->created)) continue;
+    cell_build(c);
+    if (f->og && f->og_cell_size > 0.) { /* ndtframe.cpp:79-112 */
+      uint32_t cx = i % f->wcells, cy = i / f->hcells; /* sic: the row index divides by heightNumOfCells (:81) */
+      uint32_t j, k;
+      for (j = 0; j < per_cell; ++j)
+        for (k = 0; k < per_cell; ++k) {
+          double x_c = ((cx * per_cell + j) * f->og_cell_size + f->og_cell_size / 2.) - (f->width / 2.);
+          double y_c = ((cy * per_cell + k) * f->og_cell_size + f->og_cell_size / 2.) - (f->height / 2.);
+          double p = cell_normal_distribution(c, x_c, y_c);
+          if (p > 0.) {
+            uint32_t ox = cx * per_cell + j, oy = cy * per_cell + k;
+            if (ox < f->og_min_x) f->og_min_x = ox;
+            if (ox > f->og_max_x) f->og_max_x = ox;
+            if (oy < f->og_min_y) f->og_min_y = oy;
+            if (oy > f->og_max_y) f->og_max_y = oy;
+            if ((size_t)ox + (size_t)f->og_height * oy < f->og_count) /* out of range is undefined in the reference */
+              f->og[ox + f->og_height * oy] = (int8_t)(p * 100.);
+          }
+        }
+    }
+  }
   f->built = 1;
 }
 

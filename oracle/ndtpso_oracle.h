@@ -117,6 +117,12 @@ void orc_pso_optimization(const double guess[3], orc_frame *ref, const orc_frame
                           const double deviation[3], const orc_pso_config *cfg, orc_rand *rng,
                           double out_pose[3], double *out_cost, orc_pso_stats *stats);
 
+/* occupancy grid of NDTFrame (ndtframe.h:22-29, ctor ndtframe.cpp:32-46, rasterised in build() :79-112).
+ * Enable before build(); og is width_cells x height_cells int8 (index x + height*y as the reference writes it). */
+void orc_frame_enable_occupancy_grid(orc_frame *f, double og_cell_size);
+const int8_t *orc_frame_occupancy_grid(const orc_frame *f, uint32_t *og_width, uint32_t *og_height,
+                                       uint32_t minmax[4] /* min_x, max_x, min_y, max_y */);
+
 /* accessors used by the tests */
 unsigned orc_frame_num_points(const orc_frame *f);              /* sum of points_vector[0] sizes */
 unsigned orc_frame_get_points(const orc_frame *f, double *xy);   /* cells order then insertion order (core.cpp:33-36) */

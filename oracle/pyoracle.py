@@ -81,6 +81,9 @@ def lib():
     L.orc_frame_export_cells.restype = C.c_uint
     L.orc_frame_export_cells.argtypes = [C.c_void_p, C.POINTER(CellRow), C.c_uint]
     L.orc_frame_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.orc_frame_enable_occupancy_grid.argtypes = [C.c_void_p, C.c_double]
+    L.orc_frame_occupancy_grid.restype = C.POINTER(C.c_int8)
+    L.orc_frame_occupancy_grid.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.orc_glibc_rand_fill.argtypes = [C.c_uint32, C.POINTER(C.c_int32), C.c_size_t]
     L.orc_pso_rand_draws.restype = C.c_size_t
     L.orc_pso_rand_draws.argtypes = [C.POINTER(PSOConfig)]
@@ -132,6 +135,17 @@ class Frame:
 
     def build(self):
         lib().orc_frame_build(self._h)
+
+    def enable_occupancy_grid(self, og_cell_size):
+        lib().orc_frame_enable_occupancy_grid(self._h, float(og_cell_size))
+
+    def occupancy_grid(self):
+        """(og[height-major as the reference indexes it: og[x + height*y]], width, height, (min_x, max_x, min_y, max_y))"""
+        w, h = C.c_uint32(), C.c_uint32()
+        mm = (C.c_uint32 * 4)()
+        ptr = lib().orc_frame_occupancy_grid(self._h, C.byref(w), C.byref(h), mm)
+        og = np.ctypeslib.as_array(ptr, shape=(w.value * h.value,)).copy()
+        return og, w.value, h.value, tuple(mm)
 
     def set_trans(self, trans):
         lib().orc_frame_set_trans(self._h, _dp(_vec3(trans)))

@@ -106,3 +106,36 @@ def test_scan_to_cells_equals_two_step_route(ctx, oracle, pairs8):
         assert np.array_equal(xy, xy2) and np.array_equal(idx, idx2)
         f = oracle.Frame((0, 0, 0), grid.width, grid.height, grid.cell_side)
         assert np.array_equal(idx, np.array([f.get_cell_index(x, y) for x, y in xy], dtype=np.int32))
+
+
+def test_occupancy_grid_values_match_oracle(ctx, oracle, pairs8):
+    """f-4: the occupancy-grid rasterisation of NDTFrame::build (ndtframe.cpp:79-112) on the device."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    seen = 0
+    for (frame, cs, ogcs) in ((60, 0.5, 0.1), (40, 1.0, 0.25), (60, 1.0, 0.25), (60, 0.5, 0.2)):
+        f = oracle.Frame((0, 0, 0), frame, frame, cs)
+        f.enable_occupancy_grid(ogcs)
+        f.load_laser(p.ref_ranges[0], p.angle_min, p.angle_inc, p.range_max)
+        f.build()
+        og, ogw, ogh, mm = f.occupancy_grid()
+        cells = [c for c in f.cells() if c["built"]]
+        vals = ctx.occupancy_values(capi.Grid(frame, frame, cs), ogcs, [c["index"] for c in cells],
+                                    [c["mean"] for c in cells], [c["icov"] for c in cells])
+        k = vals.shape[1]
+        W = H = int(np.ceil(frame / cs))
+        worst = 0
+        lo = [2 ** 32 - 1, 0, 2 ** 32 - 1, 0]
+        for c, v in zip(cells, vals):
+            cx, cy = c["index"] % W, c["index"] // H
+            for j in range(k):
+                for kk in range(k):
+                    if v[j, kk] >= 0:
+                        ox, oy = cx * k + j, cy * k + kk
+                        worst = max(worst, abs(int(og[ox + ogh * oy]) - int(v[j, kk])))
+                        lo = [min(lo[0], ox), max(lo[1], ox), min(lo[2], oy), max(lo[3], oy)]
+        assert worst <= 1                      # exp rounding can move 100*p across an integer
+        assert tuple(lo) == mm                 # the reference's min/max sub-cell indices
+        assert (vals > 0).sum() >= (og > 0).sum() - 2
+        seen += int((vals >= 0).sum())
+    assert seen > 100

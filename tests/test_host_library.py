@@ -91,3 +91,96 @@ def test_node_replay_matches_oracle(tmp_path, oracle):
     d32 = np.abs(got32 - want)
     print("node replay (fp32 score) max |dpose|", d32.max(axis=0))
     assert d32[:, :2].max() < 1e-3 and d32[:, 2].max() < 1e-3
+    # like the reference (ndtframe.cpp:257) align() runs 30 x 50 whatever PSO configuration the frame was given
+    out_cfg = subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs),
+                                       "7", "11", str(seed)], text=True, env=dict(os.environ, NDTPSO_SCORE="f64"))
+    assert out_cfg == out
+
+
+@pytest.mark.gpu
+def test_node_replay_map_export(tmp_path, oracle):
+    """SURVEY 8 f-4: the shutdown export of the node (ndtpso_slam_node.cpp:141-172 -> NDTFrame::dumpMap,
+    ndtframe.cpp:268-422) and the occupancy grid of the reference frame (ndtframe.cpp:79-112) after a replay."""
+    import struct
+    import zlib
+    from ndtpso_slam_amd import synth
+    _build()
+    n_scans, P, I, seed, cs, ogcs = 8, 20, 20, 3, 0.5, 0.1
+    ranges, _ = _trajectory(n_scans)
+    path = tmp_path / "scans.bin"
+    with open(path, "wb") as f:
+        np.array([n_scans, synth.N_BEAMS], dtype=np.int32).tofile(f)
+        np.array([synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX], dtype=np.float32).tofile(f)
+        ranges.tofile(f)
+    prefix = str(tmp_path / "run")
+    out = subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs), str(I),
+                                   str(P), str(seed), str(ogcs), prefix, "20"], text=True,
+                                  env=dict(os.environ, NDTPSO_SCORE="f64", NDTPSO_ALIGN_FRAME_CONFIG="1"))
+    got = np.array([[float(v) for v in line.split()[1:]] for line in out.strip().splitlines()])
+
+    # the same run on the oracle (a short 20 x 20 PSO: NDTPSO_ALIGN_FRAME_CONFIG lets align() use the frame's config)
+    cfg = oracle.PSOConfig.make(I, P)
+    n_draw = 3 + 3 * P + 6 * P * I
+    stream = oracle.glibc_rand(seed, n_draw * n_scans)
+    ref = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, cs)
+    ref.enable_occupancy_grid(ogcs)
+    cur = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, cs)
+    prev = np.zeros(3)
+    n_map_points = 0
+    for k in range(n_scans):
+        cur.load_laser(ranges[k], synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX)
+        pose = prev.copy() if k == 0 else ref.align(prev, cur, cfg, table=stream[(k - 1) * n_draw:k * n_draw])
+        prev = pose
+        ref.update(pose, cur)
+        # what a one-cell global map keeps of this scan: the points that fall strictly inside the frame
+        c, s = np.cos(pose[2]), np.sin(pose[2])
+        pts = cur.points()
+        gx, gy = pts[:, 0] * c - pts[:, 1] * s + pose[0], pts[:, 0] * s + pts[:, 1] * c + pose[1]
+        n_map_points += int(((np.abs(gx) < FRAME_M / 2) & (np.abs(gy) < FRAME_M / 2)).sum())
+        cur = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+    assert np.abs(got[-1] - prev).max() < 1e-6
+
+    # pose.csv / map.csv / gnuplot: the reference's text formats
+    lines = open(prefix + ".pose.csv").read().splitlines()
+    assert lines[0] == "timestamp,xP,yP,thP,xO,yO,thO" and len(lines) == 1 + n_scans
+    for k, row in enumerate(lines[1:]):
+        assert row == "%.6f,%.5f,%.5f,%.5f" % (0.025 * k, got[k, 0], got[k, 1], got[k, 2])
+    lines = open(prefix + ".map.csv").read().splitlines()
+    assert lines[0] == "x,y" and len(lines) == 1 + n_map_points
+    gp = open(prefix + ".gnuplot").read()
+    assert gp.startswith("set datafile separator ','\nset key autotitle columnhead\nset size ratio -1\nplot '")
+    assert gp.endswith("\npause 1000\n") and "using 2:3 title 'Pose (LiDAR)'" in gp
+    assert not os.path.exists(prefix + "-ref-frame.pose.csv")          # save_poses = false for the reference frame
+
+    # occupancy grid of the reference frame vs the oracle's
+    raw = open(prefix + "-ref-frame.og.bin", "rb").read()
+    w, h, x0, x1, y0, y1 = struct.unpack("6I", raw[:24])
+    og = np.frombuffer(raw[24:], dtype=np.int8)
+    want, ww, wh, mm = ref.occupancy_grid()
+    assert (w, h) == (ww, wh) and (x0, x1, y0, y1) == mm
+    diff = np.abs(og.astype(int) - want.astype(int))
+    print("occupancy grid: %d cells > 0, %d differ, max |d| %d" % ((want > 0).sum(), (diff > 0).sum(), diff.max()))
+    assert diff.max() <= 1 and (diff > 0).sum() <= 0.01 * max(1, (want != 0).sum())
+
+    # the two images are valid PNGs of the reference's sizes
+    def png(path):
+        b = open(path, "rb").read()
+        assert b[:8] == b"\x89PNG\r\n\x1a\n"
+        cols, rows, depth, ctype = struct.unpack(">IIBB", b[16:26])
+        pos, idat = 8, b""
+        while pos < len(b):
+            n, tag = struct.unpack(">I4s", b[pos:pos + 8])
+            assert zlib.crc32(b[pos + 4:pos + 8 + n]) == struct.unpack(">I", b[pos + 8 + n:pos + 12 + n])[0]
+            if tag == b"IDAT":
+                idat += b[pos + 8:pos + 8 + n]
+            pos += 12 + n
+        px = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(rows, -1)[:, 1:]
+        return rows, cols, ctype, px
+    rows, cols, ctype, px = png("%s-w100-30p50i-%dx%d-c%.2f-20ppm.png" % (prefix, FRAME_M, FRAME_M, float(FRAME_M)))
+    assert (rows, cols, ctype) == (FRAME_M * 20, FRAME_M * 20, 2) and (px == 0).any()
+    rows, cols, ctype, px = png("%s-ref-frame-%dx%d-cell%.2fm-occupancy-grid.png" % (prefix, w, h, ogcs))
+    assert (rows, cols, ctype) == (y1 - y0 + 1, x1 - x0 + 1, 0)
+    # pixel = 255 - 2.55 og, rows flipped, cropped to the extent
+    img = want.reshape(h, w)[y0:y1 + 1, x0:x1 + 1][::-1]      # og[x + height*y] with height == width here
+    expect = np.where(img > 0, (255.0 - img * 2.55).astype(np.uint8), 255)
+    assert (np.abs(px.astype(int) - expect.astype(int)) <= 3).all()
