@@ -169,6 +169,64 @@ int ndtpso_align(ndtpso_ctx *ctx, const double *xy, uint32_t n_points, const dou
                  const int32_t *rand_table, int score_mode, double out_pose[3], double *out_cost,
                  ndtpso_align_stats *stats);
 
+/* ---- device-resident reference frame ---------------
+ * The live node's path (ndtpso_slam_node.cpp:177-244) without the host touching a point: the map (NDTFrame with its
+ * 100-slot sliding-window cells, ndtcell.h:62-70) and the loaded scan stay in HBM; per scan the host sends the ranges
+ * and the std::rand() table and receives the pose.
+ *   ndtpso_points_*      the node's one-cell per-scan frame (ndtpso_slam_node.cpp:229-230): a point list on the device
+ *   ndtpso_map_insert    NDTFrame::update (ndtframe.cpp:187-198; pose != NULL) / loadLaser + addPoint into a multi-cell
+ *                        frame (:144-185, 215-235; pose == NULL): NDTCell::addPoint (ndtcell.cpp:21-34) per point
+ *   ndtpso_map_build     NDTFrame::build (:68-117): NDTCell::build (ndtcell.cpp:36-68) on every created cell, the
+ *                        occupancy grid (:79-112), and the alignment table of the built cells
+ *   ndtpso_map_align     NDTFrame::align's pso_optimization (core.cpp:50-116) against the map, building it first when
+ *                        points were inserted since the last build (cost_function's lazy build, core.cpp:27-28)
+ * insert and build only enqueue work; align and the get_* calls synchronise. */
+#define NDTPSO_WINDOW_SIZE 100        /* NDT_WINDOW_SIZE, config.h:8 */
+#define NDTPSO_MAX_POINTS_PER_CELL 50 /* NDT_MAX_POINTS_PER_CELL, config.h:5 */
+
+typedef struct ndtpso_points ndtpso_points;
+typedef struct ndtpso_map ndtpso_map;
+
+typedef struct {
+  uint32_t n_created, n_built; /* cells with points / cells in the alignment table (as of the last build) */
+  uint32_t status;             /* bit 0: point pool exhausted, bit 1: an occupancy write fell outside the grid */
+  uint32_t n_words;
+  int32_t x0, x1, y0, y1;      /* bounding box of the built cells, cell coordinates */
+  uint32_t og_min_x, og_max_x, og_min_y, og_max_y; /* s_occupancy_grid.{min,max}_{x,y}_ind (ndtframe.h:23-25) */
+  int32_t pool_bump, pool_free; /* 512-byte point chunks handed out / on the free stack */
+  uint64_t n_points;           /* points ever inserted */
+} ndtpso_map_info;
+
+int ndtpso_points_create(ndtpso_ctx *ctx, uint32_t capacity, ndtpso_points **out);
+void ndtpso_points_destroy(ndtpso_points *pts);
+/* loadLaser into a one-cell frame of `clip`'s size (NULL: unbounded); trans = the frame's s_trans (NULL = zero);
+ * append != 0 keeps the points already loaded (a second loadLaser into the same frame).  Asynchronous. */
+int ndtpso_points_load_scan(ndtpso_points *pts, const float *ranges, const ndtpso_scan_geom *geom, const double trans[3],
+                            const ndtpso_grid *clip, int append);
+int ndtpso_points_set(ndtpso_points *pts, const double *xy, uint32_t n);
+int ndtpso_points_get(ndtpso_points *pts, double *xy, uint32_t max_points, uint32_t *n_points);
+
+/* og_cell_size 0: no occupancy grid.  pool_bytes 0: 1 GiB of point storage (512 B per 32 points of one window slot). */
+int ndtpso_map_create(ndtpso_ctx *ctx, const ndtpso_grid *grid, double og_cell_size, uint64_t pool_bytes,
+                      ndtpso_map **out);
+void ndtpso_map_destroy(ndtpso_map *map);
+int ndtpso_map_reset(ndtpso_map *map); /* NDTFrame::resetCells (ndtframe.cpp:208-212) */
+int ndtpso_map_insert(ndtpso_map *map, const ndtpso_points *pts, const double pose[3]);
+int ndtpso_map_insert_host(ndtpso_map *map, const double *xy, uint32_t n, const double pose[3]);
+int ndtpso_map_build(ndtpso_map *map);
+int ndtpso_map_align(ndtpso_map *map, const ndtpso_points *new_points, const double guess[3], const double deviation[3],
+                     const ndtpso_pso_config *cfg, uint32_t seed, const int32_t *rand_table, int score_mode,
+                     double out_pose[3], double *out_cost, ndtpso_align_stats *stats);
+int ndtpso_map_get_info(ndtpso_map *map, ndtpso_map_info *info);
+/* created cells in ascending index order (row.reserved = the cell's current window slot) */
+int ndtpso_map_get_cells(ndtpso_map *map, ndtpso_cell_row *rows, uint32_t max_rows, uint32_t *n_rows);
+/* stored points in cell order, window-slot order, insertion order (dumpMap's order, ndtframe.cpp:314-328);
+ * slot0_only: the points cost_function visits when the frame is the NEW frame (core.cpp:33-36) */
+int ndtpso_map_get_points(ndtpso_map *map, int slot0_only, double *xy, uint64_t max_points, uint64_t *n_points);
+/* og[x + og_height * y] as the reference indexes it; extent = {min_x, max_x, min_y, max_y} */
+int ndtpso_map_get_occupancy(ndtpso_map *map, int8_t *og, uint64_t og_bytes, uint32_t *og_width, uint32_t *og_height,
+                             uint32_t extent[4]);
+
 /* ---- fused batched scan pairs (BASELINE configs 3/4) ------------------- */
 /* For pair b: reference frame <- ref scan loaded at identity and built; new frame <- new scan
  * (ndtpso_slam_node.cpp:186,229-230); pose_b = pso_optimization(guess_b, ref, new, deviation_b, cfg)

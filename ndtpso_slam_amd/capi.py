@@ -73,6 +73,13 @@ class PairsPlan(C.Structure):
                 ("window_h", C.c_uint32), ("table_bytes", C.c_uint32)]
 
 
+class MapInfo(C.Structure):
+    _fields_ = [("n_created", C.c_uint32), ("n_built", C.c_uint32), ("status", C.c_uint32), ("n_words", C.c_uint32),
+                ("x0", C.c_int32), ("x1", C.c_int32), ("y0", C.c_int32), ("y1", C.c_int32),
+                ("og_min_x", C.c_uint32), ("og_max_x", C.c_uint32), ("og_min_y", C.c_uint32), ("og_max_y", C.c_uint32),
+                ("pool_bump", C.c_int32), ("pool_free", C.c_int32), ("n_points", C.c_uint64)]
+
+
 STATS_DTYPE = np.dtype([("n_points", "<u4"), ("n_built", "<u4"), ("cost_evals", "<u4"), ("rounds", "<u4"),
                         ("gbest_updates", "<u4"), ("status", "<u4"), ("t_start", "<u4"), ("t_end", "<u4")])
 assert STATS_DTYPE.itemsize == C.sizeof(AlignStats)
@@ -83,6 +90,10 @@ EXPORTS = [
     "ndtpso_rand_draws", "ndtpso_scan_to_points", "ndtpso_ref_from_points", "ndtpso_ref_from_scan",
     "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_scan_to_cells", "ndtpso_cells_build_windowed", "ndtpso_occupancy_values", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
+    "ndtpso_points_create", "ndtpso_points_destroy", "ndtpso_points_load_scan", "ndtpso_points_set", "ndtpso_points_get",
+    "ndtpso_map_create", "ndtpso_map_destroy", "ndtpso_map_reset", "ndtpso_map_insert", "ndtpso_map_insert_host",
+    "ndtpso_map_build", "ndtpso_map_align", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
+    "ndtpso_map_get_occupancy",
 ]
 
 _lib = None
@@ -133,9 +144,29 @@ def load(build_if_missing: bool = True):
     L.ndtpso_align_pairs_describe.argtypes = [C.POINTER(ScanGeom), C.POINTER(Grid), C.POINTER(PSOConfig), C.c_int,
                                               C.c_uint32, C.POINTER(PairsPlan)]
     L.ndtpso_align_pairs_footprint.argtypes = [C.POINTER(ScanGeom), C.POINTER(Grid), C.POINTER(PSOConfig), up, up]
+    L.ndtpso_points_create.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
+    L.ndtpso_points_destroy.argtypes = [vp]
+    L.ndtpso_points_destroy.restype = None
+    L.ndtpso_points_load_scan.argtypes = [vp, fp, C.POINTER(ScanGeom), dp, C.POINTER(Grid), C.c_int]
+    L.ndtpso_points_set.argtypes = [vp, dp, C.c_uint32]
+    L.ndtpso_points_get.argtypes = [vp, dp, C.c_uint32, up]
+    L.ndtpso_map_create.argtypes = [vp, C.POINTER(Grid), C.c_double, C.c_uint64, C.POINTER(vp)]
+    L.ndtpso_map_destroy.argtypes = [vp]
+    L.ndtpso_map_destroy.restype = None
+    L.ndtpso_map_reset.argtypes = [vp]
+    L.ndtpso_map_insert.argtypes = [vp, vp, dp]
+    L.ndtpso_map_insert_host.argtypes = [vp, dp, C.c_uint32, dp]
+    L.ndtpso_map_build.argtypes = [vp]
+    L.ndtpso_map_align.argtypes = [vp, vp, dp, dp, C.POINTER(PSOConfig), C.c_uint32, ip, C.c_int, dp, dp,
+                                   C.POINTER(AlignStats)]
+    L.ndtpso_map_get_info.argtypes = [vp, C.POINTER(MapInfo)]
+    L.ndtpso_map_get_cells.argtypes = [vp, C.POINTER(CellRow), C.c_uint32, up]
+    L.ndtpso_map_get_points.argtypes = [vp, C.c_int, dp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.ndtpso_map_get_occupancy.argtypes = [vp, C.POINTER(C.c_int8), C.c_uint64, up, up, up]
     for name in EXPORTS:
         fn = getattr(L, name)
-        if name not in ("ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_rand_draws"):
+        if name not in ("ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_rand_draws", "ndtpso_points_destroy",
+                        "ndtpso_map_destroy"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -331,3 +362,126 @@ def align_pairs_describe(geom: ScanGeom, grid: Grid, cfg: PSOConfig, mode=SCORE_
     pl = PairsPlan()
     rc = L.ndtpso_align_pairs_describe(C.byref(geom), C.byref(grid), C.byref(cfg), mode, n_pairs, C.byref(pl))
     return rc, {k: getattr(pl, k) for k, _ in PairsPlan._fields_}
+
+
+class ResidentScan:
+    """ndtpso_points: a loaded scan that stays on the device (the node's one-cell per-scan frame)."""
+
+    def __init__(self, ctx: Context, capacity: int):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        h = C.c_void_p()
+        ctx._chk(self._lib.ndtpso_points_create(ctx._h, int(capacity), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self._ctx, "_h", None):   # a context that is already gone took the device with it
+                self._lib.ndtpso_points_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_scan(self, ranges, geom: ScanGeom, trans=None, clip: Grid | None = None, append=False):
+        r = np.ascontiguousarray(ranges, dtype=np.float32)
+        assert r.size == geom.n_beams
+        t = _p(_f64(trans, 3), C.c_double) if trans is not None else None
+        self._ctx._chk(self._lib.ndtpso_points_load_scan(self._h, _p(r, C.c_float), C.byref(geom), t,
+                                                         C.byref(clip) if clip is not None else None, int(bool(append))))
+
+    def set(self, xy):
+        xy = _f64(xy).reshape(-1, 2)
+        self._ctx._chk(self._lib.ndtpso_points_set(self._h, _p(xy, C.c_double), xy.shape[0]))
+
+    def get(self) -> np.ndarray:
+        n = C.c_uint32()
+        self._ctx._chk(self._lib.ndtpso_points_get(self._h, None, 0, C.byref(n)))
+        xy = np.empty((max(n.value, 1), 2))
+        self._ctx._chk(self._lib.ndtpso_points_get(self._h, _p(xy, C.c_double), n.value, C.byref(n)))
+        return xy[:n.value].copy()
+
+
+class ResidentMap:
+    """ndtpso_map: the reference frame with its sliding-window cells, resident in HBM."""
+
+    def __init__(self, ctx: Context, grid: Grid, og_cell_size=0.0, pool_bytes=0):
+        self._ctx = ctx
+        self._lib = ctx._lib
+        self.grid = grid
+        h = C.c_void_p()
+        ctx._chk(self._lib.ndtpso_map_create(ctx._h, C.byref(grid), float(og_cell_size), int(pool_bytes), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self._ctx, "_h", None):
+                self._lib.ndtpso_map_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        self._ctx._chk(self._lib.ndtpso_map_reset(self._h))
+
+    def insert(self, scan: ResidentScan, pose=None):
+        self._ctx._chk(self._lib.ndtpso_map_insert(self._h, scan._h,
+                                                   _p(_f64(pose, 3), C.c_double) if pose is not None else None))
+
+    def insert_host(self, xy, pose=None):
+        xy = _f64(xy).reshape(-1, 2)
+        self._ctx._chk(self._lib.ndtpso_map_insert_host(self._h, _p(xy, C.c_double), xy.shape[0],
+                                                        _p(_f64(pose, 3), C.c_double) if pose is not None else None))
+
+    def build(self):
+        self._ctx._chk(self._lib.ndtpso_map_build(self._h))
+
+    def align(self, scan: ResidentScan, guess, deviation, cfg: PSOConfig, seed=1, rand_table=None, mode=SCORE_F32):
+        pose = np.empty(3)
+        cost = C.c_double()
+        st = AlignStats()
+        tab = None
+        if rand_table is not None:
+            tab = np.ascontiguousarray(rand_table, dtype=np.int32)
+            assert tab.size >= self._lib.ndtpso_rand_draws(C.byref(cfg))
+        self._ctx._chk(self._lib.ndtpso_map_align(self._h, scan._h, _p(_f64(guess, 3), C.c_double),
+                                                  _p(_f64(deviation, 3), C.c_double), C.byref(cfg),
+                                                  C.c_uint32(int(seed)), _p(tab, C.c_int32) if tab is not None else None,
+                                                  mode, _p(pose, C.c_double), C.byref(cost), C.byref(st)))
+        return pose, cost.value, {k: getattr(st, k) for k, _ in AlignStats._fields_}
+
+    def info(self) -> dict:
+        i = MapInfo()
+        self._ctx._chk(self._lib.ndtpso_map_get_info(self._h, C.byref(i)))
+        return {k: getattr(i, k) for k, _ in MapInfo._fields_}
+
+    def cells(self):
+        n = C.c_uint32()
+        self._ctx._chk(self._lib.ndtpso_map_get_cells(self._h, None, 0, C.byref(n)))
+        rows = (CellRow * max(n.value, 1))()
+        self._ctx._chk(self._lib.ndtpso_map_get_cells(self._h, rows, n.value, C.byref(n)))
+        return [dict(index=r.index, count=r.count, built=bool(r.built), slot=r.reserved, mean=np.array(r.mean[:]),
+                     icov=np.array(r.icov[:])) for r in rows[:n.value]]
+
+    def points(self, slot0_only=False) -> np.ndarray:
+        n = C.c_uint64()
+        self._ctx._chk(self._lib.ndtpso_map_get_points(self._h, int(slot0_only), None, 0, C.byref(n)))
+        xy = np.empty((max(n.value, 1), 2))
+        self._ctx._chk(self._lib.ndtpso_map_get_points(self._h, int(slot0_only), _p(xy, C.c_double), n.value, C.byref(n)))
+        return xy[:n.value].copy()
+
+    def occupancy(self):
+        w, h = C.c_uint32(), C.c_uint32()
+        ext = (C.c_uint32 * 4)()
+        self._ctx._chk(self._lib.ndtpso_map_get_occupancy(self._h, None, 0, C.byref(w), C.byref(h), ext))
+        og = np.zeros(max(w.value * h.value, 1), dtype=np.int8)
+        self._ctx._chk(self._lib.ndtpso_map_get_occupancy(self._h, og.ctypes.data_as(C.POINTER(C.c_int8)), og.size,
+                                                          C.byref(w), C.byref(h), ext))
+        return og[:w.value * h.value], w.value, h.value, tuple(ext)

@@ -3,6 +3,7 @@
 #include "ndtpso_kernels.hpp"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -357,10 +358,12 @@ k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict_
 // ---- K2 --------------------------------------------------------------------------------------
 template <int MODE, int PATH>
 __global__ void __launch_bounds__(1024)
-k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n, GridP g, WinP wn, Layout L,
-        DenseP dn, PsoP ps, const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
+k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n,
+        const uint32_t* __restrict__ n_ptr, GridP g, WinP wn, Layout L, DenseP dn, PsoP ps,
+        const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
         const int32_t* __restrict__ table, unsigned char* __restrict__ ws, double* __restrict__ out_pose,
         double* __restrict__ out_cost, AlignStats* __restrict__ stats) {
+  if (n_ptr) n = min((int)*n_ptr, n);  // the point count lives on the device (resident scan); n is its capacity
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   stage_image<MODE, PATH>(image, g, wn, L, dn);
   copy16(pts, xy, n * 16);
@@ -1036,10 +1039,22 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
 
 // ---- K2 ------------------------------------------------------------------------------------------
 
-static int align_once(ndtpso_ctx* c, uint32_t n, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table, int mode,
-                      double host[4 + sizeof(AlignStats) / 8]) {
+// where one alignment's inputs live on the device: table image + its grid/window, new-frame points (count known
+// to the host, or only an upper bound with the count itself on the device)
+struct AlignSrc {
+  const unsigned char* image;
+  GridP g;
+  WinP wn;
+  const double2* xy;
+  uint32_t n;
+  const uint32_t* n_ptr;
+};
+
+static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
+                      int mode, double host[4 + sizeof(AlignStats) / 8]) {
   Plan plan;
-  if (!make_plan(mode, c->g, c->wn, std::max<int>((int)n, 1), cfg->population, &plan))
+  const uint32_t n = src.n;
+  if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan))
     return fail(c, NDTPSO_E_CAPACITY, "table + points + swarm do not fit in LDS");
   const Layout& L = plan.L;
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
@@ -1050,7 +1065,7 @@ static int align_once(ndtpso_ctx* c, uint32_t n, const ndtpso_pso_config* cfg, u
   const PsoP ps = make_pso(cfg, waves);
 #define LAUNCH_ALIGN(MODE, PATH)                                                                                   \
   hipLaunchKernelGGL((k_align<MODE, PATH>), dim3(1), dim3(waves * 64), L.total, c->stream,                         \
-                     (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, plan.dn,  \
+                     src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
                      ps, (const double*)c->small.p, (const double*)c->small.p + 3, seed,                           \
                      have_table ? (const int32_t*)c->table.p : nullptr, (unsigned char*)c->ws.p, d_out, d_out + 3, \
                      d_stats)
@@ -1065,6 +1080,9 @@ static int align_once(ndtpso_ctx* c, uint32_t n, const ndtpso_pso_config* cfg, u
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NDTPSO_OK;
 }
+
+static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
+                        int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats);
 
 int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess[3], const double deviation[3],
                  const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
@@ -1083,14 +1101,21 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   double gd[6] = {guess[0], guess[1], guess[2], deviation[0], deviation[1], deviation[2]};
   HIP_TRY(c, hipMemcpyAsync(c->small.p, gd, sizeof(gd), hipMemcpyHostToDevice, c->stream));
   if (rand_table) HIP_TRY(c, hipMemcpyAsync(c->table.p, rand_table, n_draw * 4, hipMemcpyHostToDevice, c->stream));
+  const AlignSrc src{(const unsigned char*)c->image.p, c->g, c->wn, (const double2*)c->xy2.p, n, nullptr};
+  return align_finish(c, src, cfg, seed, rand_table != nullptr, mode, out_pose, out_cost, stats);
+}
+
+// launch, fetch pose/cost/stats; an alignment the fp32 score flags (underflow regime, see ndtpso_kernels.hpp) is
+// redone with the fp64 score
+static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
+                        int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats) {
   double host[4 + sizeof(AlignStats) / 8];
-  int rc = align_once(c, n, cfg, seed, rand_table != nullptr, mode, host);
+  int rc = align_once(c, src, cfg, seed, have_table, mode, host);
   if (rc != NDTPSO_OK) return rc;
   AlignStats st;
   std::memcpy(&st, host + 4, sizeof(st));
   if (mode == NDTPSO_SCORE_F32 && (st.status & kStatusNeedsF64)) {
-    // fp32 underflow regime (see ndtpso_kernels.hpp): this alignment is redone with the fp64 score
-    rc = align_once(c, n, cfg, seed, rand_table != nullptr, NDTPSO_SCORE_F64, host);
+    rc = align_once(c, src, cfg, seed, have_table, NDTPSO_SCORE_F64, host);
     if (rc != NDTPSO_OK) return rc;
   }
   out_pose[0] = host[0];
@@ -1258,3 +1283,5 @@ int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges,
 }
 
 }  // extern "C"
+
+#include "ndtpso_map.inc"

@@ -405,6 +405,21 @@ unsigned orc_frame_get_points(const orc_frame *f, double *xy) {
   return n;
 }
 
+/* every stored point: cell order, window-slot order, insertion order (dumpMap's loops, ndtframe.cpp:314-316) */
+unsigned long orc_frame_get_points_all(const orc_frame *f, double *xy, unsigned long max_points) {
+  unsigned i, s, k;
+  unsigned long n = 0;
+  for (i = 0; i < f->num_cells; ++i)
+    if (f->cells[i])
+      for (s = 0; s < ORC_NDT_WINDOW_SIZE; ++s)
+        for (k = 0; k < f->cells[i]->points[s].n; ++k, ++n)
+          if (xy && n < max_points) {
+            xy[2 * n] = f->cells[i]->points[s].p[k].x;
+            xy[2 * n + 1] = f->cells[i]->points[s].p[k].y;
+          }
+  return n;
+}
+
 unsigned orc_frame_num_created(const orc_frame *f) {
   unsigned i, n = 0;
   for (i = 0; i < f->num_cells; ++i)
@@ -421,6 +436,8 @@ unsigned orc_frame_export_cells(const orc_frame *f, orc_cell_row *rows, unsigned
       rows[n].count = c->global_count;
       rows[n].built = c->built;
       rows[n].n_slot0 = (int32_t)c->points[0].n;
+      rows[n].window_id = (int32_t)c->current_window_id;
+      rows[n].current_count = (int32_t)c->current_count;
       rows[n].mean[0] = c->mean.x;
       rows[n].mean[1] = c->mean.y;
       memcpy(rows[n].icov, c->inv_covar, sizeof(rows[n].icov));

@@ -74,6 +74,8 @@ typedef struct {
   int32_t count;    /* s_global_count after build() */
   int32_t built;    /* NDTCell::built */
   int32_t n_slot0;  /* points_vector[0].size() */
+  int32_t window_id;     /* s_current_window_id */
+  int32_t current_count; /* s_current_count */
   double mean[2];   /* NDTCell::mean */
   double icov[4];   /* s_inv_covar, row-major (0,0),(0,1),(1,0),(1,1) */
 } orc_cell_row;
@@ -126,6 +128,7 @@ const int8_t *orc_frame_occupancy_grid(const orc_frame *f, uint32_t *og_width, u
 /* accessors used by the tests */
 unsigned orc_frame_num_points(const orc_frame *f);              /* sum of points_vector[0] sizes */
 unsigned orc_frame_get_points(const orc_frame *f, double *xy);   /* cells order then insertion order (core.cpp:33-36) */
+unsigned long orc_frame_get_points_all(const orc_frame *f, double *xy, unsigned long max_points); /* all window slots */
 unsigned orc_frame_num_created(const orc_frame *f);
 unsigned orc_frame_export_cells(const orc_frame *f, orc_cell_row *rows, unsigned max_rows);
 void orc_frame_dims(const orc_frame *f, int32_t *width_cells, int32_t *height_cells);

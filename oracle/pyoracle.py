@@ -44,6 +44,7 @@ class PSOStats(C.Structure):
 
 class CellRow(C.Structure):
     _fields_ = [("index", C.c_int32), ("count", C.c_int32), ("built", C.c_int32), ("n_slot0", C.c_int32),
+                ("window_id", C.c_int32), ("current_count", C.c_int32),
                 ("mean", C.c_double * 2), ("icov", C.c_double * 4)]
 
 
@@ -76,6 +77,8 @@ def lib():
     L.orc_frame_num_points.argtypes = [C.c_void_p]
     L.orc_frame_get_points.restype = C.c_uint
     L.orc_frame_get_points.argtypes = [C.c_void_p, dp]
+    L.orc_frame_get_points_all.restype = C.c_ulong
+    L.orc_frame_get_points_all.argtypes = [C.c_void_p, dp, C.c_ulong]
     L.orc_frame_num_created.restype = C.c_uint
     L.orc_frame_num_created.argtypes = [C.c_void_p]
     L.orc_frame_export_cells.restype = C.c_uint
@@ -165,6 +168,13 @@ class Frame:
             lib().orc_frame_get_points(self._h, _dp(xy))
         return xy
 
+    def points_all(self) -> np.ndarray:
+        """every stored point of every window slot, in dumpMap's order"""
+        n = lib().orc_frame_get_points_all(self._h, None, 0)
+        xy = np.empty((max(n, 1), 2), dtype=np.float64)
+        lib().orc_frame_get_points_all(self._h, _dp(xy), n)
+        return xy[:n]
+
     def cells(self):
         n = lib().orc_frame_num_created(self._h)
         rows = (CellRow * max(n, 1))()
@@ -172,7 +182,8 @@ class Frame:
         out = []
         for i in range(m):
             r = rows[i]
-            out.append(dict(index=r.index, count=r.count, built=bool(r.built), n_slot0=r.n_slot0,
+            out.append(dict(index=r.index, count=r.count, built=bool(r.built), n_slot0=r.n_slot0, slot=r.window_id,
+                            current_count=r.current_count,
                             mean=np.array(r.mean[:]), icov=np.array(r.icov[:])))
         return out
 

@@ -1,0 +1,155 @@
+"""the device-resident reference frame (ndtpso_map_*, ndtpso_points_*) against the oracle's
+NDTFrame -- the node's per-scan sequence loadLaser -> align -> update (ndtpso_slam_node.cpp:177-244) with the map,
+its sliding windows and the loaded scan never leaving the GPU."""
+import numpy as np
+import pytest
+
+from conftest import FRAME_M
+
+pytestmark = pytest.mark.gpu
+
+
+def _trajectory(n_scans, seed=4, step=0.6):
+    from ndtpso_slam_amd import synth
+    rng = np.random.default_rng(seed)
+    s = np.linspace(0.0, step, n_scans)
+    poses = np.stack([2.0 + 1.2 * s, -1.0 + 0.8 * np.sin(1.5 * s), 0.3 + 0.25 * s], axis=1)
+    clean = synth.raycast(poses)
+    return np.where(clean > 0, clean + rng.normal(0, 0.01, clean.shape), 0.0).astype(np.float32)
+
+
+def _geom():
+    from ndtpso_slam_amd import capi, synth
+    return capi.ScanGeom(synth.N_BEAMS, synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX, 0.1)
+
+
+def _compare_cells(got, want):
+    assert [c["index"] for c in got] == [c["index"] for c in want]
+    for g, w in zip(got, want):
+        assert g["count"] == w["count"] and g["built"] == w["built"] and g["slot"] == w["slot"], (g, w)
+        if w["built"]:
+            assert np.array_equal(g["mean"], w["mean"]) and np.array_equal(g["icov"], w["icov"]), (g, w)
+
+
+def test_resident_node_sequence_matches_oracle(ctx, oracle):
+    """24 scans, default 30 x 50 PSO, fp64 score: poses, every cell's window state that is observable (count, slot,
+    mean, inverse covariance), every stored point and the occupancy grid equal the oracle's, bit for bit."""
+    from ndtpso_slam_amd import capi, synth
+    n_scans, P, I, seed, cs, ogcs = 24, 30, 50, 11, 0.5, 0.1
+    ranges = _trajectory(n_scans)
+    geom, grid = _geom(), capi.Grid(FRAME_M, FRAME_M, cs)
+    cfg, ocfg = capi.PSOConfig.make(I, P), oracle.PSOConfig.make(I, P)
+    n_draw = 3 + 3 * P + 6 * P * I
+    stream = oracle.glibc_rand(seed, n_draw * n_scans)
+
+    rmap = capi.ResidentMap(ctx, grid, og_cell_size=ogcs, pool_bytes=64 << 20)
+    scan = capi.ResidentScan(ctx, synth.N_BEAMS)
+    ref = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, cs)
+    ref.enable_occupancy_grid(ogcs)
+    prev = np.zeros(3)
+    oprev = np.zeros(3)
+    dev = np.array([.1, .1, 3.1415e-3])
+    pose_hist = [np.zeros(3)]
+    for k in range(n_scans):
+        scan.load_scan(ranges[k], geom, clip=grid)
+        ocur = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+        ocur.load_laser(ranges[k], synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX)
+        got_pts = scan.get()
+        assert got_pts.shape == ocur.points().shape and np.abs(got_pts - ocur.points()).max() < 5e-14
+        # device sincos and glibc's differ in the last ulp of a few points (tests/test_gpu_parity.py pins that);
+        # from here on the oracle runs on the device's points so that everything downstream can be compared exactly
+        cur = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+        for q in got_pts:
+            cur.add_point(q[0], q[1])
+        if k == 0:
+            pose, opose = prev.copy(), oprev.copy()
+        else:
+            table = stream[(k - 1) * n_draw:k * n_draw]
+            # NDTFrame::align's deviation rule (ndtframe.cpp:253), same numbers on both sides
+            d = dev if k - 1 < 2 else np.abs(2. * (pose_hist[-1] - pose_hist[-2]))
+            pose, _, st = rmap.align(scan, prev, d, cfg, rand_table=table, mode=capi.SCORE_F64)
+            opose, _, _ = ref.pso(oprev, cur, d, ocfg, table=table)
+            assert st["n_points"] == len(cur.points())
+            assert np.array_equal(pose, opose), (k, pose, opose)
+            pose_hist.append(pose.copy())
+        prev, oprev = pose, opose
+        rmap.insert(scan, pose)
+        ref.update(opose, cur)
+    # the last update has not been built yet on either side (lazy build, core.cpp:27-28)
+    assert np.array_equal(rmap.points(), ref.points_all())
+    rmap.build()
+    ref.build()
+    _compare_cells(rmap.cells(), ref.cells())
+    assert max(c["slot"] for c in ref.cells()) >= 1            # the window rotated somewhere
+    assert np.array_equal(rmap.points(), ref.points_all())
+    og, w, h, ext = rmap.occupancy()
+    want, ww, wh, mm = ref.occupancy_grid()
+    assert (w, h, ext) == (ww, wh, mm)
+    d = np.abs(og.astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d > 0).sum() <= 0.01 * max(1, (want != 0).sum())
+    info = rmap.info()
+    assert info["status"] == 0 and info["n_created"] == len(ref.cells())
+    assert info["n_points"] == len(ref.points_all())            # nothing rotated out of a 100-slot window yet
+
+
+def test_resident_map_window_wraps_and_pool_recycles(ctx, oracle):
+    """A small map hammered with the same scan: cells rotate through all 100 window slots and start overwriting
+    them (NDTCell::addPoint's slot reset, ndtcell.cpp:22-27), chunks return to the pool and are handed out again."""
+    from ndtpso_slam_amd import capi, synth
+    rng = np.random.default_rng(5)
+    cs = 2.0
+    grid = capi.Grid(4, 4, cs)
+    rmap = capi.ResidentMap(ctx, grid, pool_bytes=8 << 20)
+    ref = oracle.Frame((0, 0, 0), 4, 4, cs)
+    for it in range(260):
+        n = int(rng.integers(1, 500)) if it % 11 else int(rng.integers(1025, 2300))   # some inserts span several tiles
+        xy = rng.uniform(-2.3, 2.3, size=(n, 2))
+        xy[::7] = np.round(xy[::7])                      # points on cell edges and frame borders
+        pose = (rng.uniform(-.2, .2), rng.uniform(-.2, .2), rng.uniform(-.1, .1)) if it % 3 else None
+        rmap.insert_host(xy, pose)
+        if pose is None:
+            for p in xy:
+                ref.add_point(p[0], p[1])
+        else:
+            c, s = np.cos(pose[2]), np.sin(pose[2])
+            for p in xy:
+                ref.add_point(p[0] * c - p[1] * s + pose[0], p[0] * s + p[1] * c + pose[1])
+        if it % 5:
+            rmap.build()
+            ref.build()
+        if it % 37 == 0:
+            _compare_cells(rmap.cells(), ref.cells())
+    rmap.build()
+    ref.build()
+    _compare_cells(rmap.cells(), ref.cells())
+    assert np.array_equal(rmap.points(), ref.points_all())
+    info = rmap.info()
+    assert info["status"] == 0
+    # slots were overwritten on the second lap of the window and their chunks handed out again
+    assert len(ref.points_all()) < info["n_points"] and info["pool_bump"] * 32 < info["n_points"]
+    assert info["pool_free"] >= 0
+    rmap.reset()
+    assert rmap.info()["n_created"] == 0 and len(rmap.points()) == 0
+
+
+def test_resident_scan_append_and_errors(ctx, oracle):
+    from ndtpso_slam_amd import capi, synth
+    ranges = _trajectory(2)
+    geom, grid = _geom(), capi.Grid(FRAME_M, FRAME_M, 0.5)
+    scan = capi.ResidentScan(ctx, 2 * synth.N_BEAMS)
+    scan.load_scan(ranges[0], geom, clip=grid)
+    scan.load_scan(ranges[1], geom, trans=(0.3, -0.2, 0.05), clip=grid, append=True)
+    a = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+    a.load_laser(ranges[0], synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX)
+    a.set_trans((0.3, -0.2, 0.05))
+    a.load_laser(ranges[1], synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX)
+    assert scan.get().shape == a.points().shape and np.abs(scan.get() - a.points()).max() < 5e-14
+    with pytest.raises(capi.NdtpsoError) as e:
+        scan.load_scan(ranges[0], geom, append=True)        # third scan does not fit
+    assert e.value.code == capi.E_CAPACITY
+    # a pool that is too small is reported, not silently truncated
+    tiny = capi.ResidentMap(ctx, grid, pool_bytes=64 * 512)
+    tiny.insert(scan, (0, 0, 0))
+    with pytest.raises(capi.NdtpsoError) as e:
+        tiny.info()
+    assert e.value.code == capi.E_CAPACITY
