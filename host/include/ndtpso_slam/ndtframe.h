@@ -18,6 +18,9 @@
 using namespace Eigen;
 using std::vector;
 
+struct ndtpso_points;  // device-resident scan (include/ndtpso_hip.h)
+struct ndtpso_map;     // device-resident map
+
 // Creates the process-wide device context now instead of at the first frame operation (optional).  Call it
 // before srand() when the std::rand() stream must be reproducible: runtime start-up may itself call rand().
 extern "C" void ndtpso_slam_device_init(void);
@@ -37,6 +40,10 @@ class NDTFrame {
            double occupancy_grid_cell_size = .0
 #endif
   );
+
+  ~NDTFrame();
+  NDTFrame(const NDTFrame&) = delete;  // a frame owns device state (the reference's frames are never copied either)
+  NDTFrame& operator=(const NDTFrame&) = delete;
 
   void loadLaser(const vector<float>& laser_data, const float& min_angle, const float& angle_increment,
                  const float& max_range);
@@ -61,6 +68,11 @@ class NDTFrame {
   // new-frame points in the order cost_function visits them (cells, then insertion; core.cpp:33-36)
   void collectPoints(std::vector<double>& xy) const;
   const NDTPSOConfig& config() const { return s_config; }
+  // Resident mode (default; NDTPSO_RESIDENT=0 turns it off): the points, the sliding windows, the occupancy grid and
+  // the alignment table of this frame live on the GPU and `cells` is not maintained while the frame is used.
+  // syncHostView() refreshes created / built / mean of every cell from the device.
+  bool resident() const { return s_resident; }
+  void syncHostView();
 #if BUILD_OCCUPANCY_GRID
   // the occupancy grid as the reference stores it (og[x + height * y]) and its extent {min_x, max_x, min_y, max_y}
   const vector<int8_t>& occupancyGrid(uint32_t* og_width = nullptr, uint32_t* og_height = nullptr,
@@ -78,17 +90,26 @@ class NDTFrame {
   NDTPSOConfig s_config;
   int s_iter{0};
 #if BUILD_OCCUPANCY_GRID
-  struct {  // reference: s_occupancy_grid, ndtframe.h:22-29
+  mutable struct {  // reference: s_occupancy_grid, ndtframe.h:22-29
     uint32_t count{0}, width{0}, height{0}, max_x_ind{0}, max_y_ind{0}, min_x_ind{UINT32_MAX}, min_y_ind{UINT32_MAX};
     double cell_size{0.};
     vector<int8_t> og;
   } s_occupancy_grid;
   void rasteriseOccupancy();
+  void fetchOccupancy() const;  // resident mode: device -> s_occupancy_grid
 #endif
   std::vector<uint32_t> s_created;  // indices of created cells, in creation order
   bool s_table_dirty{true};         // the device reference table must be re-uploaded before the next align
   void append(const double* xy, const int32_t* idx, uint32_t n);
   void uploadTable();
+  // resident mode
+  bool s_resident{false};
+  ndtpso_points* d_scan_{nullptr};  // a one-cell frame that only ever had scans loaded: its point list
+  ndtpso_map* d_map_{nullptr};      // everything else
+  uint32_t d_scan_upper_{0};        // upper bound of the points in d_scan_
+  uint32_t d_scan_cap_{0};
+  ndtpso_map* ensureMap();
+  void residentPoints(bool slot0_only, std::vector<double>& xy) const;
 };
 
 #endif

@@ -4,12 +4,17 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 namespace ndtpso_host {
 
 namespace {
 ndtpso_ctx* g_ctx = nullptr;
 std::once_flag g_once;
+bool g_alive = false;
+std::vector<std::pair<ndtpso_points*, uint32_t>> g_scan_pool;
+std::mutex g_pool_mutex;
 }  // namespace
 
 ndtpso_ctx* device() {
@@ -22,7 +27,11 @@ ndtpso_ctx* device() {
                    dev, rc);
       std::abort();
     }
+    g_alive = true;
     std::atexit([] {
+      g_alive = false;
+      for (auto& e : g_scan_pool) ndtpso_points_destroy(e.first);
+      g_scan_pool.clear();
       if (g_ctx) ndtpso_ctx_destroy(g_ctx);
       g_ctx = nullptr;
     });
@@ -33,6 +42,39 @@ ndtpso_ctx* device() {
 const void*& table_owner() {
   static const void* owner = nullptr;
   return owner;
+}
+
+bool alive() { return g_alive; }
+
+bool resident_default() {
+  const char* e = std::getenv("NDTPSO_RESIDENT");
+  return !(e && e[0] == '0');
+}
+
+ndtpso_points* acquire_scan(uint32_t capacity) {
+  ndtpso_ctx* c = device();
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    for (size_t i = 0; i < g_scan_pool.size(); ++i)
+      if (g_scan_pool[i].second >= capacity) {
+        ndtpso_points* p = g_scan_pool[i].first;
+        g_scan_pool.erase(g_scan_pool.begin() + (long)i);
+        return p;
+      }
+  }
+  ndtpso_points* p = nullptr;
+  check(ndtpso_points_create(c, capacity, &p), "scan buffer");
+  return p;
+}
+
+void release_scan(ndtpso_points* p, uint32_t capacity) {
+  if (!p) return;
+  if (!g_alive) return;  // the context is gone, and the device memory with it
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (g_scan_pool.size() < 8)
+    g_scan_pool.emplace_back(p, capacity);
+  else
+    ndtpso_points_destroy(p);
 }
 
 int score_mode() {

@@ -10,6 +10,11 @@ ndtpso_ctx* device();                 // lazily created on HIP device $NDTPSO_DE
 int score_mode();                     // $NDTPSO_SCORE = f32 (default) | f64
 void check(int rc, const char* what); // abort with the C-ABI error text unless rc == NDTPSO_OK
 const void*& table_owner();           // which frame's cell table currently sits in the device context
+bool resident_default();              // $NDTPSO_RESIDENT != 0
+bool alive();                         // false once the process-wide context has been torn down (atexit)
+// device scan buffers are recycled: the node allocates a fresh per-scan frame for every scan (ndtpso_slam_node.cpp:228-230)
+ndtpso_points* acquire_scan(uint32_t capacity);
+void release_scan(ndtpso_points* p, uint32_t capacity);
 }  // namespace ndtpso_host
 
 #endif

@@ -26,6 +26,15 @@ ndtpso_pso_config to_abi(const PSOConfig& c) {
   o.w_damping = c.coeff.w_dumping;
   return o;
 }
+constexpr uint32_t kScanCapacity = 4096;  // points of a pooled device scan buffer (grown for longer scans)
+
+uint64_t map_pool_bytes(unsigned num_cells) {
+  // 512 B per 32 points of one window slot.  A one-cell frame that is only ever updated (the node's global_map_,
+  // ndtpso_slam_node.cpp:70-72,200-203) is never built, so it never rotates and keeps every point it was given.
+  const char* e = std::getenv(num_cells == 1 ? "NDTPSO_GLOBAL_MAP_POOL_MB" : "NDTPSO_MAP_POOL_MB");
+  const uint64_t mb = e ? (uint64_t)std::strtoull(e, nullptr, 10) : (num_cells == 1 ? 4096u : 1024u);
+  return (mb ? mb : 1u) << 20;
+}
 }  // namespace
 
 // reference: constructor, ndtframe.cpp:19-66.  Cells are light (see ndtcell.h), so the dense vector is kept.
@@ -46,6 +55,7 @@ NDTFrame::NDTFrame(Vector3d trans, unsigned short width_, unsigned short height_
   s_x_max = width / 2.;
   s_y_min = -height / 2.;
   s_y_max = height / 2.;
+  s_resident = ndtpso_host::resident_default();
 #if BUILD_OCCUPANCY_GRID
   s_occupancy_grid.cell_size = occupancy_grid_cell_size;  // ndtframe.cpp:32-46; 0 = no grid (intermediate frames)
   if (occupancy_grid_cell_size > 0.) {
@@ -55,6 +65,72 @@ NDTFrame::NDTFrame(Vector3d trans, unsigned short width_, unsigned short height_
     s_occupancy_grid.og = vector<int8_t>(s_occupancy_grid.count, 0);
   }
 #endif
+}
+
+NDTFrame::~NDTFrame() {
+  if (d_scan_) ndtpso_host::release_scan(d_scan_, d_scan_cap_);
+  if (d_map_ && ndtpso_host::alive()) ndtpso_map_destroy(d_map_);
+}
+
+// ---- resident mode: the frame's state lives on the device (include/ndtpso_hip.h, ndtpso_map_* / ndtpso_points_*) ----
+
+// A one-cell frame that only had scans loaded is just a point list (d_scan_).  Anything else -- several cells, or an
+// update / addPoint / build on it -- is a map; a point list already loaded becomes the open slot of cell 0.
+ndtpso_map* NDTFrame::ensureMap() {
+  if (!d_map_) {
+    const ndtpso_grid grid = grid_of(*this);
+    double og_cell_size = 0.;
+#if BUILD_OCCUPANCY_GRID
+    og_cell_size = s_occupancy_grid.cell_size;
+#endif
+    ndtpso_host::check(ndtpso_map_create(ndtpso_host::device(), &grid, og_cell_size, map_pool_bytes(numOfCells), &d_map_),
+                       "device map");
+    if (d_scan_) {
+      ndtpso_host::check(ndtpso_map_insert(d_map_, d_scan_, nullptr), "device map");
+      ndtpso_host::release_scan(d_scan_, d_scan_cap_);
+      d_scan_ = nullptr;
+      d_scan_upper_ = 0;
+    }
+  }
+  return d_map_;
+}
+
+void NDTFrame::residentPoints(bool slot0_only, std::vector<double>& xy) const {
+  xy.clear();
+  if (d_map_) {
+    uint64_t n = 0;
+    ndtpso_host::check(ndtpso_map_get_points(d_map_, slot0_only ? 1 : 0, nullptr, 0, &n), "map points");
+    xy.resize(2 * (size_t)n);
+    if (n) ndtpso_host::check(ndtpso_map_get_points(d_map_, slot0_only ? 1 : 0, xy.data(), n, &n), "map points");
+  } else if (d_scan_) {
+    uint32_t n = 0;
+    xy.resize(2 * (size_t)d_scan_upper_);
+    ndtpso_host::check(ndtpso_points_get(d_scan_, xy.data(), d_scan_upper_, &n), "scan points");
+    xy.resize(2 * (size_t)n);
+  }
+}
+
+void NDTFrame::syncHostView() {
+  if (!s_resident) return;
+  if (!d_map_) {
+    if (d_scan_) {  // a one-cell frame holding loaded scans: its only cell exists as soon as one point survived
+      uint32_t n = 0;
+      ndtpso_host::check(ndtpso_points_get(d_scan_, nullptr, 0, &n), "scan points");
+      cells[0].created = cells[0].created || n > 0;
+    }
+    return;
+  }
+  uint32_t n = 0;
+  ndtpso_host::check(ndtpso_map_get_cells(d_map_, nullptr, 0, &n), "map cells");
+  std::vector<ndtpso_cell_row> rows(n ? n : 1);
+  ndtpso_host::check(ndtpso_map_get_cells(d_map_, rows.data(), n, &n), "map cells");
+  for (NDTCell& c : cells) c.created = c.built = false;
+  for (uint32_t k = 0; k < n; ++k) {
+    NDTCell& c = cells[(size_t)rows[k].index];
+    c.created = true;
+    c.built = rows[k].built != 0;
+    c.mean = Vector2d(rows[k].mean[0], rows[k].mean[1]);
+  }
 }
 
 // points + their cells (as binned on the device) -> per-cell open slots; NDTFrame::addPoint's effect, ndtframe.cpp:215-235
@@ -78,6 +154,28 @@ void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle
   ndtpso_ctx* dev = ndtpso_host::device();
   ndtpso_scan_geom geom{n, min_angle, angle_increment, max_range, s_config.laserIgnoreEpsilon};
   const double t[3] = {s_trans.x(), s_trans.y(), s_trans.z()};
+  if (s_resident) {
+    const ndtpso_grid frame = grid_of(*this);
+    if (numOfCells == 1 && !d_map_) {  // the node's per-scan frame: the scan stays a point list on the device
+      if (!d_scan_) {
+        d_scan_cap_ = std::max(kScanCapacity, n);
+        d_scan_ = ndtpso_host::acquire_scan(d_scan_cap_);
+        d_scan_upper_ = 0;
+      }
+      if (d_scan_upper_ + n <= d_scan_cap_) {
+        ndtpso_host::check(ndtpso_points_load_scan(d_scan_, laser_data.data(), &geom, t, &frame, d_scan_upper_ > 0), "loadLaser");
+        d_scan_upper_ += n;
+        return;
+      }
+    }
+    ndtpso_map* m = ensureMap();
+    const uint32_t cap = std::max(kScanCapacity, n);
+    ndtpso_points* tmp = ndtpso_host::acquire_scan(cap);
+    ndtpso_host::check(ndtpso_points_load_scan(tmp, laser_data.data(), &geom, t, nullptr, 0), "loadLaser");
+    ndtpso_host::check(ndtpso_map_insert(m, tmp, nullptr), "loadLaser");
+    ndtpso_host::release_scan(tmp, cap);  // stream order keeps the buffer intact until the insert has read it
+    return;
+  }
   std::vector<double> xy(2 * (size_t)n);
   std::vector<int32_t> idx(n);
   uint32_t kept = 0;
@@ -88,6 +186,10 @@ void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle
 
 void NDTFrame::collectPoints(std::vector<double>& xy) const {
   xy.clear();
+  if (s_resident) {
+    residentPoints(true, xy);
+    return;
+  }
   if (numOfCells == 1) {  // the node's per-scan frame (ndtpso_slam_node.cpp:229-230)
     for (const Vector2d& p : cells[0].points_vector[0]) {
       xy.push_back(p.x());
@@ -107,6 +209,18 @@ void NDTFrame::collectPoints(std::vector<double>& xy) const {
 // reference: update, ndtframe.cpp:187-198 (transform every slot-0 point of new_frame by `trans`, re-bin here)
 void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
   built = false;
+  if (s_resident) {
+    const double pose[3] = {trans.x(), trans.y(), trans.z()};
+    ndtpso_map* m = ensureMap();
+    if (new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {  // device to device, nothing to wait for
+      ndtpso_host::check(ndtpso_map_insert(m, new_frame->d_scan_, pose), "update");
+    } else {
+      std::vector<double> pts;
+      new_frame->collectPoints(pts);
+      ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), pose), "update");
+    }
+    return;
+  }
   std::vector<double> xy;
   new_frame->collectPoints(xy);
   const uint32_t n = (uint32_t)(xy.size() / 2);
@@ -128,6 +242,12 @@ int NDTFrame::getCellIndex(Vector2d point, int grid_width, double cell_side_) {
 
 // reference: addPoint, ndtframe.cpp:215-235
 void NDTFrame::addPoint(Vector2d& point) {
+  if (s_resident) {
+    const double p[2] = {point.x(), point.y()};
+    ndtpso_host::check(ndtpso_map_insert_host(ensureMap(), p, 1, nullptr), "addPoint");
+    built = false;
+    return;
+  }
   const int32_t idx = getCellIndex(point, widthNumOfCells, cell_side);
   const double xy[2] = {point.x(), point.y()};
   append(xy, &idx, 1);
@@ -135,6 +255,11 @@ void NDTFrame::addPoint(Vector2d& point) {
 
 // reference: build, ndtframe.cpp:68-117 -- NDTCell::build for every created cell, batched into one device call
 void NDTFrame::build() {
+  if (s_resident) {
+    ndtpso_host::check(ndtpso_map_build(ensureMap()), "build");
+    built = true;
+    return;
+  }
   const uint32_t n = (uint32_t)s_created.size();
   if (n) {
     std::vector<ndtpso_cell_window> cw(n);
@@ -239,7 +364,16 @@ void NDTFrame::rasteriseOccupancy() {
   }
 }
 
+void NDTFrame::fetchOccupancy() const {
+  auto& g = s_occupancy_grid;
+  if (!s_resident || !d_map_ || !(g.cell_size > 0.)) return;
+  uint32_t ext[4] = {UINT32_MAX, 0, UINT32_MAX, 0};
+  ndtpso_host::check(ndtpso_map_get_occupancy(d_map_, g.og.data(), g.og.size(), nullptr, nullptr, ext), "occupancy grid");
+  g.min_x_ind = ext[0], g.max_x_ind = ext[1], g.min_y_ind = ext[2], g.max_y_ind = ext[3];
+}
+
 const vector<int8_t>& NDTFrame::occupancyGrid(uint32_t* og_width, uint32_t* og_height, uint32_t extent[4]) const {
+  fetchOccupancy();
   if (og_width) *og_width = s_occupancy_grid.width;
   if (og_height) *og_height = s_occupancy_grid.height;
   if (extent) {
@@ -274,6 +408,36 @@ void NDTFrame::uploadTable() {
 // quantity the reference consumes it (3 + 3P + 6PI), so srand() by the caller has the reference's meaning.
 Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, const Vector3d& deviation,
                             const PSOConfig& cfg) {
+  if (s_resident) {
+    ndtpso_map* m = ensureMap();
+    // cost_function's lazy build (core.cpp:27-28), enqueued now so that the device works through the pending insert
+    // and the build while the host draws the random numbers below
+    if (!built) build();
+    const ndtpso_points* pts = nullptr;
+    ndtpso_points* tmp = nullptr;
+    uint32_t tmp_cap = 0;
+    if (new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {
+      pts = new_frame->d_scan_;
+    } else {
+      std::vector<double> xy;
+      new_frame->collectPoints(xy);
+      tmp_cap = std::max(kScanCapacity, (uint32_t)(xy.size() / 2));
+      tmp = ndtpso_host::acquire_scan(tmp_cap);
+      ndtpso_host::check(ndtpso_points_set(tmp, xy.data(), (uint32_t)(xy.size() / 2)), "align");
+      pts = tmp;
+    }
+    const ndtpso_pso_config abi = to_abi(cfg);
+    std::vector<int32_t> draws(ndtpso_rand_draws(&abi));
+    for (int32_t& d : draws) d = std::rand();
+    const double g[3] = {guess.x(), guess.y(), guess.z()};
+    const double dv[3] = {deviation.x(), deviation.y(), deviation.z()};
+    double pose[3] = {0., 0., 0.};
+    ndtpso_host::check(ndtpso_map_align(m, pts, g, dv, &abi, 0u, draws.data(), ndtpso_host::score_mode(), pose, nullptr,
+                                        nullptr), "align");
+    built = true;
+    if (tmp) ndtpso_host::release_scan(tmp, tmp_cap);
+    return Vector3d(pose[0], pose[1], pose[2]);
+  }
   if (!built) build();  // core.cpp:27-28 (lazy build inside cost_function)
   uploadTable();
   std::vector<double> xy;
@@ -291,7 +455,26 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
 
 double NDTFrame::cost(const Vector3d& trans, const NDTFrame* new_frame) {
   if (!built) build();
-  uploadTable();
+  if (s_resident) {  // single evaluations are not on the node's path: the built cells go through the staged table
+    uint32_t n = 0;
+    ndtpso_host::check(ndtpso_map_get_cells(d_map_, nullptr, 0, &n), "map cells");
+    std::vector<ndtpso_cell_row> rows(n ? n : 1);
+    ndtpso_host::check(ndtpso_map_get_cells(d_map_, rows.data(), n, &n), "map cells");
+    std::vector<int32_t> index;
+    std::vector<double> mean, icov;
+    for (uint32_t k = 0; k < n; ++k) {
+      if (!rows[k].built) continue;
+      index.push_back(rows[k].index);
+      mean.insert(mean.end(), rows[k].mean, rows[k].mean + 2);
+      icov.insert(icov.end(), rows[k].icov, rows[k].icov + 4);
+    }
+    const ndtpso_grid grid = grid_of(*this);
+    ndtpso_host::check(ndtpso_ref_set_cells(ndtpso_host::device(), &grid, (uint32_t)index.size(), index.data(),
+                                            mean.data(), icov.data()), "reference table upload");
+    ndtpso_host::table_owner() = nullptr;
+  } else {
+    uploadTable();
+  }
   std::vector<double> xy;
   new_frame->collectPoints(xy);
   const double pose[3] = {trans.x(), trans.y(), trans.z()};
@@ -330,18 +513,36 @@ void NDTFrame::addPose(double timestamp, const Vector3d& pose, const Vector3d& o
 
 void NDTFrame::resetCells() {
   for (NDTCell& c : cells) c.reset();
+  if (d_map_) ndtpso_host::check(ndtpso_map_reset(d_map_), "resetCells");
+  if (d_scan_) {
+    ndtpso_host::release_scan(d_scan_, d_scan_cap_);
+    d_scan_ = nullptr;
+    d_scan_upper_ = 0;
+  }
 }
 
 // reference: transform, ndtframe.cpp:119-140 (never called by the node; re-bins every stored point)
 void NDTFrame::transform(Vector3d trans) {
   if (trans.isZero(1e-6)) return;
+  if (s_resident) {
+    std::vector<double> pts;
+    residentPoints(false, pts);
+    ndtpso_map* m = ensureMap();
+    ndtpso_host::check(ndtpso_map_clear(m), "transform");  // fresh cells (ndtframe.cpp:123)
+    const double t[3] = {trans.x(), trans.y(), trans.z()};
+    ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), t), "transform");
+    built = false;
+    return;
+  }
   std::vector<double> xy;
-  for (uint32_t i : s_created)
-    for (auto& slot : cells[i].win_->points)
+  for (const NDTCell& c : cells) {  // cell order, slot order, insertion order (the loops of ndtframe.cpp:126-134)
+    if (!c.win_) continue;
+    for (auto& slot : c.win_->points)
       for (const Vector2d& p : slot) {
         xy.push_back(p.x());
         xy.push_back(p.y());
       }
+  }
   for (uint32_t i : s_created) cells[i] = NDTCell();
   s_created.clear();
   const uint32_t n = (uint32_t)(xy.size() / 2);
@@ -393,15 +594,21 @@ void NDTFrame::dumpMap(const char* filename, bool save_poses, bool save_points, 
     }
 
   // every stored point, in cell order then window-slot order then insertion order (ndtframe.cpp:314-328)
-  for (const NDTCell& c : cells) {
-    if (!c.win_) continue;
-    for (const auto& slot : c.win_->points)
-      for (const Vector2d& p : slot) {
-        if (save_image)
-          img.circle(size_x / 2 + static_cast<int>(p.x() * density), size_y / 2 - static_cast<int>(p.y() * density), 1,
-                     Rgb{0, 0, 0});
-        if (save_points) std::fprintf(points, "%.5f,%.5f\n", p.x(), p.y());
-      }
+  auto emit = [&](double x, double y) {
+    if (save_image)
+      img.circle(size_x / 2 + static_cast<int>(x * density), size_y / 2 - static_cast<int>(y * density), 1, Rgb{0, 0, 0});
+    if (save_points) std::fprintf(points, "%.5f,%.5f\n", x, y);
+  };
+  if (s_resident) {
+    std::vector<double> pts;
+    residentPoints(false, pts);
+    for (size_t i = 0; i + 1 < pts.size(); i += 2) emit(pts[i], pts[i + 1]);
+  } else {
+    for (const NDTCell& c : cells) {
+      if (!c.win_) continue;
+      for (const auto& slot : c.win_->points)
+        for (const Vector2d& p : slot) emit(p.x(), p.y());
+    }
   }
 
   int counter = 0;
@@ -446,6 +653,7 @@ void NDTFrame::dumpMap(const char* filename, bool save_poses, bool save_points, 
   }
 
 #if BUILD_OCCUPANCY_GRID
+  fetchOccupancy();
   const auto& g = s_occupancy_grid;
   if (save_occupancy_grid && g.cell_size > 0. && g.min_x_ind <= g.max_x_ind && g.min_y_ind <= g.max_y_ind) {
     // ndtframe.cpp:401-420.  The reference sizes the image (max - min) and then addresses row (max - min) and

@@ -210,7 +210,10 @@ int ndtpso_points_get(ndtpso_points *pts, double *xy, uint32_t max_points, uint3
 int ndtpso_map_create(ndtpso_ctx *ctx, const ndtpso_grid *grid, double og_cell_size, uint64_t pool_bytes,
                       ndtpso_map **out);
 void ndtpso_map_destroy(ndtpso_map *map);
-int ndtpso_map_reset(ndtpso_map *map); /* NDTFrame::resetCells (ndtframe.cpp:208-212) */
+/* NDTFrame::resetCells (ndtframe.cpp:208-212): NDTCell::reset (ndtcell.cpp:80-91) on every created cell -- sums, counts
+ * and point vectors are cleared, the window's partial terms and created / built / mean / inverse covariance are kept */
+int ndtpso_map_reset(ndtpso_map *map);
+int ndtpso_map_clear(ndtpso_map *map); /* back to a freshly constructed frame */
 int ndtpso_map_insert(ndtpso_map *map, const ndtpso_points *pts, const double pose[3]);
 int ndtpso_map_insert_host(ndtpso_map *map, const double *xy, uint32_t n, const double pose[3]);
 int ndtpso_map_build(ndtpso_map *map);

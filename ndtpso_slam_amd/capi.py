@@ -91,7 +91,7 @@ EXPORTS = [
     "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_scan_to_cells", "ndtpso_cells_build_windowed", "ndtpso_occupancy_values", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
     "ndtpso_points_create", "ndtpso_points_destroy", "ndtpso_points_load_scan", "ndtpso_points_set", "ndtpso_points_get",
-    "ndtpso_map_create", "ndtpso_map_destroy", "ndtpso_map_reset", "ndtpso_map_insert", "ndtpso_map_insert_host",
+    "ndtpso_map_create", "ndtpso_map_destroy", "ndtpso_map_reset", "ndtpso_map_clear", "ndtpso_map_insert", "ndtpso_map_insert_host",
     "ndtpso_map_build", "ndtpso_map_align", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
     "ndtpso_map_get_occupancy",
 ]
@@ -154,6 +154,7 @@ def load(build_if_missing: bool = True):
     L.ndtpso_map_destroy.argtypes = [vp]
     L.ndtpso_map_destroy.restype = None
     L.ndtpso_map_reset.argtypes = [vp]
+    L.ndtpso_map_clear.argtypes = [vp]
     L.ndtpso_map_insert.argtypes = [vp, vp, dp]
     L.ndtpso_map_insert_host.argtypes = [vp, dp, C.c_uint32, dp]
     L.ndtpso_map_build.argtypes = [vp]
@@ -429,7 +430,11 @@ class ResidentMap:
             pass
 
     def reset(self):
+        """NDTFrame::resetCells"""
         self._ctx._chk(self._lib.ndtpso_map_reset(self._h))
+
+    def clear(self):
+        self._ctx._chk(self._lib.ndtpso_map_clear(self._h))
 
     def insert(self, scan: ResidentScan, pose=None):
         self._ctx._chk(self._lib.ndtpso_map_insert(self._h, scan._h,

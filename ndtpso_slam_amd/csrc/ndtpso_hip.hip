@@ -461,6 +461,56 @@ struct DevBuf {
   }
 };
 
+// Pinned host staging for the per-scan uploads of the resident path (ranges, std::rand() table): the caller's buffer
+// is copied into a pinned slot and the DMA runs from there, so the call returns without waiting for the device and the
+// caller may reuse its buffer at once.  Four slots, reused round robin; a slot is waited for only if its previous
+// transfer is still in flight.
+struct PinnedRing {
+  static constexpr int kSlots = 4;
+  void* host[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  size_t cap[kSlots] = {0, 0, 0, 0};
+  hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
+  bool busy[kSlots] = {false, false, false, false};
+  int next = 0;
+  hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    const int k = next;
+    next = (next + 1) % kSlots;
+    hipError_t e = hipSuccess;
+    if (busy[k]) {
+      e = hipEventSynchronize(ev[k]);
+      if (e != hipSuccess) return e;
+      busy[k] = false;
+    }
+    if (!ev[k]) {
+      e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+      if (e != hipSuccess) return e;
+    }
+    if (cap[k] < bytes) {
+      if (host[k]) (void)hipHostFree(host[k]);
+      host[k] = nullptr;
+      cap[k] = 0;
+      e = hipHostMalloc(&host[k], bytes, hipHostMallocDefault);
+      if (e != hipSuccess) return e;
+      cap[k] = bytes;
+    }
+    std::memcpy(host[k], src, bytes);
+    e = hipMemcpyAsync(dst, host[k], bytes, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    busy[k] = true;
+    return hipEventRecord(ev[k], stream);
+  }
+  void release() {
+    for (int k = 0; k < kSlots; ++k) {
+      if (ev[k]) (void)hipEventDestroy(ev[k]);
+      if (host[k]) (void)hipHostFree(host[k]);
+      ev[k] = nullptr;
+      host[k] = nullptr;
+      cap[k] = 0;
+      busy[k] = false;
+    }
+  }
+};
+
 struct ndtpso_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -472,6 +522,7 @@ struct ndtpso_ctx {
   WinP wn{};
   uint32_t n_rows = 0;
   DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate;
+  PinnedRing pinned;
 };
 
 namespace {
@@ -686,6 +737,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
                     &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate})
     b->release();
+  c->pinned.release();
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }

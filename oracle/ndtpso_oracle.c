@@ -253,6 +253,23 @@ void orc_frame_destroy(orc_frame *f) {
   free(f);
 }
 
+/* NDTFrame::resetCells, ndtframe.cpp:208-212 -> NDTCell::reset, ndtcell.cpp:80-91: the running sums, the counts and
+ * the point vectors are cleared; the window's partial terms, created / built, mean and the inverse covariance are not */
+void orc_frame_reset_cells(orc_frame *f) {
+  unsigned i, s;
+  for (i = 0; i < f->num_cells; ++i) {
+    orc_cell *c = f->cells[i];
+    if (!c) continue; /* a cell that never received a point: reset() of an all-zero cell changes nothing */
+    c->current_partial_sum.x = c->current_partial_sum.y = 0.;
+    c->global_sum.x = c->global_sum.y = 0.;
+    c->current_count = 0;
+    c->global_count = 0;
+    memset(c->global_covar_sum, 0, sizeof(c->global_covar_sum));
+    c->current_window_id = 0;
+    for (s = 0; s < ORC_NDT_WINDOW_SIZE; ++s) c->points[s].n = 0;
+  }
+}
+
 void orc_frame_set_trans(orc_frame *f, const double trans[3]) { memcpy(f->trans, trans, sizeof(f->trans)); }
 
 void orc_frame_dims(const orc_frame *f, int32_t *wc, int32_t *hc) {

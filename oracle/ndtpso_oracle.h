@@ -102,6 +102,8 @@ void orc_frame_update(orc_frame *ref, const double trans[3], const orc_frame *ne
 void orc_frame_build(orc_frame *f);
 /* NDTFrame::getCellIndex, ndtframe.cpp:240-249 */
 int orc_frame_get_cell_index(const orc_frame *f, double x, double y);
+/* NDTFrame::resetCells, ndtframe.cpp:208-212 (NDTCell::reset, ndtcell.cpp:80-91) */
+void orc_frame_reset_cells(orc_frame *f);
 /* NDTFrame::setTrans, ndtframe.h:51 */
 void orc_frame_set_trans(orc_frame *f, const double trans[3]);
 /* NDTFrame::align, ndtframe.cpp:251-266.  use_frame_config=0 reproduces the

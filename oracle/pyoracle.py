@@ -65,6 +65,7 @@ def lib():
     L.orc_frame_add_point.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.orc_frame_update.argtypes = [C.c_void_p, dp, C.c_void_p]
     L.orc_frame_build.argtypes = [C.c_void_p]
+    L.orc_frame_reset_cells.argtypes = [C.c_void_p]
     L.orc_frame_get_cell_index.restype = C.c_int
     L.orc_frame_get_cell_index.argtypes = [C.c_void_p, C.c_double, C.c_double]
     L.orc_frame_set_trans.argtypes = [C.c_void_p, dp]
@@ -138,6 +139,9 @@ class Frame:
 
     def build(self):
         lib().orc_frame_build(self._h)
+
+    def reset_cells(self):
+        lib().orc_frame_reset_cells(self._h)
 
     def enable_occupancy_grid(self, og_cell_size):
         lib().orc_frame_enable_occupancy_grid(self._h, float(og_cell_size))

@@ -128,7 +128,20 @@ def test_resident_map_window_wraps_and_pool_recycles(ctx, oracle):
     # slots were overwritten on the second lap of the window and their chunks handed out again
     assert len(ref.points_all()) < info["n_points"] and info["pool_bump"] * 32 < info["n_points"]
     assert info["pool_free"] >= 0
+    # NDTFrame::resetCells keeps the window's partial terms and the built flags (ndtcell.cpp:80-91): same on the device
     rmap.reset()
+    ref.reset_cells()
+    assert len(rmap.points()) == 0 and rmap.info()["pool_free"] == info["pool_bump"]     # every chunk returned
+    for it in range(6):
+        xy = rng.uniform(-2.3, 2.3, size=(int(rng.integers(20, 300)), 2))
+        rmap.insert_host(xy)
+        for p in xy:
+            ref.add_point(p[0], p[1])
+        rmap.build()
+        ref.build()
+        _compare_cells(rmap.cells(), ref.cells())
+    assert np.array_equal(rmap.points(), ref.points_all())
+    rmap.clear()
     assert rmap.info()["n_created"] == 0 and len(rmap.points()) == 0
 
 

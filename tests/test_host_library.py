@@ -43,12 +43,15 @@ def _trajectory(n_scans, seed=4):
 
 
 @pytest.mark.gpu
-def test_node_replay_matches_oracle(tmp_path, oracle):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_node_replay_matches_oracle(tmp_path, oracle, resident, monkeypatch):
     """20 scans through loadLaser -> align -> update with the default 30 x 50 PSO (what the node really runs):
     the accumulated map exercises the sliding window (cells pass 50 points and open new slots) and the
     |2*pose_diff| deviation rule; one srand() at start, the stream runs on across alignments."""
     from ndtpso_slam_amd import synth
     _build()
+    # resident: map, windows and scans stay on the GPU (ndtpso_map_*); 0: the frame's bookkeeping on the host
+    monkeypatch.setenv("NDTPSO_RESIDENT", resident)
     n_scans, P, I, seed, cs = 20, 30, 50, 7, 0.5
     ranges, _ = _trajectory(n_scans)
     path = tmp_path / "scans.bin"
@@ -98,13 +101,15 @@ def test_node_replay_matches_oracle(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-def test_node_replay_map_export(tmp_path, oracle):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_node_replay_map_export(tmp_path, oracle, resident, monkeypatch):
     """SURVEY 8 f-4: the shutdown export of the node (ndtpso_slam_node.cpp:141-172 -> NDTFrame::dumpMap,
     ndtframe.cpp:268-422) and the occupancy grid of the reference frame (ndtframe.cpp:79-112) after a replay."""
     import struct
     import zlib
     from ndtpso_slam_amd import synth
     _build()
+    monkeypatch.setenv("NDTPSO_RESIDENT", resident)
     n_scans, P, I, seed, cs, ogcs = 8, 20, 20, 3, 0.5, 0.1
     ranges, _ = _trajectory(n_scans)
     path = tmp_path / "scans.bin"
@@ -184,3 +189,37 @@ def test_node_replay_map_export(tmp_path, oracle):
     img = want.reshape(h, w)[y0:y1 + 1, x0:x1 + 1][::-1]      # og[x + height*y] with height == width here
     expect = np.where(img > 0, (255.0 - img * 2.55).astype(np.uint8), 255)
     assert (np.abs(px.astype(int) - expect.astype(int)) <= 3).all()
+
+
+@pytest.mark.gpu
+def test_frame_api_resident_and_host_frames_agree(tmp_path, oracle):
+    """The public NDTFrame / core.h API beyond the node's calls (host/replay/frame_api_check.cpp): frames whose state
+    lives on the GPU and frames kept by the host print the same numbers, and the first steps match the oracle."""
+    from ndtpso_slam_amd import synth
+    _build()
+    ranges, _ = _trajectory(3)
+    path = tmp_path / "scans.bin"
+    with open(path, "wb") as f:
+        np.array([3, synth.N_BEAMS], dtype=np.int32).tofile(f)
+        np.array([synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX], dtype=np.float32).tofile(f)
+        ranges.tofile(f)
+    outs = {}
+    for resident in ("1", "0"):
+        prefix = str(tmp_path / ("dump" + resident))
+        outs[resident] = subprocess.check_output([os.path.join(HOST, "replay", "frame_api_check"), str(path), prefix],
+                                                 text=True, env=dict(os.environ, NDTPSO_RESIDENT=resident,
+                                                                     NDTPSO_SCORE="f64"))
+    print(outs["1"])
+    assert outs["1"] == outs["0"]
+    for ext in (".pose.csv", ".map.csv"):
+        assert open(str(tmp_path / "dump1") + ext).read() == open(str(tmp_path / "dump0") + ext).read()
+    lines = {l.split()[0]: l.split()[1:] for l in outs["1"].splitlines() if l.split()[0] in ("cost", "pso")}
+    a = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, 0.5)
+    a.load_laser(ranges[0], synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX)
+    a.build()
+    b = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+    b.load_laser(ranges[1], synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX)
+    want_cost = a.cost((0.05, -0.03, 0.01), b)
+    assert abs(float(lines["cost"][0]) - want_cost) <= 1e-9 * abs(want_cost)
+    pose, _, _ = a.pso((0, 0, 0), b, (.1, .1, 3.1415e-3), oracle.PSOConfig.make(25, 20), seed=5)
+    assert np.abs(np.array([float(v) for v in lines["pso"]]) - pose).max() < 1e-6
