@@ -1,0 +1,111 @@
+"""BASELINE.json's configurations at their FULL sizes.  The oracle needs ~0.1 s per 70 x 70 alignment, so at these
+sizes parity is checked on a seeded sample against the oracle and, for every alignment, through properties that do
+not depend on the size: determinism, independence of an alignment from the rest of its batch (order, sharding),
+agreement of the two score modes within the tolerance BASELINE states (1e-3 m / 1e-3 rad), a fixed amount of work
+(1 + P + P*I cost evaluations, 3 + 3P + 6PI draws) and the accuracy against the synthetic ground truth."""
+import numpy as np
+import pytest
+
+from conftest import DEVIATION, FRAME_M
+
+pytestmark = pytest.mark.gpu
+
+P, I, CS = 70, 70, 0.5
+
+
+def _geom(p, capi):
+    return capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+
+
+def _run(ctx, capi, p, sel, mode):
+    return ctx.align_pairs(p.ref_ranges[sel], p.new_ranges[sel], _geom(p, capi), capi.Grid(FRAME_M, FRAME_M, CS),
+                           (0, 0, 0), DEVIATION, capi.PSOConfig.make(I, P), seeds=p.seeds[sel], mode=mode)
+
+
+def test_config3_512_pairs(ctx, oracle):
+    """BASELINE config 3: 512 pairs, 1081 beams, 70 x 70, 0.5 m cells."""
+    from ndtpso_slam_amd import capi, synth
+    p = synth.make_pairs(512, seed=0)
+    everyone = np.arange(512)
+    pose, cost, st = _run(ctx, capi, p, everyone, capi.SCORE_F32)
+    assert (st["status"] == 0).all()
+    assert (st["n_points"] > 900).all() and (st["n_built"] > 50).all()
+    # fixed work per alignment plus the replays of the exact-order scheme (a few percent)
+    evals = 1 + P + P * I
+    assert (st["cost_evals"] >= evals).all() and st["cost_evals"].mean() < 1.06 * evals
+    # determinism and batch independence: reversed order, and an arbitrary subset
+    pose_r, cost_r, _ = _run(ctx, capi, p, everyone[::-1], capi.SCORE_F32)
+    assert np.array_equal(pose_r[::-1], pose) and np.array_equal(cost_r[::-1], cost)
+    sub = np.random.default_rng(1).choice(512, size=37, replace=False)
+    pose_s, _, _ = _run(ctx, capi, p, sub, capi.SCORE_F32)
+    assert np.array_equal(pose_s, pose[sub])
+    # the fp64 score mode (reference operation order) agrees within BASELINE's tolerance -- in fact exactly
+    pose64, cost64, st64 = _run(ctx, capi, p, everyone, capi.SCORE_F64)
+    d = np.abs(pose64 - pose)
+    print("f32 vs f64 score: max |dpose|", d.max(axis=0), "identical poses:", int((d.max(axis=1) == 0).sum()), "/ 512")
+    assert (d[:, :2] < 1e-3).all() and (d[:, 2] < 1e-3).all()
+    assert np.abs(cost64 - cost).max() < 1e-3
+    # the oracle on a seeded sample
+    sample = np.random.default_rng(2).choice(512, size=12, replace=False)
+    want, want_cost, _ = oracle.align_pairs(p.ref_ranges[sample], p.new_ranges[sample], p.angle_min, p.angle_inc,
+                                            p.range_max, 0.1, FRAME_M, FRAME_M, CS, (0, 0, 0), DEVIATION,
+                                            oracle.PSOConfig.make(I, P), p.seeds[sample])
+    assert np.abs(pose64[sample] - want).max() < 1e-9 and np.abs(cost64[sample] - want_cost).max() < 1e-9
+    assert np.abs(pose[sample] - want).max() < 1e-3
+    # accuracy against the ground truth of the synthetic pairs: the reference's own (mm / sub-mrad on average)
+    err = np.abs(pose - p.delta)
+    print("mean |error| vs truth", err.mean(axis=0))
+    # (a handful of pairs end in a neighbouring minimum along a wall -- the reference's PSO does the same, see the oracle sample)
+    assert err[:, :2].mean() < 5e-3 and err[:, 2].mean() < 1e-3 and np.quantile(err.max(axis=1), 0.98) < 2e-2
+
+
+def test_config4_4096_pairs_sharded_like_8_gpus(ctx, oracle):
+    """BASELINE config 4: 4096 pairs in 8 contiguous shards of 512 (one per GPU, ndtpso_slam_amd.sharding).  Run
+    here shard after shard on one GPU: every shard must reproduce its slice of the one-launch result."""
+    from ndtpso_slam_amd import capi, synth
+    from ndtpso_slam_amd.sharding import shard_range
+    total, world = 4096, 8
+    p = synth.make_pairs(total, seed=0)
+    pose, cost, st = _run(ctx, capi, p, np.arange(total), capi.SCORE_F32)
+    assert (st["status"] == 0).all()
+    for rank in range(world):
+        a, b = shard_range(total, rank, world)
+        assert (a, b) == (512 * rank, 512 * (rank + 1))
+        # a rank generates only its own pairs (first_pair / total_pairs), as bench.py does
+        q = synth.make_pairs(b - a, seed=0, first_pair=a, total_pairs=total)
+        assert np.array_equal(q.new_ranges, p.new_ranges[a:b]) and np.array_equal(q.seeds, p.seeds[a:b])
+        pose_k, cost_k, _ = _run(ctx, capi, q, np.arange(b - a), capi.SCORE_F32)
+        assert np.array_equal(pose_k, pose[a:b]) and np.array_equal(cost_k, cost[a:b])
+    sample = np.random.default_rng(3).choice(total, size=8, replace=False)
+    want, _, _ = oracle.align_pairs(p.ref_ranges[sample], p.new_ranges[sample], p.angle_min, p.angle_inc, p.range_max,
+                                    0.1, FRAME_M, FRAME_M, CS, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P),
+                                    p.seeds[sample])
+    d = np.abs(pose[sample] - want)
+    print("config 4 sample vs oracle: max |dpose|", d.max(axis=0))
+    assert d.max() < 1e-3
+    err = np.abs(pose - p.delta)
+    assert err[:, :2].mean() < 5e-3 and err[:, 2].mean() < 1e-3
+
+
+def test_config5_full_size_large_swarm(ctx):
+    """BASELINE config 5 at full size: 2048 particles x 200 iterations, 2048 beams, 0.25 m cells (843 M point
+    evaluations per alignment; the oracle would need ~20 s per alignment, tests/test_gpu_parity.py checks this shape
+    against it with 3 iterations).  Full size: determinism, both score modes within tolerance, fixed work."""
+    from ndtpso_slam_amd import capi, synth
+    p = synth.make_pairs(2, n_beams=2048, seed=21)
+    geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+    cfg = capi.PSOConfig.make(200, 2048)
+    out = {}
+    for mode in (capi.SCORE_F32, capi.SCORE_F64):
+        out[mode] = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, capi.Grid(FRAME_M, FRAME_M, 0.25), (0, 0, 0),
+                                    DEVIATION, cfg, seeds=p.seeds, mode=mode)
+        assert (out[mode][2]["status"] == 0).all()
+        assert (out[mode][2]["cost_evals"] >= 1 + 2048 + 2048 * 200).all()
+    again = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, capi.Grid(FRAME_M, FRAME_M, 0.25), (0, 0, 0), DEVIATION,
+                            cfg, seeds=p.seeds, mode=capi.SCORE_F32)
+    assert np.array_equal(again[0], out[capi.SCORE_F32][0])
+    d = np.abs(out[capi.SCORE_F32][0] - out[capi.SCORE_F64][0])
+    print("config 5 full size: f32 vs f64 max |dpose|", d.max(axis=0), "replay overhead",
+          out[capi.SCORE_F32][2]["cost_evals"] / (1 + 2048 + 2048 * 200) - 1)
+    assert d.max() < 1e-3
+    assert np.abs(out[capi.SCORE_F32][0] - p.delta).max() < 2e-2
