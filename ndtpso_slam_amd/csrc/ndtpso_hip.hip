@@ -144,11 +144,29 @@ __device__ __forceinline__ EvalCtx make_eval_ctx(const GridP& g, const WinP& wn,
   return E;
 }
 
+// the table image where it lies in HBM, for maps whose table does not fit in LDS (PATH 4 / 5)
+__device__ __forceinline__ EvalCtx make_eval_ctx_global(const GridP& g, const WinP& wn, const DenseP& dn,
+                                                        const unsigned char* __restrict__ image) {
+  EvalCtx E;
+  E.g = g;
+  E.wn = wn;
+  E.T.bm = reinterpret_cast<const uint2*>(image + kImageHeaderBytes);
+  E.T.mean = reinterpret_cast<const double2*>(image + image_mean_offset(wn.n_words));
+  E.T.ab = reinterpret_cast<const double2*>(image + image_ab_offset(wn.n_words, wn.rec_cap));
+  E.T.cd = reinterpret_cast<const double2*>(image + image_cd_offset(wn.n_words, wn.rec_cap));
+  E.T.chol = reinterpret_cast<const float4*>(image + image_chol_offset(wn.n_words, wn.rec_cap));
+  E.dn = dn;
+  E.lds0 = g_lds;
+  return E;
+}
+
 // stage a table image (HBM) into LDS in the form the kernel's PATH wants
 template <int MODE, int PATH>
 __device__ __forceinline__ void stage_image(const unsigned char* __restrict__ image, const GridP& g, const WinP& wn,
                                             const Layout& L, const DenseP& dn) {
-  if constexpr (PATH == 2) {
+  if constexpr (PATH >= 4) {  // table stays in HBM (served by L2); only the header is staged
+    copy16(g_lds + L.hdr_off, image, kImageHeaderBytes);
+  } else if constexpr (PATH == 2) {
     copy16(g_lds + L.hdr_off, image, kImageHeaderBytes);
     dense_from_image_wg(g, wn, image, dn, g_lds);
   } else if constexpr (MODE == kScoreF64) {
@@ -335,7 +353,7 @@ k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict_
   copy16(pts, xy, n * 16);
   pad_points_wg(pts, n);
   __syncthreads();
-  const EvalCtx E = make_eval_ctx(g, wn, L, dn);
+  const EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
   const int n_waves = blockDim.x >> 6;
   for (int k = blockIdx.x * n_waves + wave_id(); k < m; k += gridDim.x * n_waves) {
     const double th = poses[3 * k + 2];
@@ -347,7 +365,7 @@ k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict_
     if constexpr (PATH == 2)
       cost = eval_pose_wave_dense<DUMP>(E.g, E.dn, E.lds0, pts, n, cn, sn, tx, ty, dp);
     else
-      cost = eval_pose_wave_t<MODE, PATH == 1, DUMP>(E.g, E.wn, E.T, pts, n, cn, sn, tx, ty, dp);
+      cost = eval_pose_wave_t<MODE, (PATH & 3) == 1, DUMP>(E.g, E.wn, E.T, pts, n, cn, sn, tx, ty, dp);
     if constexpr (MODE == kScoreF32) {
       if (cost > -kTinyCost) cost = eval_pose_wave_tiny<PATH>(E, pts, n, cn, sn, tx, ty);  // underflow regime
     }
@@ -369,7 +387,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   copy16(pts, xy, n * 16);
   pad_points_wg(pts, n);
   __syncthreads();
-  const EvalCtx E = make_eval_ctx(g, wn, L, dn);
+  const EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
   const Swarm sw = swarm_carve(L.swarm_global ? ws : g_lds + L.region_off, ps.P);
   pso_run_wg<MODE, PATH>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost, stats);
   if (threadIdx.x == 0 && stats) {
@@ -623,13 +641,16 @@ struct Plan {
 // alignment and its table is provisioned as large as still leaves two workgroups per CU (else as large as
 // fits).  Preference: dense over bitmap (measured, profiles/r01_occupancy_study.md: dense at one workgroup per
 // CU still beats bitmap at two), swarm in LDS over swarm in HBM.
+// allow_global: when neither form fits, read the table from its HBM image (path 4 / 5; kernels that stage a prebuilt
+// table only -- a long-lived map can hold more built cells than LDS has room for).
 bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan* plan, bool dynamic_window = false,
-               bool allow_dense = true) {
+               bool allow_dense = true, bool allow_global = false) {
   const int bitmap_path = g.cs_pow2 ? 1 : 0;
   int force = -1;
   if (const char* e = std::getenv("NDTPSO_PATH")) force = std::atoi(e);  // tuning knob
   const bool dense_ok = allow_dense && mode == kScoreF32 && force != 0 && force != 1;
-  for (int swarm_global = 0; swarm_global < 2; ++swarm_global) {
+  const bool force_global = allow_global && (force == 4 || force == 5);
+  for (int swarm_global = 0; swarm_global < 2 && !force_global; ++swarm_global) {
     if (swarm_global && P <= 0) break;
     if (dense_ok) {
       const int full_w = wn.w + 1, full_h = wn.h + 1;
@@ -673,6 +694,17 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
   plan->path = bitmap_path;
   plan->dn = DenseP{0, 0, 0, 0, 0, 0, 0., 0.};
   plan->dense_cap = 0;
+  if (allow_global) {
+    for (int swarm_global = 0; swarm_global < 2; ++swarm_global) {
+      if (swarm_global && P <= 0) break;
+      const Layout Lg = make_layout(0, 0, n_max, P, mode, 0, 0, swarm_global != 0);
+      if (Lg.total <= kMaxLds) {
+        plan->path = bitmap_path | 4;
+        plan->L = Lg;
+        return true;
+      }
+    }
+  }
   return false;
 }
 
@@ -719,6 +751,15 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   BIG_PATHS(k_cost_batch, COMMA true)
   BIG_PATHS(k_align)
   BIG_PATHS(k_align_pairs)
+#define GLOBAL_PATHS(K, ...)                                                   \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 4 __VA_ARGS__>);         \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 5 __VA_ARGS__>);         \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF64, 4 __VA_ARGS__>);         \
+  if (e == hipSuccess) e = allow_big_lds(K<kScoreF64, 5 __VA_ARGS__>);
+  GLOBAL_PATHS(k_cost_batch, COMMA false)
+  GLOBAL_PATHS(k_cost_batch, COMMA true)
+  GLOBAL_PATHS(k_align)
+#undef GLOBAL_PATHS
 #undef COMMA
 #undef BIG_PATHS
   if (e != hipSuccess) {
@@ -890,8 +931,7 @@ int ndtpso_ref_set_cells(ndtpso_ctx* c, const ndtpso_grid* grid, uint32_t n_cell
   wn.h = y1 - y0 + 1;
   wn.n_words = (wn.w * wn.h + 31) / 32;
   wn.rec_cap = std::max<int>((int)n_cells, 1);
-  const Layout L = make_layout(wn.n_words, wn.rec_cap, 1, 0, 2);
-  if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "reference table does not fit in LDS");
+  // (a table too large for LDS is read from this image where it lies in HBM: paths 4 / 5 of the kernels)
   // pack the LDS image on the host: bitmap words {bits, exclusive prefix}, records in ascending cell order
   const size_t bytes = image_bytes(wn.n_words, wn.rec_cap);
   std::vector<unsigned char> img(bytes, 0);
@@ -1058,8 +1098,8 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
   if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
   HIP_TRY(c, hipSetDevice(c->device));
   Plan plan;
-  if (!make_plan(mode, c->g, c->wn, std::max<int>((int)n, 1), 0, &plan))
-    return fail(c, NDTPSO_E_CAPACITY, "table + points do not fit in LDS");
+  if (!make_plan(mode, c->g, c->wn, std::max<int>((int)n, 1), 0, &plan, false, true, true))
+    return fail(c, NDTPSO_E_CAPACITY, "points do not fit in LDS");
   const Layout& L = plan.L;
   HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
   HIP_TRY(c, c->poses.reserve((size_t)m * 24));
@@ -1076,9 +1116,20 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
 #define LAUNCH_COST2(MODE, PATH) \
   do { if (cell_idx) LAUNCH_COST(MODE, PATH, true); else LAUNCH_COST(MODE, PATH, false); } while (0)
   if (mode == NDTPSO_SCORE_F32) {
-    if (plan.path == 2) LAUNCH_COST2(kScoreF32, 2); else if (plan.path == 1) LAUNCH_COST2(kScoreF32, 1); else LAUNCH_COST2(kScoreF32, 0);
+    switch (plan.path) {
+      case 2: LAUNCH_COST2(kScoreF32, 2); break;
+      case 1: LAUNCH_COST2(kScoreF32, 1); break;
+      case 4: LAUNCH_COST2(kScoreF32, 4); break;
+      case 5: LAUNCH_COST2(kScoreF32, 5); break;
+      default: LAUNCH_COST2(kScoreF32, 0);
+    }
   } else {
-    if (plan.path == 1) LAUNCH_COST2(kScoreF64, 1); else LAUNCH_COST2(kScoreF64, 0);
+    switch (plan.path) {
+      case 1: LAUNCH_COST2(kScoreF64, 1); break;
+      case 4: LAUNCH_COST2(kScoreF64, 4); break;
+      case 5: LAUNCH_COST2(kScoreF64, 5); break;
+      default: LAUNCH_COST2(kScoreF64, 0);
+    }
   }
 #undef LAUNCH_COST2
 #undef LAUNCH_COST
@@ -1106,8 +1157,8 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
                       int mode, double host[4 + sizeof(AlignStats) / 8]) {
   Plan plan;
   const uint32_t n = src.n;
-  if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan))
-    return fail(c, NDTPSO_E_CAPACITY, "table + points + swarm do not fit in LDS");
+  if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true))
+    return fail(c, NDTPSO_E_CAPACITY, "points + swarm do not fit in LDS");
   const Layout& L = plan.L;
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
@@ -1122,9 +1173,20 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
                      have_table ? (const int32_t*)c->table.p : nullptr, (unsigned char*)c->ws.p, d_out, d_out + 3, \
                      d_stats)
   if (mode == NDTPSO_SCORE_F32) {
-    if (plan.path == 2) LAUNCH_ALIGN(kScoreF32, 2); else if (plan.path == 1) LAUNCH_ALIGN(kScoreF32, 1); else LAUNCH_ALIGN(kScoreF32, 0);
+    switch (plan.path) {
+      case 2: LAUNCH_ALIGN(kScoreF32, 2); break;
+      case 1: LAUNCH_ALIGN(kScoreF32, 1); break;
+      case 4: LAUNCH_ALIGN(kScoreF32, 4); break;
+      case 5: LAUNCH_ALIGN(kScoreF32, 5); break;
+      default: LAUNCH_ALIGN(kScoreF32, 0);
+    }
   } else {
-    if (plan.path == 1) LAUNCH_ALIGN(kScoreF64, 1); else LAUNCH_ALIGN(kScoreF64, 0);
+    switch (plan.path) {
+      case 1: LAUNCH_ALIGN(kScoreF64, 1); break;
+      case 4: LAUNCH_ALIGN(kScoreF64, 4); break;
+      case 5: LAUNCH_ALIGN(kScoreF64, 5); break;
+      default: LAUNCH_ALIGN(kScoreF64, 0);
+    }
   }
 #undef LAUNCH_ALIGN
   HIP_TRY(c, hipGetLastError());

@@ -945,7 +945,8 @@ struct PsoShared {  // small control block in LDS
   RngState rng;
 };
 
-// PATH: 0 = bitmap table, true division by cell_side; 1 = bitmap table, power-of-two cell side; 2 = dense fast path
+// PATH: 0 = bitmap table, true division by cell_side; 1 = bitmap table, power-of-two cell side; 2 = dense fast path;
+// 4 / 5 = as 0 / 1 with the table read from its HBM image instead of LDS (maps too large to stage)
 struct EvalCtx {
   GridP g;
   WinP wn;
@@ -997,7 +998,7 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
       double term = 0.;
       if (fabs(qx) < g.hw && fabs(qy) < g.hh) {
         int ix, iy;
-        cell_coords<PATH == 1>(g, qx, qy, ix, iy);
+        cell_coords<(PATH & 3) == 1>(g, qx, qy, ix, iy);
         if (ix == g.W) {
           ix = 0;
           iy += 1;
@@ -1037,7 +1038,7 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
     if constexpr (PATH == 2)
       cost = eval_pose_wave_dense<false>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
     else
-      cost = eval_pose_wave<MODE, PATH == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+      cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
     if (lane_id() == 0) {
       sw.tcost[j] = cost;
       // A cost in the fp32 underflow regime is only ambiguous when what it is compared with is there too: an

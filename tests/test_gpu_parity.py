@@ -346,3 +346,84 @@ def test_randomised_staged_tables(ctx, oracle):
                 exact32 += int(d == 0.0)
                 assert d < 1e-3, (case, n_beams, frame, cs, P, I, d)
     print("staged tables, fp32 score: bit-identical in %d/24 configurations" % exact32)
+
+
+def test_table_in_hbm_paths_match_lds_paths(ctx, oracle, pairs8, monkeypatch):
+    """Paths 4 / 5 read the cell table from its HBM image instead of LDS (maps too large to stage).  Forced on a
+    small table they must reproduce the LDS bitmap paths bit for bit: same arithmetic, different address space."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    rng = np.random.default_rng(8)
+    poses = np.concatenate([np.zeros((1, 3)), rng.uniform(-1, 1, (40, 3)) * DEVIATION * 2])
+    for cs, lds_path, hbm_path in ((0.5, "1", "5"), (0.3, "0", "4")):
+        grid = capi.Grid(FRAME_M, FRAME_M, cs)
+        table = oracle.glibc_rand(int(p.seeds[1]), 3 + 3 * 30 + 6 * 30 * 50)
+        xy = ctx.scan_to_points(p.new_ranges[1], _geom(p, capi))
+        ctx.ref_from_scan(grid, p.ref_ranges[1], _geom(p, capi))
+        out = {}
+        for path in (lds_path, hbm_path):
+            monkeypatch.setenv("NDTPSO_PATH", path)
+            for mode in (capi.SCORE_F64, capi.SCORE_F32):
+                costs, idx = ctx.cost_batch(xy, poses, mode=mode, want_cells=True)
+                pose, cost, st = ctx.align(xy, (0, 0, 0), DEVIATION, capi.PSOConfig.make(50, 30), rand_table=table, mode=mode)
+                out[(path, mode)] = (costs, idx, pose, cost, st["cost_evals"])
+        monkeypatch.delenv("NDTPSO_PATH")
+        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+            a, b = out[(lds_path, mode)], out[(hbm_path, mode)]
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            assert np.array_equal(a[2], b[2]) and a[3] == b[3] and a[4] == b[4]
+
+
+def test_map_larger_than_lds_is_served_from_hbm(ctx, oracle):
+    """A long-lived map can hold more built cells than LDS has room for (here 9000 cells of a 240 x 240 grid:
+    576 KB of records).  The reference aligns against any map; so does this path, reading the table through L2."""
+    from ndtpso_slam_amd import capi
+    rng = np.random.default_rng(12)
+    cs, n_cells = 0.25, 9000
+    W = int(np.ceil(FRAME_M / cs))
+    grid = capi.Grid(FRAME_M, FRAME_M, cs)
+    chosen = rng.choice(W * W, size=n_cells, replace=False)
+    cx, cy = chosen % W, chosen // W
+    ref = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, cs)
+    pts = []
+    for x, y in zip(cx, cy):
+        k = int(rng.integers(3, 7))
+        px = (x + rng.uniform(0.1, 0.9, k)) * cs - FRAME_M / 2
+        py = (y + rng.uniform(0.1, 0.9, k)) * cs - FRAME_M / 2
+        pts.append(np.stack([px, py], axis=1))
+    pts = np.concatenate(pts)
+    for q in pts:
+        ref.add_point(q[0], q[1])
+    ref.build()
+    cells = [c for c in ref.cells() if c["built"]]
+    assert len(cells) == n_cells
+    # new scan: points near the map's own points, moved by a small motion
+    truth = np.array([0.04, -0.03, 0.008])
+    sel = pts[rng.choice(len(pts), size=1081, replace=False)] + rng.normal(0, 0.01, (1081, 2))
+    c, s = np.cos(-truth[2]), np.sin(-truth[2])
+    d = sel - truth[:2]
+    new_xy = np.stack([d[:, 0] * c - d[:, 1] * s, d[:, 0] * s + d[:, 1] * c], axis=1)
+    cur = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+    for q in new_xy:
+        cur.add_point(q[0], q[1])
+    new_xy = cur.points()
+    P, I, seed = 30, 50, 77
+    table = oracle.glibc_rand(seed, 3 + 3 * P + 6 * P * I)
+    want, want_cost, _ = ref.pso((0, 0, 0), cur, DEVIATION, oracle.PSOConfig.make(I, P), table=table)
+    poses = np.concatenate([np.zeros((1, 3)), truth[None], rng.uniform(-1, 1, (30, 3)) * DEVIATION])
+    want_costs = np.array([ref.cost(q, cur) for q in poses])
+
+    ctx.ref_set_cells(grid, [c["index"] for c in cells], [c["mean"] for c in cells], [c["icov"] for c in cells])
+    costs, _ = ctx.cost_batch(new_xy, poses, mode=capi.SCORE_F64, want_cells=True)
+    assert np.abs(costs - want_costs).max() < 1e-9
+    for mode, tol in ((capi.SCORE_F64, 1e-9), (capi.SCORE_F32, 1e-3)):
+        got, cost, st = ctx.align(new_xy, (0, 0, 0), DEVIATION, capi.PSOConfig.make(I, P), rand_table=table, mode=mode)
+        assert st["n_built"] == n_cells and np.abs(got - want).max() < tol, (mode, got, want)
+    # the same map, resident: inserted, built and aligned against on the device
+    rmap = capi.ResidentMap(ctx, grid, pool_bytes=64 << 20)
+    rmap.insert_host(pts)
+    scan = capi.ResidentScan(ctx, 2048)
+    scan.set(new_xy)
+    got, cost, st = rmap.align(scan, (0, 0, 0), DEVIATION, capi.PSOConfig.make(I, P), rand_table=table, mode=capi.SCORE_F64)
+    assert st["n_built"] == n_cells and np.abs(got - want).max() < 1e-9 and abs(cost - want_cost) < 1e-9
+    assert np.abs(want - truth).max() < 2e-2
