@@ -157,11 +157,12 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic_bytes(),
                 "kernel": "k_align_pairs", "kernel_ms": kern_ms,
                 "algorithmic_bytes_per_launch": algo_bytes,
+                "valu": _valu_roof(stats, kern_ms),
                 "note": "achieved = streaming-equivalent bytes (40 B per point-eval x (1+P+P*I) x N_valid, summed "
                         "over the launch's pairs) / kernel time; the kernel keeps table+points+swarm in LDS, so this "
                         "is an effective bandwidth that can exceed the HBM peak; traffic = HBM bytes per launch from "
                         "profiles/r01_pmc_summary.json (compulsory ~8.7 KB/alignment).  The kernel is VALU-bound: "
-                        "see DESIGN.md section 5",
+                        "`valu` is the roof that bounds it (DESIGN.md section 5)",
             },
             "extra": {
                 "mean_cost_evals_per_alignment": float(stats["cost_evals"].mean()),
@@ -215,6 +216,26 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _valu_roof(stats, kern_ms):
+    """The roof that actually bounds the kernel ("quote the ALU roof"): vector-ALU issue.  Work = the
+    64-point chunks this launch scored (cost evaluations x ceil(points / 64), from the kernel's own counters) x the
+    VALU instructions one chunk takes; peak = 1024 SIMDs issuing one such instruction every `cycles_per_instr`
+    cycles.  Instructions per chunk and cycles per instruction are the measured PMC figures of this kernel
+    (profiles/r01_pmc_summary.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU); the duration is this run's."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+            d = json.load(f)["derived"]
+        ipc, cpi = float(d["valu_instr_per_64_point_evals"]), float(d["valu_cycles_per_instr"])
+    except (OSError, KeyError, ValueError):
+        return None
+    clock_hz, simds = 2.4e9, 256 * 4
+    chunks = float((stats["cost_evals"].astype(np.float64) * np.ceil(stats["n_points"] / 64.0)).sum())
+    achieved = chunks * ipc / (kern_ms * 1e-3)
+    peak = simds * clock_hz / cpi
+    return {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "wave-instructions/s", "frac": achieved / peak,
+            "valu_instr_per_64_point_evals": ipc, "valu_cycles_per_instr": cpi, "clock_hz": clock_hz}
 
 
 def _pmc_traffic_bytes():
