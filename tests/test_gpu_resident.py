@@ -166,3 +166,79 @@ def test_resident_scan_append_and_errors(ctx, oracle):
     with pytest.raises(capi.NdtpsoError) as e:
         tiny.info()
     assert e.value.code == capi.E_CAPACITY
+
+
+def test_resident_sequence_matches_golden_fixture(ctx):
+    """Fixture G5 (tests/golden/oracle_golden_sequence.npz) through the device-resident path, no oracle at run time:
+    poses of the 14-scan sequence, the cells' window state, the occupancy grid, the stored points, resetCells."""
+    import os
+    from ndtpso_slam_amd import capi
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden_sequence.npz"))
+    frame, n_beams, n_scans, P, I, seed = (int(v) for v in g["params"])
+    cs, ogcs = float(g["cell_side"]), float(g["og_cell_size"])
+    geom = capi.ScanGeom(n_beams, float(g["angle_min"]), float(g["angle_inc"]), float(g["range_max"]), 0.1)
+    grid = capi.Grid(frame, frame, cs)
+    cfg = capi.PSOConfig.make(I, P)
+    rmap = capi.ResidentMap(ctx, grid, og_cell_size=ogcs, pool_bytes=16 << 20)
+    scan = capi.ResidentScan(ctx, 1024)
+    prev, prev_pose, pose_diff, s_iter = np.zeros(3), np.zeros(3), np.zeros(3), 0
+    stream = _glibc_rand(seed, (3 + 3 * P + 6 * P * I) * n_scans)
+    poses = []
+    for k in range(n_scans):
+        scan.load_scan(g["ranges"][k], geom, clip=grid)
+        if k == 0:
+            pose = prev.copy()
+        else:
+            # NDTFrame::align, ndtframe.cpp:251-266; one srand(seed) stream runs on across the alignments
+            dev = np.array([.1, .1, 3.1415e-3]) if s_iter < 2 else np.abs(2. * pose_diff)
+            s_iter += 1
+            n_draw = 3 + 3 * P + 6 * P * I
+            table = stream[(k - 1) * n_draw:k * n_draw]
+            pose, _, _ = rmap.align(scan, prev, dev, cfg, rand_table=table, mode=capi.SCORE_F64)
+            pose_diff, prev_pose = pose - prev_pose, pose
+        prev = pose
+        rmap.insert(scan, pose)
+        poses.append(pose)
+    poses = np.array(poses)
+    print("max |dpose| vs fixture", np.abs(poses - g["poses"]).max(axis=0))
+    assert np.abs(poses - g["poses"]).max() < 1e-6
+    rmap.build()
+    cells = rmap.cells()
+    assert np.array_equal([c["index"] for c in cells], g["cell_index"])
+    assert np.array_equal([c["count"] for c in cells], g["cell_count"])
+    assert np.array_equal([c["slot"] for c in cells], g["cell_slot"])
+    built = np.array([c["built"] for c in cells])
+    assert np.array_equal(built, g["cell_built"].astype(bool))
+    mean = np.array([c["mean"] for c in cells])[built]
+    icov = np.array([c["icov"] for c in cells])[built]
+    assert np.allclose(mean, g["cell_mean"][built], rtol=0, atol=1e-6)
+    assert np.allclose(icov, g["cell_icov"][built], rtol=1e-4, atol=1e-6)
+    og, w, h, ext = rmap.occupancy()
+    assert (w, h) == tuple(g["og_shape"]) and ext == tuple(int(v) for v in g["og_extent"])
+    want = np.zeros(w * h, dtype=np.int8)
+    want[g["og_nonzero_index"]] = g["og_nonzero_value"]
+    assert np.abs(og.astype(int) - want.astype(int)).max() <= 1
+    pts = rmap.points()
+    assert len(pts) == int(g["points_count"]) and np.allclose(pts[:64], g["points_head"], atol=1e-6)
+    assert np.allclose(pts.sum(axis=0), g["points_sum"], atol=1e-3)
+    rmap.reset()
+    for k in (0, 1):
+        scan.load_scan(g["ranges"][k], geom, clip=None)
+        rmap.insert(scan, None)
+        rmap.build()
+    cells = rmap.cells()
+    assert np.array_equal([c["count"] for c in cells], g["reset_cell_count"])
+    assert np.array_equal([c["built"] for c in cells], g["reset_cell_built"].astype(bool))
+
+
+def _glibc_rand(seed, n):
+    """glibc srand(seed); rand() x n (TYPE_3 additive feedback: r[i] = r[i-31] + r[i-3], output >> 1)"""
+    r = [0] * (34 + 310 + n)
+    r[0] = seed if seed else 1
+    for i in range(1, 31):
+        r[i] = (16807 * r[i - 1]) % 2147483647
+    for i in range(31, 34):
+        r[i] = r[i - 31]
+    for i in range(34, 344 + n):
+        r[i] = (r[i - 31] + r[i - 3]) & 0xFFFFFFFF
+    return np.array([v >> 1 for v in r[344:344 + n]], dtype=np.int32)

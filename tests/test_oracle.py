@@ -243,3 +243,23 @@ def test_oracle_batch_threads_agree(oracle, pairs8):
     b, cb, used = oracle.align_pairs(p.ref_ranges, p.new_ranges, p.angle_min, p.angle_inc, p.range_max, 0.1, FRAME_M,
                                      FRAME_M, 0.5, (0, 0, 0), DEVIATION, cfg, p.seeds, n_threads=4)
     assert np.array_equal(a, b) and np.array_equal(ca, cb) and used >= 1
+
+
+def test_golden_node_sequence(oracle):
+    """Fixture G5 (tests/golden/make_golden_sequence.py): the node's loadLaser -> align -> update sequence with
+    sliding-window cells, the occupancy grid and resetCells, recomputed and compared with the committed vectors."""
+    import importlib.util
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_golden_sequence", os.path.join(here, "golden", "make_golden_sequence.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    g = np.load(os.path.join(here, "golden", "oracle_golden_sequence.npz"))
+    ranges, amin, ainc, rmax = gen.scans()
+    assert np.array_equal(ranges, g["ranges"]) and amin == g["angle_min"] and ainc == g["angle_inc"]
+    out = gen.run(g["ranges"], g["angle_min"], g["angle_inc"], g["range_max"])
+    for k, v in out.items():
+        if np.asarray(v).dtype.kind == "f":
+            assert np.allclose(v, g[k], rtol=1e-12, atol=1e-12), k
+        else:
+            assert np.array_equal(v, g[k]), k
+    assert g["cell_slot"].max() >= 1 and len(g["og_nonzero_index"]) > 50      # the fixture exercises both
