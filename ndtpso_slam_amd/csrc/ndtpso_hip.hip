@@ -427,7 +427,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     dn.ox = wn.x0 - 1;
     dn.oy = wn.y0 - 1;
     dense_set_limits(dn, g.hw, g.hh, g.inv_cs);
-    if (dn.dw * dn.dh > dense_cap) {  // uniform
+    if (dense_entries(dn.dw, dn.dh) > dense_cap) {  // uniform
       if (threadIdx.x == 0) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
       return;
     }
@@ -655,7 +655,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
     if (dense_ok) {
       const int full_w = wn.w + 1, full_h = wn.h + 1;
       Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, full_w, full_h, swarm_global != 0);
-      int cap = full_w * full_h;
+      int cap = dense_entries(full_w, full_h);
       if (dynamic_window && Ld.total > kMaxLds / 2) {
         // shrink the provisioned (square) table until two workgroups fit per CU, else until one does;
         // never below 64 x 64 cells
@@ -665,7 +665,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
             const Layout Lt = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0);
             if (Lt.total <= limit) {
               Ld = Lt;
-              cap = side * side;
+              cap = dense_entries(side, side);
               found = true;
               break;
             }

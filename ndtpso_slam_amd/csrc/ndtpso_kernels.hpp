@@ -96,7 +96,11 @@ __host__ __device__ inline void dense_set_limits(DenseP& d, double hw, double hh
   d.xmax = (2. * hw) * inv_cs - (double)d.ox;
   d.ymax = (2. * hh) * inv_cs - (double)d.oy;
 }
-__host__ __device__ inline int dense_tab_bytes(int dw, int dh) { return align16_c(dw * dh * 2); }
+// The dense table holds (dw + 1) x (dh + 1) u16 entries: dw x dh is the staging window with its empty low border
+// column / row; the extra high column and row are always null, so that a clamped coordinate needs no range test.
+__host__ __device__ inline int dense_stride(int dw) { return dw + 1; }
+__host__ __device__ inline int dense_entries(int dw, int dh) { return (dw + 1) * (dh + 1); }
+__host__ __device__ inline int dense_tab_bytes(int dw, int dh) { return align16_c(dense_entries(dw, dh) * 2); }
 constexpr int kRecImageBytes = 64;  // per record in the HBM image: mean, ab, cd, chol
 
 struct ImageHeader {
@@ -334,13 +338,13 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   for (int u = 0; u < U; ++u) {
     gx[u] = fma(p[u].x, it.C, fma(-p[u].y, it.S, it.TX));
     gy[u] = fma(p[u].x, it.S, fma(p[u].y, it.C, it.TY));
-    const unsigned rx = (unsigned)(int)gx[u], ry = (unsigned)(int)gy[u];
-    bool ok = (int)(rx < (unsigned)dn.dw) & (int)(ry < (unsigned)dn.dh);
+    // Out-of-window coordinates clamp into the always-null high column / row (negative ones convert to huge
+    // unsigned values first; column / row 0 is the empty low border): no range test, no select.
+    const unsigned rx = min((unsigned)(int)gx[u], (unsigned)dn.dw), ry = min((unsigned)(int)gy[u], (unsigned)dn.dh);
+    lin[u] = __umul24(ry, (unsigned)dense_stride(dn.dw)) + rx;
     // A grid whose last cells overhang the frame (width/cs not an integer): points past the frame's upper
-    // bound are rejected by NDTFrame::getCellIndex (ndtframe.cpp:242) although a cell exists there.  (Below the
-    // lower bound the cell coordinate is negative or lands in the empty border column.)
-    if constexpr (CLIP) ok = (int)ok & (int)(gx[u] < it.XMAX) & (int)(gy[u] < it.YMAX);
-    lin[u] = ok ? __umul24(ry, (unsigned)dn.dw) + rx : 0u;  // cell 0 is a border cell: always the null record
+    // bound are rejected by NDTFrame::getCellIndex (ndtframe.cpp:242) although a cell exists there.
+    if constexpr (CLIP) lin[u] = ((int)(gx[u] < it.XMAX) & (int)(gy[u] < it.YMAX)) ? lin[u] : 0u;  // cell 0: null
   }
   // the dense table starts at LDS address 0 and records are addressed absolutely: plain shifts, no base add
   typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
@@ -604,7 +608,7 @@ __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsi
   r.l22 = l[2];
   r.w = 0.f;
   reinterpret_cast<DenseRec*>(lds0 + dn.rec_off)[slot + 1] = r;
-  reinterpret_cast<unsigned short*>(lds0)[(ry + 1) * dn.dw + (rx + 1)] =
+  reinterpret_cast<unsigned short*>(lds0)[(ry + 1) * dense_stride(dn.dw) + (rx + 1)] =
       (unsigned short)(((unsigned)dn.rec_off >> 4) + 2u * (slot + 1));
 }
 
@@ -981,7 +985,7 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
       const double gy = fma(p.x, it.S, fma(p.y, it.C, it.TY));
       const unsigned rx = (unsigned)(int)gx, ry = (unsigned)(int)gy;
       const bool ok = (rx < (unsigned)E.dn.dw) && (ry < (unsigned)E.dn.dh) && (!E.dn.clip || (gx < it.XMAX && gy < it.YMAX));
-      const unsigned lin = ok ? ry * (unsigned)E.dn.dw + rx : 0u;
+      const unsigned lin = ok ? ry * (unsigned)dense_stride(E.dn.dw) + rx : 0u;
       const unsigned e = reinterpret_cast<const unsigned short*>(E.lds0)[lin];
       const DenseRec* r = reinterpret_cast<const DenseRec*>(E.lds0 + (e << 4));
       const double d0 = gx - r->mgx, d1 = gy - r->mgy;
