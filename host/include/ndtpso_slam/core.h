@@ -27,5 +27,8 @@ Vector2d transform_point(const Vector2d& point, const Vector3d& trans);
 float index_to_angle(unsigned int idx, float step, float min_angle);
 // polar -> cartesian in fp64
 Vector2d laser_to_point(float r, float theta);
+// lower-left corner of the cell_side-aligned square that contains `point` (reference core.h:33-36; unused by the library)
+vector<double> origin_at(Vector2d& point, double& cell_side);
+// glir_pso_optimization (reference core.h:21-23, marked "UNTESTED" there and never called) is not provided.
 
 #endif

@@ -26,3 +26,10 @@ Vector2d laser_to_point(float r, float theta) {
   const double t = double(theta);
   return Vector2d(double(r) * std::cos(t), double(r) * std::sin(t));
 }
+
+vector<double> origin_at(Vector2d& point, double& cell_side) {
+  vector<double> corner(2);
+  corner[0] = std::floor(point.x() / cell_side) * cell_side;
+  corner[1] = std::floor(point.y() / cell_side) * cell_side;
+  return corner;
+}
