@@ -53,8 +53,12 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NDTPSO_BENCH_FORCE_DIST=1: take the RCCL path (process group, all_gather, barriers) even with one rank --
+    # lets a single-GPU box exercise the code the multi-GPU runs use
+    use_dist = world > 1 or os.environ.get("NDTPSO_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from ndtpso_slam_amd import capi, sharding, synth
@@ -89,13 +93,13 @@ def main():
         ctx.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(),
                             cfg, d_seeds.data_ptr(), 0, mode, d_pose.data_ptr(), d_cost.data_ptr(),
                             d_stats.data_ptr())
-        if world > 1:
-            sharding.gather_poses(d_pose, equal_sizes=True)  # the single RCCL gather of poses over xGMI
+        if use_dist:
+            sharding.gather_poses(d_pose, equal_sizes=True, force=True)  # the single RCCL gather of poses over xGMI
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
@@ -108,14 +112,14 @@ def main():
                             cfg, d_seeds.data_ptr(), 0, mode, d_pose.data_ptr(), d_cost.data_ptr(),
                             d_stats.data_ptr())
         ev[k][1].record(stream)
-        if world > 1:
-            sharding.gather_poses(d_pose, equal_sizes=True)
+        if use_dist:
+            sharding.gather_poses(d_pose, equal_sizes=True, force=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -212,8 +216,8 @@ def main():
         out["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -17,10 +17,11 @@ def shard_range(n_total: int, rank: int, world: int) -> tuple[int, int]:
     return first, first + base + (1 if rank < rem else 0)
 
 
-def gather_poses(local: torch.Tensor, group=None, equal_sizes: bool = False) -> torch.Tensor:
+def gather_poses(local: torch.Tensor, group=None, equal_sizes: bool = False, force: bool = False) -> torch.Tensor:
     """all_gather of per-rank [n_i, 3] pose tensors -> [sum n_i, 3] in pair order (every rank gets it).
-    equal_sizes=True skips the size exchange (every rank holds the same number of pairs): ONE collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    equal_sizes=True skips the size exchange (every rank holds the same number of pairs): ONE collective.
+    force=True issues the collective even in a one-rank group (exercises the backend)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return local
     world = dist.get_world_size(group)
     if equal_sizes:
