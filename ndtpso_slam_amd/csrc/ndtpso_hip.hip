@@ -243,6 +243,14 @@ k_scan_to_cells(const float* __restrict__ ranges, ScanP sp, int do_trans, double
   if (threadIdx.x == 0) out_n[0] = (uint32_t)n;
 }
 
+// int8_t(p * 100.) as the reference's x86-64 build evaluates it (ndtframe.cpp:105): cvttsd2si to 32 bits -- which
+// yields INT_MIN for NaN and for values outside int32, where the GPU's conversion saturates -- then the low byte.
+// Only matters for the garbage Gaussians a resetCells can leave behind (p = inf), but those are reproduced too.
+__device__ __forceinline__ int8_t x86_int8_of(double v) {
+  const int32_t i = (v > -2147483649. && v < 2147483648.) ? (int32_t)v : INT32_MIN;
+  return (int8_t)(uint8_t)((uint32_t)i & 0xffu);
+}
+
 // ---- occupancy-grid values of built cells (NDTFrame::build, ndtframe.cpp:79-112) ----------------------------
 __global__ void __launch_bounds__(256)
 k_occupancy_values(int n_cells, int per_cell, double og_cs, double hw, double hh, int W, int H,
@@ -262,7 +270,7 @@ k_occupancy_values(int n_cells, int per_cell, double og_cs, double hw, double hh
   const double r0 = d0 * ic.x + d1 * ic.z;
   const double r1 = d0 * ic.y + d1 * ic.w;
   const double p = exp(-(r0 * d0 + r1 * d1) / 2.);
-  values[t] = (p > 0.) ? (int8_t)(p * 100.) : (int8_t)-1;
+  values[t] = (p > 0.) ? x86_int8_of(p * 100.) : (int8_t)-1;
 }
 
 // ---- K3d: NDTCell::build with sliding-window state, one thread per created cell (ndtcell.cpp:36-68,93-111) ----

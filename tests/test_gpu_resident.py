@@ -242,3 +242,80 @@ def _glibc_rand(seed, n):
     for i in range(34, 344 + n):
         r[i] = (r[i - 31] + r[i - 3]) & 0xFFFFFFFF
     return np.array([v >> 1 for v in r[344:344 + n]], dtype=np.int32)
+
+
+@pytest.mark.parametrize("seed,frame_w,frame_h,cs,ogcs", [(1, 20, 12, 0.7, 0.2), (2, 12, 20, 1.0, 0.5), (3, 16, 16, 0.5, 0.0)])
+def test_resident_map_random_operation_sequences(ctx, oracle, seed, frame_w, frame_h, cs, ogcs):
+    """Differential fuzz of the resident map against the oracle's NDTFrame: random sequences of addPoint batches
+    (empty, single, several tiles, points on cell edges and frame borders), updates with a pose, builds, alignments
+    (which build lazily), resetCells -- on non-square frames and a cell side that is not a power of two.  After every
+    build the cells' observable state must be identical; at the end every stored point and the occupancy grid too."""
+    from ndtpso_slam_amd import capi
+    rng = np.random.default_rng(seed)
+    grid = capi.Grid(frame_w, frame_h, cs)
+    rmap = capi.ResidentMap(ctx, grid, og_cell_size=ogcs, pool_bytes=32 << 20)
+    ref = oracle.Frame((0, 0, 0), frame_w, frame_h, cs)
+    if ogcs > 0:
+        ref.enable_occupancy_grid(ogcs)
+    scan = capi.ResidentScan(ctx, 4096)
+    hw, hh = frame_w / 2, frame_h / 2
+    cfg, ocfg = capi.PSOConfig.make(6, 9), oracle.PSOConfig.make(6, 9)
+
+    def cloud(n):
+        xy = np.stack([rng.uniform(-hw * 1.1, hw * 1.1, n), rng.uniform(-hh * 1.1, hh * 1.1, n)], axis=1)
+        if n:
+            k = rng.integers(0, n, size=max(1, n // 9))
+            xy[k] = np.round(xy[k] / cs) * cs                 # exactly on cell edges / frame borders
+            xy[rng.integers(0, n, size=max(1, n // 5))] *= 0.2   # a dense centre: cells that rotate
+        return xy
+
+    n_builds = n_aligns = 0
+    for it in range(140):
+        op = rng.choice(["add", "add", "update", "build", "align", "reset"], p=[.3, .2, .2, .15, .1, .05])
+        if op in ("add", "update"):
+            n = int(rng.choice([0, 1, 2, 7, 64, 300, 1024, 1025, 2500]))
+            xy = cloud(n)
+            pose = None if op == "add" else rng.uniform(-1, 1, 3) * (0.3, 0.3, 0.2)
+            rmap.insert_host(xy, pose)
+            if pose is not None and n:
+                c, s = np.cos(pose[2]), np.sin(pose[2])
+                xy = np.stack([xy[:, 0] * c - xy[:, 1] * s + pose[0], xy[:, 0] * s + xy[:, 1] * c + pose[1]], axis=1)
+            for q in xy:
+                ref.add_point(q[0], q[1])
+        elif op == "build":
+            rmap.build()
+            ref.build()
+            n_builds += 1
+            _compare_cells(rmap.cells(), ref.cells())
+        elif op == "align":
+            new_xy = cloud(200) * 0.5
+            new = oracle.Frame((0, 0, 0), frame_w, frame_h, float(max(frame_w, frame_h)))
+            for q in new_xy:
+                new.add_point(q[0], q[1])
+            new_xy = new.points()
+            if len(new_xy) == 0:
+                continue
+            scan.set(new_xy)
+            table = oracle.glibc_rand(int(rng.integers(1, 1 << 30)), 3 + 3 * 9 + 6 * 9 * 6)
+            got, cost, _ = rmap.align(scan, (0, 0, 0), (.2, .2, .05), cfg, rand_table=table, mode=capi.SCORE_F64)
+            want, want_cost, _ = ref.pso((0, 0, 0), new, (.2, .2, .05), ocfg, table=table)
+            # (after a resetCells the window's stale partial terms can make a covariance indefinite and a cost infinite --
+            # in the reference too; equal infinities count as equal)
+            assert np.abs(got - want).max() < 1e-9, (it, got, want)
+            assert cost == want_cost or abs(cost - want_cost) < 1e-9 * max(1.0, abs(want_cost)), (it, cost, want_cost)
+            n_aligns += 1
+            _compare_cells(rmap.cells(), ref.cells())
+        else:
+            rmap.reset()
+            ref.reset_cells()
+    rmap.build()
+    ref.build()
+    _compare_cells(rmap.cells(), ref.cells())
+    assert np.array_equal(rmap.points(), ref.points_all())
+    if ogcs > 0:
+        og, w, h, ext = rmap.occupancy()
+        want, ww, wh, mm = ref.occupancy_grid()
+        assert (w, h, ext) == (ww, wh, mm)
+        d = np.abs(og.astype(int) - want.astype(int))
+        assert d.max() <= 1 and (d > 0).sum() <= max(2, 0.01 * (want != 0).sum())
+    assert rmap.info()["status"] & 1 == 0 and n_builds > 5 and n_aligns > 3
