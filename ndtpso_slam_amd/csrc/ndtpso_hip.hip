@@ -382,13 +382,15 @@ k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict_
 }
 
 // ---- K2 --------------------------------------------------------------------------------------
-template <int MODE, int PATH>
+// CLUSTER: gridDim.x workgroups share this one alignment (see ClusterP in ndtpso_kernels.hpp)
+template <int MODE, int PATH, bool CLUSTER>
 __global__ void __launch_bounds__(1024)
 k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n,
         const uint32_t* __restrict__ n_ptr, GridP g, WinP wn, Layout L, DenseP dn, PsoP ps,
         const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
         const int32_t* __restrict__ table, unsigned char* __restrict__ ws, double* __restrict__ out_pose,
-        double* __restrict__ out_cost, AlignStats* __restrict__ stats) {
+        double* __restrict__ out_cost, AlignStats* __restrict__ stats, ClusterP cl) {
+  cl.rank = (int)blockIdx.x;
   if (n_ptr) n = min((int)*n_ptr, n);  // the point count lives on the device (resident scan); n is its capacity
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   stage_image<MODE, PATH>(image, g, wn, L, dn);
@@ -397,11 +399,12 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   __syncthreads();
   const EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
   const Swarm sw = swarm_carve(L.swarm_global ? ws : g_lds + L.region_off, ps.P);
-  pso_run_wg<MODE, PATH>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost, stats);
-  if (threadIdx.x == 0 && stats) {
+  pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost,
+                                  stats, cl);
+  if (threadIdx.x == 0 && stats && cl.rank == 0) {
     const ImageHeader* h = reinterpret_cast<const ImageHeader*>(g_lds + L.hdr_off);
     stats->n_built = h->n_built;
-    stats->status = (stats->status & kStatusNeedsF64) | h->status;
+    stats->status = (stats->status & (kStatusNeedsF64 | kStatusClusterTimeout)) | h->status;
   }
 }
 
@@ -547,7 +550,7 @@ struct ndtpso_ctx {
   GridP g{};
   WinP wn{};
   uint32_t n_rows = 0;
-  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate;
+  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster;
   PinnedRing pinned;
 };
 
@@ -757,7 +760,8 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
 #define COMMA ,
   BIG_PATHS(k_cost_batch, COMMA false)
   BIG_PATHS(k_cost_batch, COMMA true)
-  BIG_PATHS(k_align)
+  BIG_PATHS(k_align, COMMA false)
+  BIG_PATHS(k_align, COMMA true)
   BIG_PATHS(k_align_pairs)
 #define GLOBAL_PATHS(K, ...)                                                   \
   if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 4 __VA_ARGS__>);         \
@@ -766,7 +770,8 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   if (e == hipSuccess) e = allow_big_lds(K<kScoreF64, 5 __VA_ARGS__>);
   GLOBAL_PATHS(k_cost_batch, COMMA false)
   GLOBAL_PATHS(k_cost_batch, COMMA true)
-  GLOBAL_PATHS(k_align)
+  GLOBAL_PATHS(k_align, COMMA false)
+  GLOBAL_PATHS(k_align, COMMA true)
 #undef GLOBAL_PATHS
 #undef COMMA
 #undef BIG_PATHS
@@ -784,7 +789,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
-                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate})
+                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate, &c->cluster})
     b->release();
   c->pinned.release();
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1161,8 +1166,22 @@ struct AlignSrc {
   const uint32_t* n_ptr;
 };
 
+// How many workgroups share one alignment (cluster mode, see ClusterP).  One item per wave and round: enough waves
+// for the whole swarm (P + 1 items in the first round), 4 per workgroup (one per SIMD) for small swarms, 8 for larger
+// ones, at most 32 workgroups -- the shapes scripts/cluster_sweep.py found fastest (30 x 50: 8 x 4 waves, 0.43 ms vs
+// 0.63 ms on one workgroup; 70 x 70: 0.64 ms vs 1.49 ms).  NDTPSO_CLUSTER=0 keeps a lone alignment on one
+// workgroup, =K forces K workgroups; NDTPSO_CLUSTER_WAVES sets the waves per workgroup.
+static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw) {
+  *K = 1;
+  *cw = (P + 1 <= 32) ? 4 : 8;
+  if (const char* e = std::getenv("NDTPSO_CLUSTER_WAVES")) *cw = std::min(16, std::max(1, std::atoi(e)));
+  int k = std::min(32, (P + 1 + *cw - 1) / *cw);
+  if (const char* e = std::getenv("NDTPSO_CLUSTER")) k = std::min(32, std::max(0, std::atoi(e)));
+  if (allow && swarm_in_lds && k >= 2) *K = k;
+}
+
 static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
-                      int mode, double host[4 + sizeof(AlignStats) / 8]) {
+                      int mode, double host[4 + sizeof(AlignStats) / 8], bool allow_cluster = true) {
   Plan plan;
   const uint32_t n = src.n;
   if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true))
@@ -1172,14 +1191,27 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
   HIP_TRY(c, hipMemsetAsync(c->out.p, 0, 256, c->stream));
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population)));
-  const int waves = pick_waves(cfg->population, L.total, 1);
-  const PsoP ps = make_pso(cfg, waves);
-#define LAUNCH_ALIGN(MODE, PATH)                                                                                   \
-  hipLaunchKernelGGL((k_align<MODE, PATH>), dim3(1), dim3(waves * 64), L.total, c->stream,                         \
+  int K, cw;
+  cluster_shape(cfg->population, !L.swarm_global, allow_cluster, &K, &cw);
+  const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
+  PsoP ps = make_pso(cfg, waves);
+  ClusterP cl{K, 0, 0, nullptr, nullptr};
+  if (K > 1) {
+    ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
+    cl.stride = round_up(cfg->population + 1, 8);
+    HIP_TRY(c, c->cluster.reserve(64 + (size_t)2 * cl.stride * 8));
+    HIP_TRY(c, hipMemsetAsync(c->cluster.p, 0, 64, c->stream));
+    cl.bar = (unsigned*)c->cluster.p;
+    cl.xc = (double*)((unsigned char*)c->cluster.p + 64);
+  }
+#define LAUNCH_ALIGN_C(MODE, PATH, CL)                                                                             \
+  hipLaunchKernelGGL((k_align<MODE, PATH, CL>), dim3(K), dim3(waves * 64), L.total, c->stream,                     \
                      src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
                      ps, (const double*)c->small.p, (const double*)c->small.p + 3, seed,                           \
                      have_table ? (const int32_t*)c->table.p : nullptr, (unsigned char*)c->ws.p, d_out, d_out + 3, \
-                     d_stats)
+                     d_stats, cl)
+#define LAUNCH_ALIGN(MODE, PATH) \
+  do { if (K > 1) LAUNCH_ALIGN_C(MODE, PATH, true); else LAUNCH_ALIGN_C(MODE, PATH, false); } while (0)
   if (mode == NDTPSO_SCORE_F32) {
     switch (plan.path) {
       case 2: LAUNCH_ALIGN(kScoreF32, 2); break;
@@ -1197,9 +1229,16 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     }
   }
 #undef LAUNCH_ALIGN
+#undef LAUNCH_ALIGN_C
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(host, c->out.p, (4 + sizeof(AlignStats) / 8) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (K > 1) {
+    AlignStats st;
+    std::memcpy(&st, host + 4, sizeof(st));
+    if (st.status & kStatusClusterTimeout)  // the cluster was not co-resident (device shared with other work): one workgroup
+      return align_once(c, src, cfg, seed, have_table, mode, host, false);
+  }
   return NDTPSO_OK;
 }
 

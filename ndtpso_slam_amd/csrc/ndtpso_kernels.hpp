@@ -946,6 +946,7 @@ struct PsoShared {  // small control block in LDS
   double gbc;
   int jstar[3];  // first improver of a group, rotating by group number (see pso_run_wg)
   int tiny;      // fp32 score mode: some cost of the current group fell in the underflow regime
+  int timed_out; // cluster mode: a workgroup of the cluster did not arrive at an exchange
   RngState rng;
 };
 
@@ -1056,12 +1057,83 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
   }
 }
 
+// ---- one alignment on several compute units ("cluster") --------------------------------------------------------
+//
+// A lone alignment (the live node, BASELINE config 2) is bounded by the VALU of the one CU its workgroup runs on.
+// K workgroups can share it: every one of them holds the table, the points and the WHOLE swarm and runs the
+// identical control flow (proposals, commits, replays -- deterministic, so the K copies never diverge); only the
+// cost evaluations of a round are divided, one item per wave across all K x waves waves.  After evaluating, the
+// workgroups publish their costs (agent-scope stores into xc[round parity][item]), meet at a counter barrier and
+// read all costs of the round back; first-improver / underflow detection then runs locally on identical data.
+// Per-item arithmetic is the single-workgroup kernel's, so the results are bit-identical to it.
+// Measured price of one exchange on MI355X (scripts/ubench_cluster_barrier.hip): 1.4-1.7 us for K = 4..16.
+// The wait is bounded by the real-time counter: a workgroup that never arrives (cluster not co-resident) raises
+// kStatusClusterTimeout and the host reruns the alignment on one workgroup.
+struct ClusterP {
+  int K, rank, stride;  // workgroups, this one's index, doubles per exchange buffer
+  unsigned* bar;        // arrival counter, zeroed before the launch
+  double* xc;           // [2][stride] exchanged costs
+};
+constexpr uint32_t kStatusClusterTimeout = 16u;
+constexpr unsigned long long kClusterWaitTicks = 20000000ull;  // 0.2 s of the 100 MHz counter
+
+// Evaluates items [first, last) of the swarm; on return (after the caller's barrier) sw.tcost holds their costs and
+// *improver / *tiny are set as eval_items sets them.  `epoch` counts the cluster's exchanges.
+template <int MODE, int PATH, bool CLUSTER>
+__device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first, int last,
+                                  double gbc, int* improver, int* tiny, const ClusterP& cl, unsigned& epoch,
+                                  int* timed_out) {
+  if constexpr (!CLUSTER) {
+    eval_items<MODE, PATH>(E, pts, n, sw, S, first, last, gbc, improver, tiny);
+  } else {
+    const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
+    double* buf = cl.xc + (size_t)(epoch & 1u) * cl.stride;
+    for (int j = first + cl.rank * n_waves + wave_id(); j < last; j += total_waves) {
+      const double c = sw.tc[j], s = sw.ts[j];
+      const double tx = sw.tpos[j], ty = sw.tpos[S + j];
+      double cost;
+      if constexpr (PATH == 2)
+        cost = eval_pose_wave_dense<false>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
+      else
+        cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+      if (lane_id() == 0) __hip_atomic_store(&buf[j], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      __threadfence();
+      atomicAdd(cl.bar, 1u);
+      const unsigned want = (unsigned)cl.K * (epoch + 1u);
+      const unsigned long long t0 = wall_clock64();
+      while (__hip_atomic_load(cl.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (wall_clock64() - t0 > kClusterWaitTicks) {
+          *timed_out = 1;
+          break;
+        }
+      }
+      __threadfence();
+    }
+    __syncthreads();
+    for (int j = first + (int)threadIdx.x; j < last; j += blockDim.x) {
+      const double cost = __hip_atomic_load(&buf[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sw.tcost[j] = cost;
+      if (MODE == kScoreF32 && cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))
+        *tiny = 1;
+      else if (improver && cost < gbc)
+        atomicMin(improver, j);
+    }
+    ++epoch;
+  }
+}
+
 // returns false when the alignment was abandoned for the fp64-score kernel (fp32 underflow regime)
-template <int MODE, int PATH>
+template <int MODE, int PATH, bool CLUSTER = false>
 __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
-                                  PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats) {
+                                  PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats,
+                                  const ClusterP& cl = ClusterP{1, 0, 0, nullptr, nullptr}) {
+  unsigned epoch = 0;
+  const bool writer = !CLUSTER || cl.rank == 0;  // the workgroup that reports the result
   const int tid = threadIdx.x;
   const int P = ps.P, S = P + 1;
   const bool gen = (table == nullptr);
@@ -1069,7 +1141,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   uint32_t n_evals = 0, n_rounds = 0, n_gb = 0;
 
   // ---- swarm initialisation: core.cpp:58-69 ----
-  if (tid == 0) sh->tiny = 0;
+  if (tid == 0) sh->tiny = sh->timed_out = 0;
   if (gen && wave_id() == 0) {
     rng_seed_wave0(&sh->rng, seed);
     rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 3 * S);
@@ -1095,12 +1167,16 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     }
   }
   __syncthreads();
-  eval_items<MODE, PATH>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny);
+  eval_round<MODE, PATH, CLUSTER>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out);
   n_evals += S;
   n_rounds += 1;
   __syncthreads();
+  if (CLUSTER && sh->timed_out) {
+    if (tid == 0 && stats && writer) stats->status |= kStatusClusterTimeout;
+    return false;
+  }
   if (MODE == kScoreF32 && sh->tiny) {  // underflow regime: give up, the fp64-score kernel redoes this alignment
-    if (tid == 0 && stats) stats->status |= kStatusNeedsF64;
+    if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
     return false;
   }
   if (tid == 0) {
@@ -1179,19 +1255,26 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       // priority; the turn comes from the shared 100 MHz real-time counter (5 us slices), so the two are
       // complementary at all times, and the later-dispatched one gets 9 of 16 slices, which is what equalises
       // their finishing times.
-      if ((((unsigned)(wall_clock64() >> 9) & 15u) < 9u) == (blockIdx.x >= (gridDim.x >> 1)))
-        __builtin_amdgcn_s_setprio(1);
-      else
-        __builtin_amdgcn_s_setprio(0);
+      if constexpr (!CLUSTER) {
+        if ((((unsigned)(wall_clock64() >> 9) & 15u) < 9u) == (blockIdx.x >= (gridDim.x >> 1)))
+          __builtin_amdgcn_s_setprio(1);
+        else
+          __builtin_amdgcn_s_setprio(0);
+      }
 #endif
       const int slot = (int)(grp % 3u);
       const int hi_g = min(lo + ps.G, P);
-      eval_items<MODE, PATH>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny);
+      eval_round<MODE, PATH, CLUSTER>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
+                                      &sh->timed_out);
       n_evals += (uint32_t)(hi_g - lo);
       n_rounds += 1;
       __syncthreads();
+      if (CLUSTER && sh->timed_out) {
+        if (tid == 0 && stats && writer) stats->status |= kStatusClusterTimeout;
+        return false;
+      }
       if (MODE == kScoreF32 && sh->tiny) {
-        if (tid == 0 && stats) stats->status |= kStatusNeedsF64;
+        if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
         return false;
       }
       const int js = sh->jstar[slot];
@@ -1230,7 +1313,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     w *= ps.wdamp;  // core.cpp:108
   }
 
-  if (tid == 0) {
+  if (tid == 0 && writer) {
     for (int k = 0; k < 3; ++k) out_pose[k] = sh->gb[k];  // core.cpp:115
     if (out_cost) *out_cost = sh->gbc;
     if (stats) {
