@@ -415,14 +415,23 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
 // PATH 2 sizes its staging window per alignment (bounding box of the occupied cells, `dense_cap` table
 // entries provisioned); a box that does not fit flags kStatusNeedsBitmap and leaves the alignment to the
 // bitmap-form kernel, whose window is the static range box.
-template <int MODE, int PATH>
+// CLUSTER (small batches: fewer alignments than compute units): cl.K consecutive workgroups share alignment
+// blockIdx.x / K -- each of them ingests both scans and builds the table for itself (identical arithmetic, so the
+// copies agree), then the PSO runs as a cluster (ClusterP).  Never combined with a gate.
+template <int MODE, int PATH, bool CLUSTER>
 __global__ void __launch_bounds__(1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
               const double* __restrict__ dev, const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables,
               size_t table_stride, unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
-              double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate) {
-  const size_t b = blockIdx.x;
+              double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl) {
+  const size_t b = CLUSTER ? blockIdx.x / (unsigned)cl.K : blockIdx.x;
+  if constexpr (CLUSTER) {
+    cl.rank = (int)(blockIdx.x % (unsigned)cl.K);
+    cl.bar += b * 16;
+    cl.xc += b * 2 * (size_t)cl.stride;
+  }
+  const bool writer = !CLUSTER || cl.rank == 0;
   if (gate && !(stats[b].status & gate)) return;
   const uint32_t t_start = (uint32_t)wall_clock64();
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
@@ -438,8 +447,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     dn.ox = wn.x0 - 1;
     dn.oy = wn.y0 - 1;
     dense_set_limits(dn, g.hw, g.hh, g.inv_cs);
-    if (dense_entries(dn.dw, dn.dh) > dense_cap) {  // uniform
-      if (threadIdx.x == 0) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
+    if (dense_entries(dn.dw, dn.dh) > dense_cap) {  // uniform (and the same in every workgroup of a cluster)
+      if (threadIdx.x == 0 && writer) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
       return;
     }
   }
@@ -455,11 +464,11 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
 
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
   const Swarm sw = swarm_carve(L.swarm_global ? ws + b * ws_stride : g_lds + L.region_off, ps.P);
-  if (threadIdx.x == 0) stats[b].status &= ~gate;
-  pso_run_wg<MODE, PATH>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                         tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off), out_pose + 3 * b,
-                         out_cost ? out_cost + b : nullptr, stats + b);
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
+  pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                                  tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
+                                  out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+  if (threadIdx.x == 0 && writer) {
     stats[b].n_built = hdr->n_built;
     stats[b].status |= hdr->status;
     stats[b].t_start = t_start;
@@ -550,6 +559,7 @@ struct ndtpso_ctx {
   GridP g{};
   WinP wn{};
   uint32_t n_rows = 0;
+  int n_cus = 256;  // compute units of the device (multiProcessorCount)
   DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster;
   PinnedRing pinned;
 };
@@ -749,6 +759,10 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
     return NDTPSO_E_HIP;
   }
   c->stream = c->own_stream;
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cus = cus;
+  }
   hipError_t e = hipSuccess;
   if (e == hipSuccess) e = allow_big_lds(k_build_table);
 #define BIG_PATHS(K, ...)                                                      \
@@ -762,7 +776,8 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   BIG_PATHS(k_cost_batch, COMMA true)
   BIG_PATHS(k_align, COMMA false)
   BIG_PATHS(k_align, COMMA true)
-  BIG_PATHS(k_align_pairs)
+  BIG_PATHS(k_align_pairs, COMMA false)
+  BIG_PATHS(k_align_pairs, COMMA true)
 #define GLOBAL_PATHS(K, ...)                                                   \
   if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 4 __VA_ARGS__>);         \
   if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 5 __VA_ARGS__>);         \
@@ -1176,9 +1191,13 @@ static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw)
   *cw = (P + 1 <= 32) ? 4 : 8;
   if (const char* e = std::getenv("NDTPSO_CLUSTER_WAVES")) *cw = std::min(16, std::max(1, std::atoi(e)));
   int k = std::min(32, (P + 1 + *cw - 1) / *cw);
+  if (P + 1 <= 16) k = 0;  // one workgroup already has a wave per item
   if (const char* e = std::getenv("NDTPSO_CLUSTER")) k = std::min(32, std::max(0, std::atoi(e)));
   if (allow && swarm_in_lds && k >= 2) *K = k;
 }
+// a cluster must bring at least twice the waves of one 16-wave workgroup to pay for its exchanges (measured:
+// scripts/small_batch_check.py); forced shapes (NDTPSO_CLUSTER) are taken as given
+static bool cluster_worthwhile(int K, int cw) { return std::getenv("NDTPSO_CLUSTER") != nullptr || K * cw >= 32; }
 
 static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
                       int mode, double host[4 + sizeof(AlignStats) / 8], bool allow_cluster = true) {
@@ -1339,7 +1358,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
                         const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess, const double* d_dev,
                         const ndtpso_pso_config* cfg, const uint32_t* d_seeds, const int32_t* d_tables, int mode,
                         double* d_pose, double* d_cost, AlignStats* d_stats, uint32_t gate, bool allow_dense,
-                        int* path_out) {
+                        int* path_out, bool allow_cluster = false) {
   GridP g;
   WinP wn;
   Plan plan;
@@ -1349,20 +1368,40 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
   const ScanP sp = make_scan(geom);
-  const PsoP ps = make_pso(cfg, waves);
+  // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
+  int K = 1, cw = 4;
+  cluster_shape(cfg->population, !plan.L.swarm_global, allow_cluster && gate == 0, &K, &cw);
+  if (K > 1) K = std::min<int>(K, c->n_cus / (int)std::min<uint32_t>(n_pairs, (uint32_t)c->n_cus));
+  if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
+  if (K > 1) waves = cw;
+  PsoP ps = make_pso(cfg, waves);
+  ClusterP cl{K, 0, 0, nullptr, nullptr};
+  if (K > 1) {
+    ps.G = std::min(std::max(cfg->population, 1), K * waves);
+    cl.stride = round_up(cfg->population + 1, 8);
+    const size_t bars = 64 * (size_t)n_pairs;
+    HIP_TRY(c, c->cluster.reserve(bars + (size_t)n_pairs * 2 * cl.stride * 8));
+    HIP_TRY(c, hipMemsetAsync(c->cluster.p, 0, bars, c->stream));
+    cl.bar = (unsigned*)c->cluster.p;
+    cl.xc = (double*)((unsigned char*)c->cluster.p + bars);
+  }
   const size_t stride = ndtpso_rand_draws(cfg);
   const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population) : 0;
   if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs));
-#define LAUNCH_PAIRS(MODE, PATH)                                                                                  \
-  hipLaunchKernelGGL((k_align_pairs<MODE, PATH>), dim3(n_pairs), dim3(waves * 64), plan.L.total, c->stream, d_ref,  \
-                     d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev, d_seeds, d_tables,     \
-                     stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate)
+#define LAUNCH_PAIRS_C(MODE, PATH, CL)                                                                            \
+  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL>), dim3(n_pairs * (unsigned)K), dim3(waves * 64), plan.L.total, \
+                     c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
+                     d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
+                     cl)
+#define LAUNCH_PAIRS(MODE, PATH) \
+  do { if (K > 1) LAUNCH_PAIRS_C(MODE, PATH, true); else LAUNCH_PAIRS_C(MODE, PATH, false); } while (0)
   if (mode == NDTPSO_SCORE_F32) {
     if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
   } else {
     if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
   }
 #undef LAUNCH_PAIRS
+#undef LAUNCH_PAIRS_C
   HIP_TRY(c, hipGetLastError());
   return NDTPSO_OK;
 }
@@ -1384,10 +1423,17 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
   }
   HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(AlignStats) * (size_t)n_pairs, c->stream));
   int path = 0;
+  const bool small_batch = n_pairs * 2u <= (uint32_t)c->n_cus;
   int rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
-                        st, 0u, true, &path);
-  if (rc != NDTPSO_OK || mode != NDTPSO_SCORE_F32) return rc;
+                        st, 0u, true, &path, small_batch);
+  if (rc != NDTPSO_OK) return rc;
   if (std::getenv("NDTPSO_NO_REDO")) return rc;  // diagnostics only
+  if (small_batch) {  // a cluster that was not co-resident gave up (bounded wait): those alignments on one workgroup each
+    rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
+                      st, kStatusClusterTimeout, true, nullptr);
+    if (rc != NDTPSO_OK) return rc;
+  }
+  if (mode != NDTPSO_SCORE_F32) return rc;
   // Gated redo launches (every workgroup whose alignment is not flagged exits on its first instruction):
   //  - dense form only: alignments whose occupied box exceeded the provisioned cell table -> bitmap form;
   //  - alignments whose fp32 costs fell in the underflow regime (degenerate overlap) -> fp64 score.

@@ -427,3 +427,39 @@ def test_map_larger_than_lds_is_served_from_hbm(ctx, oracle):
     got, cost, st = rmap.align(scan, (0, 0, 0), DEVIATION, capi.PSOConfig.make(I, P), rand_table=table, mode=capi.SCORE_F64)
     assert st["n_built"] == n_cells and np.abs(got - want).max() < 1e-9 and abs(cost - want_cost) < 1e-9
     assert np.abs(want - truth).max() < 2e-2
+
+
+def test_cluster_of_workgroups_matches_one_workgroup(ctx, oracle, pairs8, monkeypatch):
+    """A lone alignment is spread over several compute units (cluster mode of k_align: replicated control flow, the
+    evaluations of a round divided one item per wave, costs exchanged per round).  Whatever the cluster's shape the
+    pose, the cost and the number of gbest updates are those of the one-workgroup kernel, bit for bit."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    grid = _grid(capi)
+    for b, (P, I) in enumerate(((30, 50), (70, 70), (3, 5), (97, 9))):
+        xy = ctx.scan_to_points(p.new_ranges[b], _geom(p, capi))
+        ctx.ref_from_scan(grid, p.ref_ranges[b], _geom(p, capi))
+        cfg = capi.PSOConfig.make(I, P)
+        table = oracle.glibc_rand(int(p.seeds[b]), 3 + 3 * P + 6 * P * I)
+        for mode in (capi.SCORE_F32, capi.SCORE_F64):
+            for kw in (dict(rand_table=table), dict(seed=int(p.seeds[b]))):     # host table / device replay of rand()
+                monkeypatch.setenv("NDTPSO_CLUSTER", "0")
+                want = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, mode=mode, **kw)
+                for shape in (None, ("2", "1"), ("5", "3"), ("32", "4"), ("7", "16")):
+                    if shape is None:
+                        monkeypatch.delenv("NDTPSO_CLUSTER")
+                        monkeypatch.delenv("NDTPSO_CLUSTER_WAVES", raising=False)
+                    else:
+                        monkeypatch.setenv("NDTPSO_CLUSTER", shape[0])
+                        monkeypatch.setenv("NDTPSO_CLUSTER_WAVES", shape[1])
+                    got = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, mode=mode, **kw)
+                    assert np.array_equal(got[0], want[0]) and got[1] == want[1], (P, I, mode, shape)
+                    assert got[2]["gbest_updates"] == want[2]["gbest_updates"] and got[2]["status"] == want[2]["status"]
+                monkeypatch.delenv("NDTPSO_CLUSTER_WAVES", raising=False)
+        if (P, I) == (30, 50):
+            o = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, CELL_SIDE)
+            o.load_laser(p.ref_ranges[b], p.angle_min, p.angle_inc, p.range_max)
+            n = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+            n.load_laser(p.new_ranges[b], p.angle_min, p.angle_inc, p.range_max)
+            opose, _, _ = o.pso((0, 0, 0), n, DEVIATION, oracle.PSOConfig.make(I, P), table=table)
+            assert np.abs(want[0] - opose).max() < 1e-3
