@@ -391,6 +391,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
         const int32_t* __restrict__ table, unsigned char* __restrict__ ws, double* __restrict__ out_pose,
         double* __restrict__ out_cost, AlignStats* __restrict__ stats, ClusterP cl) {
   cl.rank = (int)blockIdx.x;
+  if (CLUSTER && cl.rank == cl.absent) return;
   if (n_ptr) n = min((int)*n_ptr, n);  // the point count lives on the device (resident scan); n is its capacity
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   stage_image<MODE, PATH>(image, g, wn, L, dn);
@@ -432,6 +433,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     cl.xc += b * 2 * (size_t)cl.stride;
   }
   const bool writer = !CLUSTER || cl.rank == 0;
+  if (CLUSTER && cl.rank == cl.absent) return;
   if (gate && !(stats[b].status & gate)) return;
   const uint32_t t_start = (uint32_t)wall_clock64();
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
@@ -1195,6 +1197,12 @@ static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw)
   if (const char* e = std::getenv("NDTPSO_CLUSTER")) k = std::min(32, std::max(0, std::atoi(e)));
   if (allow && swarm_in_lds && k >= 2) *K = k;
 }
+// NDTPSO_CLUSTER_TEST_ABSENT=r (tests only): rank r of every cluster leaves immediately, so the others run into the
+// bounded wait and the one-workgroup rerun is exercised
+static int cluster_test_absent() {
+  const char* e = std::getenv("NDTPSO_CLUSTER_TEST_ABSENT");
+  return e ? std::atoi(e) : -1;
+}
 // a cluster must bring at least twice the waves of one 16-wave workgroup to pay for its exchanges (measured:
 // scripts/small_batch_check.py); forced shapes (NDTPSO_CLUSTER) are taken as given
 static bool cluster_worthwhile(int K, int cw) { return std::getenv("NDTPSO_CLUSTER") != nullptr || K * cw >= 32; }
@@ -1214,7 +1222,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   cluster_shape(cfg->population, !L.swarm_global, allow_cluster, &K, &cw);
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves);
-  ClusterP cl{K, 0, 0, nullptr, nullptr};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
     cl.stride = round_up(cfg->population + 1, 8);
@@ -1375,7 +1383,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   if (K > 1) waves = cw;
   PsoP ps = make_pso(cfg, waves);
-  ClusterP cl{K, 0, 0, nullptr, nullptr};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);
     cl.stride = round_up(cfg->population + 1, 8);

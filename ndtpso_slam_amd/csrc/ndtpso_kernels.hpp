@@ -1071,6 +1071,7 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
 // kStatusClusterTimeout and the host reruns the alignment on one workgroup.
 struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, doubles per exchange buffer
+  int absent;           // test hook: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout
   unsigned* bar;        // arrival counter, zeroed before the launch
   double* xc;           // [2][stride] exchanged costs
 };
@@ -1131,7 +1132,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
                                   PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats,
-                                  const ClusterP& cl = ClusterP{1, 0, 0, nullptr, nullptr}) {
+                                  const ClusterP& cl = ClusterP{1, 0, 0, -1, nullptr, nullptr}) {
   unsigned epoch = 0;
   const bool writer = !CLUSTER || cl.rank == 0;  // the workgroup that reports the result
   const int tid = threadIdx.x;

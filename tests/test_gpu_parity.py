@@ -463,3 +463,37 @@ def test_cluster_of_workgroups_matches_one_workgroup(ctx, oracle, pairs8, monkey
             n.load_laser(p.new_ranges[b], p.angle_min, p.angle_inc, p.range_max)
             opose, _, _ = o.pso((0, 0, 0), n, DEVIATION, oracle.PSOConfig.make(I, P), table=table)
             assert np.abs(want[0] - opose).max() < 1e-3
+
+
+def test_small_batches_cluster_and_timeout_fallback(ctx, oracle, pairs8, monkeypatch):
+    """Batches smaller than the device run K workgroups per pair; the poses equal those of one workgroup per pair.
+    A cluster that is not complete (test hook: one rank leaves at once) gives up after its bounded wait and the
+    alignment is redone on one workgroup -- same results, no hang."""
+    import time
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    cfg = capi.PSOConfig.make(40, 33)
+
+    def run(sel, mode):
+        return ctx.align_pairs(p.ref_ranges[sel], p.new_ranges[sel], _geom(p, capi), _grid(capi), (0, 0, 0), DEVIATION,
+                               cfg, seeds=p.seeds[sel], mode=mode)
+    for mode in (capi.SCORE_F32, capi.SCORE_F64):
+        monkeypatch.setenv("NDTPSO_CLUSTER", "0")
+        want = run(np.arange(8), mode)
+        monkeypatch.delenv("NDTPSO_CLUSTER")
+        for sel in (np.arange(1), np.arange(3), np.arange(8)):
+            got = run(sel, mode)
+            assert np.array_equal(got[0], want[0][sel]) and np.array_equal(got[1], want[1][sel])
+            assert (got[2]["status"] == 0).all()
+    xy = ctx.scan_to_points(p.new_ranges[0], _geom(p, capi))
+    ctx.ref_from_scan(_grid(capi), p.ref_ranges[0], _geom(p, capi))
+    want_one = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, seed=int(p.seeds[0]))
+    monkeypatch.setenv("NDTPSO_CLUSTER_TEST_ABSENT", "1")
+    t0 = time.perf_counter()
+    got = run(np.arange(2), capi.SCORE_F32)
+    got_one = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, seed=int(p.seeds[0]))
+    waited = time.perf_counter() - t0
+    monkeypatch.delenv("NDTPSO_CLUSTER_TEST_ABSENT")
+    assert np.array_equal(got[0], want[0][:2]) and (got[2]["status"] == 0).all()
+    assert np.array_equal(got_one[0], want_one[0]) and got_one[1] == want_one[1]
+    assert 0.3 < waited < 5.0          # two bounded waits of 0.2 s, then the reruns
