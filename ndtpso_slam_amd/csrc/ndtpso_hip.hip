@@ -102,6 +102,9 @@ DenseP make_dense(const GridP& g, const WinP& wn, const Layout& L) {
 
 static_assert(sizeof(PsoShared) + 32 * sizeof(int) <= kCtrlBytes, "control block too small");
 
+// cluster kernels run at most 8 waves per workgroup (cluster_shape), which leaves each wave 256 VGPRs
+constexpr int kClusterMaxThreads = 512;
+
 extern __shared__ __attribute__((aligned(16))) unsigned char g_lds[];
 
 __device__ __forceinline__ PsoShared* lds_ctrl(int ctrl_off) { return reinterpret_cast<PsoShared*>(g_lds + ctrl_off); }
@@ -384,7 +387,7 @@ k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict_
 // ---- K2 --------------------------------------------------------------------------------------
 // CLUSTER: gridDim.x workgroups share this one alignment (see ClusterP in ndtpso_kernels.hpp)
 template <int MODE, int PATH, bool CLUSTER>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
 k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n,
         const uint32_t* __restrict__ n_ptr, GridP g, WinP wn, Layout L, DenseP dn, PsoP ps,
         const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
@@ -420,7 +423,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
 // blockIdx.x / K -- each of them ingests both scans and builds the table for itself (identical arithmetic, so the
 // copies agree), then the PSO runs as a cluster (ClusterP).  Never combined with a gate.
 template <int MODE, int PATH, bool CLUSTER>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
               const double* __restrict__ dev, const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables,
@@ -1191,7 +1194,7 @@ struct AlignSrc {
 static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw) {
   *K = 1;
   *cw = (P + 1 <= 32) ? 4 : 8;
-  if (const char* e = std::getenv("NDTPSO_CLUSTER_WAVES")) *cw = std::min(16, std::max(1, std::atoi(e)));
+  if (const char* e = std::getenv("NDTPSO_CLUSTER_WAVES")) *cw = std::min(kClusterMaxThreads / 64, std::max(1, std::atoi(e)));
   int k = std::min(32, (P + 1 + *cw - 1) / *cw);
   if (P + 1 <= 16) k = 0;  // one workgroup already has a wave per item
   if (const char* e = std::getenv("NDTPSO_CLUSTER")) k = std::min(32, std::max(0, std::atoi(e)));

@@ -374,7 +374,10 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
     t[u] = __builtin_amdgcn_exp2f(-fmaf(a, a, fmaf(b, b, f[u].w)));  // null record: w = +inf -> 0
   }
   // the U terms (each in [0,1]) are summed in fp32 first, then folded into the fp64 lane accumulator
-  if constexpr (U == 4)
+  if constexpr (U == 8) {  // two groups of four in flight together, folded in the order two U = 4 trips would be
+    acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));
+    acc[0] += (double)((t[4] + t[5]) + (t[6] + t[7]));
+  } else if constexpr (U == 4)
     acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));
   else if constexpr (U == 2)
     acc[0] += (double)(t[0] + t[1]);
@@ -393,7 +396,9 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   }
 }
 
-template <bool DUMP, bool CLIP>
+// WIDE: a wave that has its SIMD to itself (cluster mode) keeps eight chunks in flight instead of four to cover the
+// LDS latency; the terms are folded in exactly the order of the U = 4 loop, so the sum is the same bit for bit.
+template <bool DUMP, bool CLIP, bool WIDE = false>
 __device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                          const double2* __restrict__ pts, int n, double c, double s,
                                                          double tx, double ty, int32_t* __restrict__ dump) {
@@ -402,17 +407,20 @@ __device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const D
   double acc[4] = {0., 0., 0., 0.};  // the dense trips fold their U terms in fp32 and use acc[0] only
   const int n_pad = round_up(n, kWave);
   int base = 0;
+  if constexpr (WIDE && U == 4 && !DUMP)
+    for (; base + 8 * kWave <= n_pad; base += 8 * kWave)
+      score_trip_dense<8, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
   for (; base + U * kWave <= n_pad; base += U * kWave)
     score_trip_dense<U, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
   for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
   return -wave_sum(acc[0]);
 }
-template <bool DUMP>
+template <bool DUMP, bool WIDE = false>
 __device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                        const double2* __restrict__ pts, int n, double c, double s,
                                                        double tx, double ty, int32_t* __restrict__ dump) {
-  if (dn.clip) return eval_pose_wave_dense_c<DUMP, true>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
-  return eval_pose_wave_dense_c<DUMP, false>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
+  if (dn.clip) return eval_pose_wave_dense_c<DUMP, true, WIDE>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
+  return eval_pose_wave_dense_c<DUMP, false, WIDE>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
 }
 
 // pts must be padded to a multiple of kPointPad with out-of-frame sentinels (pad_points_wg)
@@ -1069,6 +1077,24 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
 // Measured price of one exchange on MI355X (scripts/ubench_cluster_barrier.hip): 1.4-1.7 us for K = 4..16.
 // The wait is bounded by the real-time counter: a workgroup that never arrives (cluster not co-resident) raises
 // kStatusClusterTimeout and the host reruns the alignment on one workgroup.
+// NDTPSO_PROFILE_PHASES (diagnostic builds only): thread 0 of rank 0 accumulates the real-time-counter ticks between
+// the marks of a cluster round and prints them at the end: [other -> 0] control, [0 -> 1] evaluation, [1 -> 2]
+// exchange, [2 -> 3] read-back and detection
+#ifdef NDTPSO_PROFILE_PHASES
+__device__ unsigned long long g_phase_ticks[4];
+__device__ unsigned long long g_phase_last;
+#define NDTPSO_PHASE_MARK(k)                                                            \
+  do {                                                                                  \
+    if (threadIdx.x == 0 && cl.rank == 0) {                                             \
+      const unsigned long long now__ = wall_clock64();                                  \
+      g_phase_ticks[k] += now__ - g_phase_last;                                         \
+      g_phase_last = now__;                                                             \
+    }                                                                                   \
+  } while (0)
+#else
+#define NDTPSO_PHASE_MARK(k) do { } while (0)
+#endif
+
 struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, doubles per exchange buffer
   int absent;           // test hook: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout
@@ -1087,6 +1113,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
   if constexpr (!CLUSTER) {
     eval_items<MODE, PATH>(E, pts, n, sw, S, first, last, gbc, improver, tiny);
   } else {
+    NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
     double* buf = cl.xc + (size_t)(epoch & 1u) * cl.stride;
     for (int j = first + cl.rank * n_waves + wave_id(); j < last; j += total_waves) {
@@ -1094,12 +1121,13 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       double cost;
       if constexpr (PATH == 2)
-        cost = eval_pose_wave_dense<false>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
+        cost = eval_pose_wave_dense<false, true>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
       else
         cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
       if (lane_id() == 0) __hip_atomic_store(&buf[j], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
+    NDTPSO_PHASE_MARK(1);
     if (threadIdx.x == 0) {
       __threadfence();
       atomicAdd(cl.bar, 1u);
@@ -1114,6 +1142,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
       __threadfence();
     }
     __syncthreads();
+    NDTPSO_PHASE_MARK(2);
     for (int j = first + (int)threadIdx.x; j < last; j += blockDim.x) {
       const double cost = __hip_atomic_load(&buf[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       sw.tcost[j] = cost;
@@ -1123,6 +1152,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
         atomicMin(improver, j);
     }
     ++epoch;
+    NDTPSO_PHASE_MARK(3);
   }
 }
 
@@ -1314,6 +1344,13 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     w *= ps.wdamp;  // core.cpp:108
   }
 
+#ifdef NDTPSO_PROFILE_PHASES
+  if (CLUSTER && tid == 0 && cl.rank == 0) {
+    printf("cluster phases (us): control %.1f eval %.1f exchange %.1f readback %.1f  rounds %u\n", g_phase_ticks[0] * 0.01,
+           g_phase_ticks[1] * 0.01, g_phase_ticks[2] * 0.01, g_phase_ticks[3] * 0.01, n_rounds);
+    g_phase_ticks[0] = g_phase_ticks[1] = g_phase_ticks[2] = g_phase_ticks[3] = 0;
+  }
+#endif
   if (tid == 0 && writer) {
     for (int k = 0; k < 3; ++k) out_pose[k] = sh->gb[k];  // core.cpp:115
     if (out_cost) *out_cost = sh->gbc;
