@@ -195,6 +195,14 @@ def main():
             lat.append(a.elapsed_time(b))
         out["extra"]["single_pair_latency_ms"] = float(np.median(lat))
 
+    # the node's live sequence: loadLaser -> align -> update against an accumulating resident map,
+    # default 30 x 50 PSO, rand() table from the host as the drop-in library passes it; rank 0 only, 60 scans
+    if rank == 0 and not args.no_latency:
+        try:
+            out["extra"]["live_sequence"] = _live_sequence(ctx, capi, synth, mode)
+        except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench run fails
+            out["extra"]["live_sequence"] = {"error": str(e)}
+
     # CPU baseline: the oracle (a port of the reference's algorithm) on a bounded sample, host cores of this box
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         from oracle import pyoracle
@@ -220,6 +228,43 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _live_sequence(ctx, capi, synth, mode, n_scans=60):
+    """Scans per second of the per-scan sequence of ndtpso_slam_node (ndtpso_slam_node.cpp:177-244) with the map, its
+    sliding windows and the scans resident on the device (ndtpso_map_* / ndtpso_points_*)."""
+    rng = np.random.default_rng(4)
+    s = np.linspace(0.0, 0.6, n_scans)
+    poses = np.stack([2.0 + 1.2 * s, -1.0 + 0.8 * np.sin(1.5 * s), 0.3 + 0.25 * s], axis=1)
+    clean = synth.raycast(poses)
+    ranges = np.where(clean > 0, clean + rng.normal(0, 0.01, clean.shape), 0.0).astype(np.float32)
+    geom = capi.ScanGeom(synth.N_BEAMS, float(synth.ANGLE_MIN), float(synth.ANGLE_INC), float(synth.RANGE_MAX), 0.1)
+    grid = capi.Grid(FRAME_M, FRAME_M, CELL_SIDE)
+    cfg = capi.PSOConfig.make(50, 30)
+    n_draw = 3 + 3 * 30 + 6 * 30 * 50
+    tables = np.random.default_rng(5).integers(0, 2**31 - 1, size=(n_scans, n_draw), dtype=np.int64).astype(np.int32)
+    rmap = capi.ResidentMap(ctx, grid, og_cell_size=0.1, pool_bytes=256 << 20)
+    scan = capi.ResidentScan(ctx, 4096)
+    prev = np.zeros(3)
+    hist = [np.zeros(3), np.zeros(3)]
+    t0 = None
+    for k in range(n_scans):
+        if k == 1:
+            ctx.synchronize()
+            t0 = time.perf_counter()
+        scan.load_scan(ranges[k], geom, clip=grid)
+        if k > 0:
+            dev = np.array(DEVIATION) if k <= 2 else np.abs(2.0 * (hist[-1] - hist[-2]))   # ndtframe.cpp:253
+            prev, _, _ = rmap.align(scan, prev, dev, cfg, rand_table=tables[k], mode=mode)
+            hist.append(prev.copy())
+        rmap.insert(scan, prev)
+    ctx.synchronize()
+    dt = (time.perf_counter() - t0) / (n_scans - 1)
+    info = rmap.info()
+    rmap.close()
+    scan.close()
+    return {"scans_per_s": 1.0 / dt, "ms_per_scan": 1e3 * dt, "pso": "30 x 50", "scans": n_scans,
+            "map_cells_built": int(info["n_built"]), "through": "ctypes binding (host/replay/node_replay.cpp is the C++ equivalent)"}
 
 
 def _valu_roof(stats, kern_ms):

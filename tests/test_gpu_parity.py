@@ -485,6 +485,12 @@ def test_small_batches_cluster_and_timeout_fallback(ctx, oracle, pairs8, monkeyp
             got = run(sel, mode)
             assert np.array_equal(got[0], want[0][sel]) and np.array_equal(got[1], want[1][sel])
             assert (got[2]["status"] == 0).all()
+        # the std::rand() tables handed over by the host instead of the device replaying srand(seed)
+        n_draw = 3 + 3 * 33 + 6 * 33 * 40
+        tables = np.stack([oracle.glibc_rand(int(sd), n_draw) for sd in p.seeds[:3]])
+        got = ctx.align_pairs(p.ref_ranges[:3], p.new_ranges[:3], _geom(p, capi), _grid(capi), (0, 0, 0), DEVIATION, cfg,
+                              rand_tables=tables, mode=mode)
+        assert np.array_equal(got[0], want[0][:3]) and np.array_equal(got[1], want[1][:3])
     xy = ctx.scan_to_points(p.new_ranges[0], _geom(p, capi))
     ctx.ref_from_scan(_grid(capi), p.ref_ranges[0], _geom(p, capi))
     want_one = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, seed=int(p.seeds[0]))
