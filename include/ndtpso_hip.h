@@ -142,8 +142,10 @@ typedef struct {
 } ndtpso_cell_window;
 
 /* NDTCell::build + s_calc_covar_inverse for n_cells created cells at once (NDTFrame::build's loop,
- * ndtframe.cpp:73-76).  pts_offset[n_cells+1] delimits each cell's CURRENT-slot points (insertion order) in
- * pts_xy; cells[] is updated in place.  The slot advance (ndtcell.cpp:61-65) is bookkeeping left to the host. */
+ * ndtframe.cpp:73-76).  pts_offset[n_cells+1] delimits each cell's points_vector[s_current_window_id] (insertion
+ * order) in pts_xy -- with current_count == 0 these are the stale points of the window's previous lap, which the
+ * reference's covariance loop still visits (ndtcell.cpp:49) while its running sum is zero; cells[] is updated in
+ * place.  The slot advance (ndtcell.cpp:61-65) is bookkeeping left to the host. */
 int ndtpso_cells_build_windowed(ndtpso_ctx *ctx, uint32_t n_cells, ndtpso_cell_window *cells,
                                 const uint32_t *pts_offset, const double *pts_xy);
 

@@ -290,12 +290,16 @@ k_cells_build_windowed(CellWindow* __restrict__ cells, int n_cells, const uint32
   if (c >= n_cells) return;
   CellWindow w = cells[c];
   const uint32_t p0 = off[c], p1 = off[c + 1];
-  // s_current_partial_sum: running sum of the current slot's points in insertion order (ndtcell.cpp:30)
+  // s_current_partial_sum: running sum, in insertion order, of the points added since the last rotation
+  // (ndtcell.cpp:30,61-65).  Those are the slot's whole point vector -- except right after a rotation onto a slot
+  // that still holds the points of the previous lap of the window (the vector is only cleared by the next addPoint,
+  // ndtcell.cpp:22-27): then the sum is zero while the covariance below still runs over the stale points.
   double cx = 0., cy = 0.;
-  for (uint32_t i = p0; i < p1; ++i) {
-    cx += pts[i].x;
-    cy += pts[i].y;
-  }
+  if (w.current_count > 0)
+    for (uint32_t i = p0; i < p1; ++i) {
+      cx += pts[i].x;
+      cy += pts[i].y;
+    }
   // WINDOW_ADD (ndtcell.h:13-15): global = (global + partial) - partials[idx]; partials[idx] = partial
   w.global_sum[0] = (w.global_sum[0] + cx) - w.slot_sum[0];
   w.global_sum[1] = (w.global_sum[1] + cy) - w.slot_sum[1];

@@ -223,3 +223,52 @@ def test_frame_api_resident_and_host_frames_agree(tmp_path, oracle):
     assert abs(float(lines["cost"][0]) - want_cost) <= 1e-9 * abs(want_cost)
     pose, _, _ = a.pso((0, 0, 0), b, (.1, .1, 3.1415e-3), oracle.PSOConfig.make(25, 20), seed=5)
     assert np.abs(np.array([float(v) for v in lines["pso"]]) - pose).max() < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_node_replay_through_window_wrap_around(tmp_path, oracle, resident):
+    """A long replay on coarse cells: the busiest cells rotate through all 100 window slots and start reusing them
+    (stale points of the previous lap still feed the covariance, the running sum restarts at zero, ndtcell.cpp:22-27,
+    49, 61-65).  Both kinds of frames must follow the oracle pose by pose."""
+    from ndtpso_slam_amd import synth
+    _build()
+    n_scans, P, I, seed, cs = 420, 8, 6, 5, 2.0
+    s = np.linspace(0.0, 1.0, n_scans)
+    poses = np.stack([4.0 * np.cos(2 * np.pi * s), 3.0 * np.sin(2 * np.pi * s), 2 * np.pi * s + np.pi / 2], axis=1)
+    rng = np.random.default_rng(6)
+    clean = synth.raycast(poses)
+    ranges = np.where(clean > 0, clean + rng.normal(0, 0.01, clean.shape), 0.0).astype(np.float32)
+    path = tmp_path / "scans.bin"
+    with open(path, "wb") as f:
+        np.array([n_scans, synth.N_BEAMS], dtype=np.int32).tofile(f)
+        np.array([synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX], dtype=np.float32).tofile(f)
+        ranges.tofile(f)
+    out = subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs), str(I),
+                                   str(P), str(seed)], text=True,
+                                  env=dict(os.environ, NDTPSO_SCORE="f64", NDTPSO_ALIGN_FRAME_CONFIG="1",
+                                           NDTPSO_RESIDENT=resident))
+    got = np.array([[float(v) for v in line.split()[1:]] for line in out.strip().splitlines()])
+    cfg = oracle.PSOConfig.make(I, P)
+    n_draw = 3 + 3 * P + 6 * P * I
+    stream = oracle.glibc_rand(seed, n_draw * n_scans)
+    ref = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, cs)
+    prev = np.zeros(3)
+    want = []
+    n_inserted = 0
+    for k in range(n_scans):
+        cur = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+        cur.load_laser(ranges[k], synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX)
+        pose = prev.copy() if k == 0 else ref.align(prev, cur, cfg, table=stream[(k - 1) * n_draw:k * n_draw])
+        prev = pose
+        ref.update(pose, cur)
+        n_inserted += len(cur.points())        # (all inside the frame here)
+        want.append(pose)
+    want = np.array(want)
+    laps = max(c["slot"] for c in ref.cells())
+    ref.build()
+    assert len(ref.points_all()) < n_inserted      # reused slots dropped the points of their previous lap
+    d = np.abs(got - want)
+    first = np.nonzero(d.max(axis=1) > 0)[0]
+    print("window wrap replay: max |dpose| %.3e, first differing scan %s, busiest cell at slot %d" % (d.max(), first[:1], laps))
+    assert d.max() < 1e-9
