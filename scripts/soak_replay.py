@@ -20,7 +20,7 @@ outs = {}
 for tag, env in (("resident+cluster", {}), ("resident, one WG", {"NDTPSO_CLUSTER": "0"}), ("host frames", {"NDTPSO_RESIDENT": "0"})):
     t = time.time()
     r = subprocess.run(['host/replay/node_replay', '/tmp/soak.bin', '60', '0.5', '50', '30', '7', '0.1', '/tmp/soak_' + tag.split()[0].strip(','), '5'],
-                       capture_output=True, text=True, env=dict(os.environ, NDTPSO_SCORE="f64", **env))
+                       capture_output=True, text=True, env=dict(os.environ, NDTPSO_SCORE=os.environ.get("SOAK_SCORE", "f64"), **env))
     outs[tag] = np.array([[float(v) for v in l.split()[1:]] for l in r.stdout.strip().splitlines()])
     print(tag, r.stderr.strip().splitlines()[-1], "wall %.1f s" % (time.time() - t), "final pose", outs[tag][-1])
 base = outs["host frames"]
