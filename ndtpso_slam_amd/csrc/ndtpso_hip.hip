@@ -399,6 +399,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
         double* __restrict__ out_cost, AlignStats* __restrict__ stats, ClusterP cl) {
   cl.rank = (int)blockIdx.x;
   if (CLUSTER && cl.rank == cl.absent) return;
+  if (threadIdx.x == 0 && cl.rank == 0 && stats) *stats = AlignStats{0, 0, 0, 0, 0, 0, 0, 0};  // only this workgroup writes it
   if (n_ptr) n = min((int)*n_ptr, n);  // the point count lives on the device (resident scan); n is its capacity
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   stage_image<MODE, PATH>(image, g, wn, L, dn);
@@ -520,6 +521,12 @@ struct PinnedRing {
   bool busy[kSlots] = {false, false, false, false};
   int next = 0;
   hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t stream) {
+    return upload2(dst, src, bytes, 0, nullptr, 0, stream);
+  }
+  // two host buffers, one transfer: [a | padding up to b_offset | b]
+  hipError_t upload2(void* dst, const void* a, size_t a_bytes, size_t b_offset, const void* b, size_t b_bytes,
+                     hipStream_t stream) {
+    const size_t bytes = b_bytes ? b_offset + b_bytes : a_bytes;
     const int k = next;
     next = (next + 1) % kSlots;
     hipError_t e = hipSuccess;
@@ -540,7 +547,8 @@ struct PinnedRing {
       if (e != hipSuccess) return e;
       cap[k] = bytes;
     }
-    std::memcpy(host[k], src, bytes);
+    std::memcpy(host[k], a, a_bytes);
+    if (b_bytes) std::memcpy((unsigned char*)host[k] + b_offset, b, b_bytes);
     e = hipMemcpyAsync(dst, host[k], bytes, hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return e;
     busy[k] = true;
@@ -569,7 +577,8 @@ struct ndtpso_ctx {
   WinP wn{};
   uint32_t n_rows = 0;
   int n_cus = 256;  // compute units of the device (multiProcessorCount)
-  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster;
+  size_t cluster_next = 0;  // next unused arrival counter of the ring in `cluster`
+  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster, cluster_xc;
   PinnedRing pinned;
 };
 
@@ -813,7 +822,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
-                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate, &c->cluster})
+                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate, &c->cluster, &c->cluster_xc})
     b->release();
   c->pinned.release();
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1179,6 +1188,9 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
 
 // ---- K2 ------------------------------------------------------------------------------------------
 
+// c->table of a single alignment: [guess, deviation (6 doubles, padded to 64 bytes) | std::rand() table]
+constexpr size_t kGuessBytes = 64;
+
 // where one alignment's inputs live on the device: table image + its grid/window, new-frame points (count known
 // to the host, or only an upper bound with the count itself on the device)
 struct AlignSrc {
@@ -1204,6 +1216,26 @@ static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw)
   if (const char* e = std::getenv("NDTPSO_CLUSTER")) k = std::min(32, std::max(0, std::atoi(e)));
   if (allow && swarm_in_lds && k >= 2) *K = k;
 }
+// Arrival counters of the clusters of one launch (64 bytes each) and their exchange buffers.  The counters come from a
+// pre-zeroed ring and are used once, so a launch needs no memset of its own; the ring is re-zeroed when it wraps.
+static int cluster_counters(ndtpso_ctx* c, size_t n_counters, size_t xc_bytes, unsigned** bar, double** xc) {
+  constexpr size_t kRing = 4096;  // counters in the ring (256 KiB)
+  if (n_counters > kRing) return fail(c, NDTPSO_E_ARG, "too many clusters in one launch");
+  if (c->cluster.cap < kRing * 64) {
+    HIP_TRY(c, c->cluster.reserve(kRing * 64));
+    c->cluster_next = kRing;  // forces the zeroing below
+  }
+  if (c->cluster_next + n_counters > kRing) {
+    HIP_TRY(c, hipMemsetAsync(c->cluster.p, 0, kRing * 64, c->stream));
+    c->cluster_next = 0;
+  }
+  *bar = (unsigned*)((unsigned char*)c->cluster.p + c->cluster_next * 64);
+  c->cluster_next += n_counters;
+  HIP_TRY(c, c->cluster_xc.reserve(xc_bytes));
+  *xc = (double*)c->cluster_xc.p;
+  return NDTPSO_OK;
+}
+
 // NDTPSO_CLUSTER_TEST_ABSENT=r (tests only): rank r of every cluster leaves immediately, so the others run into the
 // bounded wait and the one-workgroup rerun is exercised
 static int cluster_test_absent() {
@@ -1223,7 +1255,6 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   const Layout& L = plan.L;
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
-  HIP_TRY(c, hipMemsetAsync(c->out.p, 0, 256, c->stream));
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population)));
   int K, cw;
   cluster_shape(cfg->population, !L.swarm_global, allow_cluster, &K, &cw);
@@ -1233,17 +1264,16 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
     cl.stride = round_up(cfg->population + 1, 8);
-    HIP_TRY(c, c->cluster.reserve(64 + (size_t)2 * cl.stride * 8));
-    HIP_TRY(c, hipMemsetAsync(c->cluster.p, 0, 64, c->stream));
-    cl.bar = (unsigned*)c->cluster.p;
-    cl.xc = (double*)((unsigned char*)c->cluster.p + 64);
+    unsigned* bar = nullptr;
+    if (int rc = cluster_counters(c, 1, (size_t)2 * cl.stride * 8, &bar, &cl.xc)) return rc;
+    cl.bar = bar;
   }
 #define LAUNCH_ALIGN_C(MODE, PATH, CL)                                                                             \
   hipLaunchKernelGGL((k_align<MODE, PATH, CL>), dim3(K), dim3(waves * 64), L.total, c->stream,                     \
                      src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
-                     ps, (const double*)c->small.p, (const double*)c->small.p + 3, seed,                           \
-                     have_table ? (const int32_t*)c->table.p : nullptr, (unsigned char*)c->ws.p, d_out, d_out + 3, \
-                     d_stats, cl)
+                     ps, (const double*)c->table.p, (const double*)c->table.p + 3, seed,                           \
+                     have_table ? (const int32_t*)((const unsigned char*)c->table.p + kGuessBytes) : nullptr,      \
+                     (unsigned char*)c->ws.p, d_out, d_out + 3, d_stats, cl)
 #define LAUNCH_ALIGN(MODE, PATH) \
   do { if (K > 1) LAUNCH_ALIGN_C(MODE, PATH, true); else LAUNCH_ALIGN_C(MODE, PATH, false); } while (0)
   if (mode == NDTPSO_SCORE_F32) {
@@ -1289,13 +1319,11 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t n_draw = ndtpso_rand_draws(cfg);
   HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
-  HIP_TRY(c, c->small.reserve(256));
   HIP_TRY(c, c->out.reserve(256));
-  if (rand_table) HIP_TRY(c, c->table.reserve(n_draw * 4));
+  HIP_TRY(c, c->table.reserve(kGuessBytes + (rand_table ? n_draw * 4 : 0)));
   if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   double gd[6] = {guess[0], guess[1], guess[2], deviation[0], deviation[1], deviation[2]};
-  HIP_TRY(c, hipMemcpyAsync(c->small.p, gd, sizeof(gd), hipMemcpyHostToDevice, c->stream));
-  if (rand_table) HIP_TRY(c, hipMemcpyAsync(c->table.p, rand_table, n_draw * 4, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, c->pinned.upload2(c->table.p, gd, sizeof(gd), kGuessBytes, rand_table, rand_table ? n_draw * 4 : 0, c->stream));
   const AlignSrc src{(const unsigned char*)c->image.p, c->g, c->wn, (const double2*)c->xy2.p, n, nullptr};
   return align_finish(c, src, cfg, seed, rand_table != nullptr, mode, out_pose, out_cost, stats);
 }
@@ -1394,11 +1422,9 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);
     cl.stride = round_up(cfg->population + 1, 8);
-    const size_t bars = 64 * (size_t)n_pairs;
-    HIP_TRY(c, c->cluster.reserve(bars + (size_t)n_pairs * 2 * cl.stride * 8));
-    HIP_TRY(c, hipMemsetAsync(c->cluster.p, 0, bars, c->stream));
-    cl.bar = (unsigned*)c->cluster.p;
-    cl.xc = (double*)((unsigned char*)c->cluster.p + bars);
+    unsigned* bar = nullptr;
+    if (int rc = cluster_counters(c, n_pairs, (size_t)n_pairs * 2 * cl.stride * 8, &bar, &cl.xc)) return rc;
+    cl.bar = bar;
   }
   const size_t stride = ndtpso_rand_draws(cfg);
   const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population) : 0;
