@@ -77,6 +77,75 @@ void release_scan(ndtpso_points* p, uint32_t capacity) {
     ndtpso_points_destroy(p);
 }
 
+// ---- std::rand() in bulk ------------------------------------------------------------------------------------------
+// One alignment consumes 3 + 3P + 6PI outputs of std::rand() (9093 at the default 30 x 50) -- Eigen's Random() in the
+// reference, core.cpp:14,84.  Through rand() that is 80 us of call + lock overhead per scan, a sixth of the live
+// path.  glibc's generator (TYPE_3 additive feedback: r[i] = r[i-31] + r[i-3], output >> 1) keeps its state in a plain
+// int32 array that setstate() hands out, with the rear index stored in the word in front of it; so the state is
+// advanced in place here, n steps at once, and handed back.  The result is indistinguishable from n calls of rand():
+// same outputs, same state afterwards.  A self-test on a private state (the caller's stream is not touched) decides
+// once whether this glibc behaves as expected; otherwise, and for generator types other than TYPE_3, rand() is called.
+namespace {
+#if defined(__GLIBC__)
+constexpr int kRandTypes = 5, kRandType3 = 3, kRandDeg = 31, kRandSep = 3;
+
+bool fast_fill(int32_t* out, size_t n) {
+  static char scratch[128];
+  static bool scratch_ready = false;
+  if (!scratch_ready) {  // a valid state to park the generator on while its real state is edited
+    char* prev = initstate(1u, scratch, sizeof(scratch));
+    setstate(prev);
+    scratch_ready = true;
+  }
+  int32_t* w = reinterpret_cast<int32_t*>(setstate(scratch));  // w[0]: type + 5 * rear, w[1..31]: the table
+  if (!w) return false;
+  const int type = w[0] % kRandTypes;
+  if (type != kRandType3) {
+    setstate(reinterpret_cast<char*>(w));
+    return false;
+  }
+  uint32_t* t = reinterpret_cast<uint32_t*>(w + 1);
+  int r = w[0] / kRandTypes, f = (r + kRandSep) % kRandDeg;
+  for (size_t i = 0; i < n; ++i) {
+    t[f] += t[r];
+    out[i] = (int32_t)(t[f] >> 1);
+    if (++f == kRandDeg) f = 0;
+    if (++r == kRandDeg) r = 0;
+  }
+  w[0] = r * kRandTypes + kRandType3;
+  setstate(reinterpret_cast<char*>(w));
+  return true;
+}
+
+bool fast_fill_verified() {
+  static const bool ok = [] {
+    if (const char* e = std::getenv("NDTPSO_SLOW_RAND"))
+      if (e[0] == '1') return false;
+    static char a[128], b[128];
+    constexpr int kN = 200;
+    int32_t want[kN], got[kN];
+    char* user = initstate(20240521u, a, sizeof(a));  // the caller's state is parked, untouched
+    for (int i = 0; i < kN; ++i) want[i] = std::rand();
+    const int32_t want_next = std::rand();
+    initstate(20240521u, b, sizeof(b));
+    bool good = fast_fill(got, kN);
+    for (int i = 0; good && i < kN; ++i) good = got[i] == want[i];
+    good = good && std::rand() == want_next;  // the state after the bulk draw continues the same stream
+    setstate(user);
+    return good;
+  }();
+  return ok;
+}
+#endif
+}  // namespace
+
+void draw_rand(int32_t* out, size_t n) {
+#if defined(__GLIBC__)
+  if (fast_fill_verified() && fast_fill(out, n)) return;
+#endif
+  for (size_t i = 0; i < n; ++i) out[i] = std::rand();
+}
+
 int score_mode() {
   const char* e = std::getenv("NDTPSO_SCORE");
   return (e && std::strcmp(e, "f64") == 0) ? NDTPSO_SCORE_F64 : NDTPSO_SCORE_F32;

@@ -428,7 +428,7 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
     }
     const ndtpso_pso_config abi = to_abi(cfg);
     std::vector<int32_t> draws(ndtpso_rand_draws(&abi));
-    for (int32_t& d : draws) d = std::rand();
+    ndtpso_host::draw_rand(draws.data(), draws.size());
     const double g[3] = {guess.x(), guess.y(), guess.z()};
     const double dv[3] = {deviation.x(), deviation.y(), deviation.z()};
     double pose[3] = {0., 0., 0.};
@@ -444,7 +444,7 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
   new_frame->collectPoints(xy);
   const ndtpso_pso_config abi = to_abi(cfg);
   std::vector<int32_t> draws(ndtpso_rand_draws(&abi));
-  for (int32_t& d : draws) d = std::rand();
+  ndtpso_host::draw_rand(draws.data(), draws.size());
   const double g[3] = {guess.x(), guess.y(), guess.z()};
   const double dv[3] = {deviation.x(), deviation.y(), deviation.z()};
   double pose[3] = {0., 0., 0.};

@@ -32,6 +32,17 @@ def test_host_library_exports_reference_api():
     assert "libndtpso_hip.so" in needed
 
 
+def test_bulk_rand_draw_is_indistinguishable_from_rand():
+    """host/replay/rand_check.cpp: the bulk draw of the std::rand() stream (glibc state advanced in place) gives the
+    outputs of n rand() calls and leaves the generator where they would; also with the slow path forced."""
+    _build()
+    exe = os.path.join(HOST, "replay", "rand_check")
+    out = subprocess.check_output([exe], text=True)
+    assert out.startswith("ok:"), out
+    out = subprocess.check_output([exe], text=True, env=dict(os.environ, NDTPSO_SLOW_RAND="1"))
+    assert out.startswith("ok:"), out
+
+
 def _trajectory(n_scans, seed=4):
     from ndtpso_slam_amd import synth
     rng = np.random.default_rng(seed)
