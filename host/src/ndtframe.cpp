@@ -219,6 +219,10 @@ void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
       new_frame->collectPoints(pts);
       ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), pose), "update");
     }
+    // A frame that is aligned against gets its cells built and its table packed right away, off the next align()'s
+    // critical path; should something other than align / build come first, the device takes the build back
+    // (ndtpso_map_speculate_build), so the lazy build of the reference is what every caller still observes.
+    if (s_iter > 0) ndtpso_host::check(ndtpso_map_speculate_build(m), "update");
     return;
   }
   std::vector<double> xy;
@@ -409,10 +413,7 @@ void NDTFrame::uploadTable() {
 Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, const Vector3d& deviation,
                             const PSOConfig& cfg) {
   if (s_resident) {
-    ndtpso_map* m = ensureMap();
-    // cost_function's lazy build (core.cpp:27-28), enqueued now so that the device works through the pending insert
-    // and the build while the host draws the random numbers below
-    if (!built) build();
+    ndtpso_map* m = ensureMap();  // ndtpso_map_align builds first if need be (cost_function's lazy build, core.cpp:27-28)
     const ndtpso_points* pts = nullptr;
     ndtpso_points* tmp = nullptr;
     uint32_t tmp_cap = 0;

@@ -219,6 +219,12 @@ int ndtpso_map_clear(ndtpso_map *map); /* back to a freshly constructed frame */
 int ndtpso_map_insert(ndtpso_map *map, const ndtpso_points *pts, const double pose[3]);
 int ndtpso_map_insert_host(ndtpso_map *map, const double *xy, uint32_t n, const double pose[3]);
 int ndtpso_map_build(ndtpso_map *map);
+/* Builds the cells and packs the alignment table NOW, ahead of the ndtpso_map_align (or ndtpso_map_build) that will ask
+ * for them, so that they are off that call's critical path -- without changing what any call observes: everything the
+ * build overwrites is logged, and an insert / reset / export arriving first puts the map back before it runs (the
+ * reference builds lazily, core.cpp:27-28; a frame that is only ever updated is never built).  The occupancy grid is
+ * rasterised when the speculation is committed.  A caller uses it after NDTFrame::update on a frame it aligns against. */
+int ndtpso_map_speculate_build(ndtpso_map *map);
 int ndtpso_map_align(ndtpso_map *map, const ndtpso_points *new_points, const double guess[3], const double deviation[3],
                      const ndtpso_pso_config *cfg, uint32_t seed, const int32_t *rand_table, int score_mode,
                      double out_pose[3], double *out_cost, ndtpso_align_stats *stats);

@@ -92,7 +92,7 @@ EXPORTS = [
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
     "ndtpso_points_create", "ndtpso_points_destroy", "ndtpso_points_load_scan", "ndtpso_points_set", "ndtpso_points_get",
     "ndtpso_map_create", "ndtpso_map_destroy", "ndtpso_map_reset", "ndtpso_map_clear", "ndtpso_map_insert", "ndtpso_map_insert_host",
-    "ndtpso_map_build", "ndtpso_map_align", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
+    "ndtpso_map_build", "ndtpso_map_speculate_build", "ndtpso_map_align", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
     "ndtpso_map_get_occupancy",
 ]
 
@@ -158,6 +158,7 @@ def load(build_if_missing: bool = True):
     L.ndtpso_map_insert.argtypes = [vp, vp, dp]
     L.ndtpso_map_insert_host.argtypes = [vp, dp, C.c_uint32, dp]
     L.ndtpso_map_build.argtypes = [vp]
+    L.ndtpso_map_speculate_build.argtypes = [vp]
     L.ndtpso_map_align.argtypes = [vp, vp, dp, dp, C.POINTER(PSOConfig), C.c_uint32, ip, C.c_int, dp, dp,
                                    C.POINTER(AlignStats)]
     L.ndtpso_map_get_info.argtypes = [vp, C.POINTER(MapInfo)]
@@ -447,6 +448,9 @@ class ResidentMap:
 
     def build(self):
         self._ctx._chk(self._lib.ndtpso_map_build(self._h))
+
+    def speculate_build(self):
+        self._ctx._chk(self._lib.ndtpso_map_speculate_build(self._h))
 
     def align(self, scan: ResidentScan, guess, deviation, cfg: PSOConfig, seed=1, rand_table=None, mode=SCORE_F32):
         pose = np.empty(3)

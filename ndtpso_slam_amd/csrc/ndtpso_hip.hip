@@ -1191,6 +1191,12 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
 // c->table of a single alignment: [guess, deviation (6 doubles, padded to 64 bytes) | std::rand() table]
 constexpr size_t kGuessBytes = 64;
 
+// work to enqueue right after the alignment kernel, before the host waits for it (runs behind it on the stream)
+struct AfterLaunch {
+  int (*fn)(void*);
+  void* arg;
+};
+
 // where one alignment's inputs live on the device: table image + its grid/window, new-frame points (count known
 // to the host, or only an upper bound with the count itself on the device)
 struct AlignSrc {
@@ -1247,7 +1253,8 @@ static int cluster_test_absent() {
 static bool cluster_worthwhile(int K, int cw) { return std::getenv("NDTPSO_CLUSTER") != nullptr || K * cw >= 32; }
 
 static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
-                      int mode, double host[4 + sizeof(AlignStats) / 8], bool allow_cluster = true) {
+                      int mode, double host[4 + sizeof(AlignStats) / 8], bool allow_cluster = true,
+                      AfterLaunch after = AfterLaunch{nullptr, nullptr}) {
   Plan plan;
   const uint32_t n = src.n;
   if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true))
@@ -1296,6 +1303,8 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
 #undef LAUNCH_ALIGN_C
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(host, c->out.p, (4 + sizeof(AlignStats) / 8) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  if (after.fn)
+    if (int rc = after.fn(after.arg)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   if (K > 1) {
     AlignStats st;
@@ -1307,7 +1316,8 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
 }
 
 static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
-                        int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats);
+                        int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats,
+                        AfterLaunch after = AfterLaunch{nullptr, nullptr});
 
 int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess[3], const double deviation[3],
                  const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
@@ -1331,9 +1341,9 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
 // launch, fetch pose/cost/stats; an alignment the fp32 score flags (underflow regime, see ndtpso_kernels.hpp) is
 // redone with the fp64 score
 static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
-                        int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats) {
+                        int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats, AfterLaunch after) {
   double host[4 + sizeof(AlignStats) / 8];
-  int rc = align_once(c, src, cfg, seed, have_table, mode, host);
+  int rc = align_once(c, src, cfg, seed, have_table, mode, host, true, after);
   if (rc != NDTPSO_OK) return rc;
   AlignStats st;
   std::memcpy(&st, host + 4, sizeof(st));

@@ -319,3 +319,73 @@ def test_resident_map_random_operation_sequences(ctx, oracle, seed, frame_w, fra
         d = np.abs(og.astype(int) - want.astype(int))
         assert d.max() <= 1 and (d > 0).sum() <= max(2, 0.01 * (want != 0).sum())
     assert rmap.info()["status"] & 1 == 0 and n_builds > 5 and n_aligns > 3
+
+
+def test_speculative_build_is_invisible(ctx, oracle):
+    """ndtpso_map_speculate_build builds cells and table ahead of the alignment that will want them.  Whatever comes
+    next -- the alignment, an explicit build, another insert (the build is taken back), a reset, an export -- the map
+    behaves exactly as the lazily built reference frame."""
+    from ndtpso_slam_amd import capi
+    rng = np.random.default_rng(21)
+    cs = 1.0
+    grid = capi.Grid(16, 12, cs)
+    rmap = capi.ResidentMap(ctx, grid, og_cell_size=0.25, pool_bytes=16 << 20)
+    ref = oracle.Frame((0, 0, 0), 16, 12, cs)
+    ref.enable_occupancy_grid(0.25)
+    scan = capi.ResidentScan(ctx, 1024)
+    cfg, ocfg = capi.PSOConfig.make(5, 8), oracle.PSOConfig.make(5, 8)
+
+    def add(n):
+        xy = np.stack([rng.uniform(-8.5, 8.5, n), rng.uniform(-6.5, 6.5, n)], axis=1)
+        xy[: n // 3] *= 0.15
+        rmap.insert_host(xy)
+        for q in xy:
+            ref.add_point(q[0], q[1])
+
+    def check(points=True):
+        _compare_cells(rmap.cells(), ref.cells())
+        if points:
+            assert np.array_equal(rmap.points(), ref.points_all())
+        og, w, h, ext = rmap.occupancy()
+        want, ww, wh, mm = ref.occupancy_grid()
+        assert (w, h, ext) == (ww, wh, mm) and np.abs(og.astype(int) - want.astype(int)).max() <= 1
+
+    for it in range(40):
+        add(int(rng.integers(50, 600)))
+        rmap.speculate_build()
+        nxt = rng.choice(["align", "build", "insert", "export", "reset", "twice"])
+        if nxt == "align":
+            new_xy = np.stack([rng.uniform(-3, 3, 150), rng.uniform(-3, 3, 150)], axis=1)
+            new = oracle.Frame((0, 0, 0), 16, 12, 16.0)
+            for q in new_xy:
+                new.add_point(q[0], q[1])
+            scan.set(new.points())
+            table = oracle.glibc_rand(int(rng.integers(1, 1 << 30)), 3 + 3 * 8 + 6 * 8 * 5)
+            got, cost, _ = rmap.align(scan, (0, 0, 0), (.2, .2, .05), cfg, rand_table=table, mode=capi.SCORE_F64)
+            want, want_cost, _ = ref.pso((0, 0, 0), new, (.2, .2, .05), ocfg, table=table)
+            assert np.array_equal(got, want) and (cost == want_cost or abs(cost - want_cost) < 1e-9 * max(1, abs(want_cost)))
+            check()
+        elif nxt == "build":
+            rmap.build()
+            ref.build()
+            check()
+        elif nxt == "insert":
+            pass                              # the next round's insert arrives while the speculation is pending
+        elif nxt == "export":
+            check()                           # the unbuilt state must be what is exported
+            rmap.build()
+            ref.build()
+            check()
+        elif nxt == "reset":
+            rmap.reset()
+            ref.reset_cells()
+            check()
+        else:
+            rmap.speculate_build()            # idempotent
+            rmap.build()
+            rmap.speculate_build()            # nothing to do: already built
+            ref.build()
+            check()
+    rmap.build()
+    ref.build()
+    check()
