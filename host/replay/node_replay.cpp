@@ -5,10 +5,13 @@
 //   file: int32 n_scans, int32 n_beams, float angle_min, float angle_inc, float range_max, then n_scans*n_beams floats
 //   usage: node_replay scans.bin frame_size cell_side iterations population [srand_seed [og_cell_size dump_prefix
 //          [pixels_per_metre]]]
+//   NODE_REPLAY_PACE_HZ=f in the environment delivers the scans at f Hz like a sensor would (the time a scan takes is
+//   then the latency a robot sees, with whatever the library does between scans off the clock)
 // With a dump prefix the shutdown export of the node (:141-172) runs too: a one-cell global map collects every scan
 // and pose and is dumped as <prefix>.{pose.csv,map.csv,gnuplot,png}; the reference frame (with its occupancy grid) as
 // <prefix>-ref-frame.*, plus the raw grid as <prefix>-ref-frame.og.bin for the tests.
 #include <chrono>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -49,8 +52,14 @@ int main(int argc, char** argv) {
   bool first_iteration = true;
   std::vector<float> ranges((size_t)n_beams);
   double busy_s = 0.;
+  const double pace_hz = std::getenv("NODE_REPLAY_PACE_HZ") ? std::atof(std::getenv("NODE_REPLAY_PACE_HZ")) : 0.;
+  auto next_scan = std::chrono::steady_clock::now();
   for (int k = 0; k < n_scans; ++k) {
     if (std::fread(ranges.data(), 4, (size_t)n_beams, f) != (size_t)n_beams) return 2;
+    if (pace_hz > 0.) {
+      std::this_thread::sleep_until(next_scan);
+      next_scan += std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(1. / pace_hz));
+    }
     const auto t0 = std::chrono::steady_clock::now();
     current_frame->loadLaser(ranges, amin, ainc, rmax);                       // :186
     if (first_iteration)
