@@ -43,6 +43,12 @@ def main():
     ap.add_argument("--identical", action="store_true", help="diagnostic: replicate pair 0 (no load imbalance)")
     args = ap.parse_args()
 
+    # stdout carries exactly one line, the JSON result: everything else that may print there on the way (RCCL's
+    # version banner, device-side printf of diagnostic builds) is sent to stderr at the file-descriptor level
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -223,11 +229,19 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:  # libc's own stdout buffer (native libraries printf into it) must drain while fd 1 still points at stderr
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 def _live_sequence(ctx, capi, synth, mode, n_scans=60):
