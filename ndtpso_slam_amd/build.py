@@ -36,12 +36,28 @@ def needs_build() -> bool:
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """Compile if the library is missing or older than its sources.  Safe when several processes call it at once (one
+    rank per GPU importing the package): one of them compiles under a file lock, into a temporary name that is moved
+    into place atomically; the others wait and find it fresh."""
     if force or needs_build():
+        import fcntl
         os.makedirs(LIB_DIR, exist_ok=True)
-        cmd = [hipcc()] + FLAGS + [SRC, "-o", LIB]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+        with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if force or needs_build():  # somebody else may have built it while this process waited
+                    tmp = "%s.%d.tmp" % (LIB, os.getpid())
+                    cmd = [hipcc()] + FLAGS + [SRC, "-o", tmp]
+                    if verbose:
+                        print(" ".join(cmd[:-1] + [LIB]))
+                    try:
+                        subprocess.check_call(cmd)
+                        os.replace(tmp, LIB)
+                    finally:
+                        if os.path.exists(tmp):
+                            os.remove(tmp)
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
