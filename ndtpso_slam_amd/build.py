@@ -28,11 +28,27 @@ def hipcc() -> str:
     return exe
 
 
+STAMP = LIB + ".sources"   # hash of the sources the library was built from (travels with the .so)
+
+
+def _sources_hash() -> str:
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in DEPS:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build() -> bool:
+    """Content, not mtime, decides: a copy of the tree (the GPU box gets one) does not keep timestamps in order."""
     if not os.path.exists(LIB):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    try:
+        with open(STAMP) as f:
+            return f.read().strip() != _sources_hash()
+    except OSError:
+        return True
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
@@ -53,6 +69,8 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
                     try:
                         subprocess.check_call(cmd)
                         os.replace(tmp, LIB)
+                        with open(STAMP, "w") as f:
+                            f.write(_sources_hash() + "\n")
                     finally:
                         if os.path.exists(tmp):
                             os.remove(tmp)
