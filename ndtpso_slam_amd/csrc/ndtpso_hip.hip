@@ -407,7 +407,8 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   pad_points_wg(pts, n);
   __syncthreads();
   const EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
-  const Swarm sw = swarm_carve(L.swarm_global ? ws : g_lds + L.region_off, ps.P);
+  // a swarm too large for LDS lives in an HBM workspace, one per workgroup of a cluster (each keeps the whole swarm)
+  const Swarm sw = swarm_carve(L.swarm_global ? ws + (size_t)cl.rank * swarm_bytes(ps.P) : g_lds + L.region_off, ps.P);
   pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost,
                                   stats, cl);
   if (threadIdx.x == 0 && stats && cl.rank == 0) {
@@ -473,7 +474,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   __syncthreads();
 
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
-  const Swarm sw = swarm_carve(L.swarm_global ? ws + b * ws_stride : g_lds + L.region_off, ps.P);
+  const Swarm sw = swarm_carve(L.swarm_global ? ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride
+                                              : g_lds + L.region_off, ps.P);
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
   pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                                   tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
@@ -1219,7 +1221,7 @@ static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw)
   if (const char* e = std::getenv("NDTPSO_CLUSTER_WAVES")) *cw = std::min(kClusterMaxThreads / 64, std::max(1, std::atoi(e)));
   int k = std::min(32, (P + 1 + *cw - 1) / *cw);
   if (P + 1 <= 16) k = 0;  // one workgroup already has a wave per item
-  if (const char* e = std::getenv("NDTPSO_CLUSTER")) k = std::min(32, std::max(0, std::atoi(e)));
+  if (const char* e = std::getenv("NDTPSO_CLUSTER")) k = std::min(128, std::max(0, std::atoi(e)));
   if (allow && swarm_in_lds && k >= 2) *K = k;
 }
 // Arrival counters of the clusters of one launch (64 bytes each) and their exchange buffers.  The counters come from a
@@ -1262,9 +1264,9 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   const Layout& L = plan.L;
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
-  if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population)));
   int K, cw;
-  cluster_shape(cfg->population, !L.swarm_global, allow_cluster, &K, &cw);
+  cluster_shape(cfg->population, true, allow_cluster, &K, &cw);
+  if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves);
   ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr};
@@ -1423,7 +1425,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   const ScanP sp = make_scan(geom);
   // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
   int K = 1, cw = 4;
-  cluster_shape(cfg->population, !plan.L.swarm_global, allow_cluster && gate == 0, &K, &cw);
+  cluster_shape(cfg->population, true, allow_cluster && gate == 0, &K, &cw);
   if (K > 1) K = std::min<int>(K, c->n_cus / (int)std::min<uint32_t>(n_pairs, (uint32_t)c->n_cus));
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   if (K > 1) waves = cw;
@@ -1438,7 +1440,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   }
   const size_t stride = ndtpso_rand_draws(cfg);
   const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population) : 0;
-  if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs));
+  if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs * (size_t)K));
 #define LAUNCH_PAIRS_C(MODE, PATH, CL)                                                                            \
   hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL>), dim3(n_pairs * (unsigned)K), dim3(waves * 64), plan.L.total, \
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
