@@ -659,12 +659,13 @@ PsoP make_pso(const ndtpso_pso_config* c, int waves) {
 // Waves per workgroup for the PSO kernels.  The kernels are compiled for <= 128 VGPRs, i.e. 16 waves per CU.
 // With many alignments in flight two 8-wave workgroups per CU (when their LDS fits twice) overlap each other's
 // serial phases; a lone alignment, or one whose LDS needs more than half a CU, gets all 16 waves.
-int pick_waves(int P, int lds_bytes, unsigned n_jobs) {
+int pick_waves(int P, int lds_bytes, unsigned n_jobs, unsigned n_cus = 0) {
   if (const char* e = std::getenv("NDTPSO_WAVES")) {  // tuning knob
     const int w = std::atoi(e);
     if (w >= 1 && w <= 16) return w;
   }
-  int w = (n_jobs > 1 && lds_bytes <= kMaxLds / 2) ? 8 : 16;
+  // two 8-wave workgroups per CU only when there are more alignments than compute units to pair up
+  int w = (n_jobs > std::max(1u, n_cus) && lds_bytes <= kMaxLds / 2) ? 8 : 16;
   while (w > 1 && w / 2 >= P) w /= 2;  // never more than ~2 waves per particle
   return w;
 }
@@ -1364,13 +1365,14 @@ static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_con
 // ---- fused pairs -----------------------------------------------------------------------------------
 
 static int pairs_plan(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg, int mode,
-                      unsigned n_pairs, GridP* g, WinP* wn, Plan* plan, int* waves, bool allow_dense = true) {
+                      unsigned n_pairs, GridP* g, WinP* wn, Plan* plan, int* waves, bool allow_dense = true,
+                      unsigned n_cus = 0) {
   if (!geom || geom->n_beams == 0 || !cfg || cfg->population < 1 || cfg->iterations < 0) return NDTPSO_E_ARG;
   if (make_grid(grid, g) != NDTPSO_OK) return NDTPSO_E_ARG;
   const double r = (double)geom->max_range;
   *wn = make_window(*g, -r, r, -r, r, (int)(geom->n_beams / 3) + 1);
   const bool ok = make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan, true, allow_dense);
-  *waves = pick_waves(cfg->population, plan->L.total, n_pairs);
+  *waves = pick_waves(cfg->population, plan->L.total, n_pairs, n_cus);
   return ok ? NDTPSO_OK : NDTPSO_E_CAPACITY;
 }
 
@@ -1418,7 +1420,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   WinP wn;
   Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves, allow_dense);
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves, allow_dense, (unsigned)c->n_cus);
   if (path_out) *path_out = plan.path;
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
