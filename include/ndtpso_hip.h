@@ -238,6 +238,13 @@ int ndtpso_map_get_points(ndtpso_map *map, int slot0_only, double *xy, uint64_t 
 int ndtpso_map_get_occupancy(ndtpso_map *map, int8_t *og, uint64_t og_bytes, uint32_t *og_width, uint32_t *og_height,
                              uint32_t extent[4]);
 
+/* ---- one alignment on several compute units --------------------------
+ * ndtpso_align, ndtpso_map_align and small batches of ndtpso_align_pairs* spread an alignment over K workgroups (each
+ * keeps the table, the points and the whole swarm and runs the identical control flow; the cost evaluations of a round
+ * are divided one item per wave and exchanged once per round).  Results are bit-identical to one workgroup; a cluster
+ * whose workgroups cannot run together gives up after a bounded wait and the alignment is redone on one workgroup
+ * (status bit 16 is internal and never returned).  Environment: NDTPSO_CLUSTER=0|K, NDTPSO_CLUSTER_WAVES=w. */
+
 /* ---- fused batched scan pairs (BASELINE configs 3/4) ------------------- */
 /* For pair b: reference frame <- ref scan loaded at identity and built; new frame <- new scan
  * (ndtpso_slam_node.cpp:186,229-230); pose_b = pso_optimization(guess_b, ref, new, deviation_b, cfg)
@@ -258,7 +265,9 @@ int ndtpso_align_pairs_dev(ndtpso_ctx *ctx, uint32_t n_pairs, const float *d_ref
 int ndtpso_align_pairs_footprint(const ndtpso_scan_geom *geom, const ndtpso_grid *grid,
                                  const ndtpso_pso_config *cfg, uint32_t *lds_bytes, uint32_t *block_threads);
 
-/* How ndtpso_align_pairs would run a configuration (LDS cell-table sizing / occupancy study, BASELINE config 5) */
+/* How ndtpso_align_pairs would run a configuration (LDS cell-table sizing / occupancy study, BASELINE config 5), for a
+ * batch with more pairs than the device has compute units.  Smaller batches use 16-wave workgroups, and below half the
+ * compute units several workgroups share a pair (cluster mode): same layout per workgroup, different shape. */
 typedef struct {
   uint32_t lds_bytes;        /* dynamic LDS per workgroup (0 if the configuration does not fit) */
   uint32_t block_threads;    /* workgroup size */
