@@ -449,8 +449,16 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   ImageHeader* hdr = reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off);
 
   // reference frame <- scan A at identity (ndtpso_slam_node.cpp:186,198 for the first scan), then build
+#ifdef NDTPSO_PROFILE_SETUP
+  unsigned long long tk[6];
+  tk[0] = wall_clock64();
+#define NDTPSO_SETUP_MARK(i) tk[i] = wall_clock64()
+#else
+#define NDTPSO_SETUP_MARK(i) do { } while (0)
+#endif
   const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
   __syncthreads();
+  NDTPSO_SETUP_MARK(1);
   if constexpr (PATH == 2) {
     wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
     dn.dw = wn.w + 1;
@@ -463,15 +471,23 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
       return;
     }
   }
+  NDTPSO_SETUP_MARK(2);
   build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
                  reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
                  reinterpret_cast<uint2*>(g_lds + L.bm2_off), reinterpret_cast<unsigned short*>(g_lds + L.plist_off),
                  nullptr, nullptr, PATH == 2 ? &dn : nullptr, g_lds);
+  NDTPSO_SETUP_MARK(3);
   // new frame <- scan B (one-cell frame of the same size: the point list inside the frame, ndtpso_slam_node.cpp:229-230)
   const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
                                       g.hw, g.hh);
   pad_points_wg(pts, n_new);
   __syncthreads();
+  NDTPSO_SETUP_MARK(4);
+#ifdef NDTPSO_PROFILE_SETUP
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("setup (us): scan A %.1f window %.1f table %.1f scan B %.1f\n", (tk[1] - tk[0]) * 0.01, (tk[2] - tk[1]) * 0.01,
+           (tk[3] - tk[2]) * 0.01, (tk[4] - tk[3]) * 0.01);
+#endif
 
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
   const Swarm sw = swarm_carve(L.swarm_global ? ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride

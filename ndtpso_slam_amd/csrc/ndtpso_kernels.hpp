@@ -560,14 +560,30 @@ __device__ inline WinP dynamic_window_wg(const GridP& g, const double2* pts, int
     box[1] = box[3] = -1;
   }
   __syncthreads();
+  // per-thread, then per-wave extremes; one LDS atomic per wave and bound (four addresses shared by every point
+  // serialised 4 x n atomics: 23 us of a 75 us setup)
+  int x_lo = 0x7fffffff, x_hi = -1, y_lo = 0x7fffffff, y_hi = -1;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int ix, iy;
     if (point_cell(g, pts[i], ix, iy)) {
-      atomicMin(&box[0], ix);
-      atomicMax(&box[1], ix);
-      atomicMin(&box[2], iy);
-      atomicMax(&box[3], iy);
+      x_lo = min(x_lo, ix);
+      x_hi = max(x_hi, ix);
+      y_lo = min(y_lo, iy);
+      y_hi = max(y_hi, iy);
     }
+  }
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) {
+    x_lo = min(x_lo, __shfl_xor(x_lo, d, kWave));
+    x_hi = max(x_hi, __shfl_xor(x_hi, d, kWave));
+    y_lo = min(y_lo, __shfl_xor(y_lo, d, kWave));
+    y_hi = max(y_hi, __shfl_xor(y_hi, d, kWave));
+  }
+  if (lane_id() == 0 && x_hi >= 0) {
+    atomicMin(&box[0], x_lo);
+    atomicMax(&box[1], x_hi);
+    atomicMin(&box[2], y_lo);
+    atomicMax(&box[3], y_hi);
   }
   __syncthreads();
   WinP w;
@@ -639,6 +655,13 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   }
   __syncthreads();
 
+#ifdef NDTPSO_PROFILE_SETUP
+  unsigned long long bt[8];
+  bt[0] = bt[6] = wall_clock64();
+#define NDTPSO_BT(i) bt[i] = wall_clock64()
+#else
+#define NDTPSO_BT(i) do { } while (0)
+#endif
   // 1. bin every point (NDTFrame::addPoint -> getCellIndex); mark created cells
   for (int i = tid; i < n; i += nt) {
     const double2 p = pts[i];
@@ -665,6 +688,7 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   if (tid < 4 && n + tid < ((n + 3) & ~3)) key[n + tid] = -1;  // pad the key array to a multiple of 4 entries
   __syncthreads();
 
+  NDTPSO_BT(1);
   // 2. created cells -> dense slots in ascending cell order
   if (wave_id() == 0) prefix_words_wave0(bm2, wn.n_words, &hdr->n_created);
   __syncthreads();
@@ -682,6 +706,7 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   }
   __syncthreads();
 
+  NDTPSO_BT(2);
   // 3. points per cell (integer atomics: order independent); key[i] becomes the point's cell slot
   for (int i = tid; i < n; i += nt) {
     const int k = key[i];
@@ -693,6 +718,7 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   }
   __syncthreads();
 
+  NDTPSO_BT(3);
   // 4. built cells (count > 2, ndtcell.cpp:43) -> final record slots; per-cell offsets into the point lists
   for (int s = tid; s < n_created; s += nt)
     if (cnt[s] > 2) {
@@ -724,10 +750,33 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   __syncthreads();
   if (tid == 0 && (int)hdr->n_built > wn.rec_cap) atomicOr(&hdr->status, 2u);
 
-  // 5. statistics: one owner thread per created cell.  The owner first gathers the indices of its points
-  //    (vectorised scan of the slot keys, ascending = beam order), then visits only those: sums round exactly
-  //    as the reference's per-cell vectors do (insertion order).
-  const int n4 = (n + 3) >> 2;
+  NDTPSO_BT(4);
+  // 5a. Per-cell point lists in beam order (= the reference's insertion order): every point files itself at its rank
+  //     among its cell's points, i.e. the number of earlier points with the same slot -- a branch-free scan of the slot
+  //     keys (15 us for 1081 points, compare-bound).  Tried instead: each cell's owner scanning all keys and storing
+  //     matches conditionally (35 us per owner: load -> branch -> store chains, the original); one wave walking the
+  //     points 64 at a time with ballots and a running position per cell (32 us: a serial chain of LDS round trips).
+  {
+    const int4* k4 = reinterpret_cast<const int4*>(key);
+    for (int i = tid; i < n; i += nt) {
+      const int s = key[i];
+      if (s < 0) continue;
+      auto hits = [s](const int4 kk) { return (int)(kk.x == s) + (int)(kk.y == s) + (int)(kk.z == s) + (int)(kk.w == s); };
+      const int full = i >> 2;
+      int rank = 0, q = 0;
+      for (; q + 4 <= full; q += 4) {  // four loads in flight
+        const int4 a = k4[q], b = k4[q + 1], c4 = k4[q + 2], d = k4[q + 3];
+        rank += (hits(a) + hits(b)) + (hits(c4) + hits(d));
+      }
+      for (; q < full; ++q) rank += hits(k4[q]);
+      for (int j = full << 2; j < i; ++j) rank += (int)(key[j] == s);
+      plist[((unsigned)cnt[s] >> 16) + rank] = (unsigned short)i;
+    }
+  }
+  __syncthreads();
+  NDTPSO_BT(6);
+  // 5b. statistics: one owner thread per created cell visits its list: sums round exactly as the reference's
+  //     per-cell vectors do (insertion order).
   for (int s = tid; s < n_created; s += nt) {
     const int mykey = cellkey[s];
     const int c = cnt[s] & 0xffff;
@@ -735,32 +784,46 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
     const bool built = c > 2;
     double mx = 0., my = 0., ia = 0., ib = 0., ic = 0., id = 0.;
     if (built) {
-      unsigned short* mine = plist + off;
-      int w = 0;
-      for (int q = 0; q < n4; ++q) {
-        const int4 kk = reinterpret_cast<const int4*>(key)[q];
-        if (kk.x == s) mine[w++] = (unsigned short)(4 * q);
-        if (kk.y == s) mine[w++] = (unsigned short)(4 * q + 1);
-        if (kk.z == s) mine[w++] = (unsigned short)(4 * q + 2);
-        if (kk.w == s) mine[w++] = (unsigned short)(4 * q + 3);
-      }
+      const unsigned short* mine = plist + off;
+      // Both passes add in insertion order, one point after the other, as the reference does; only the loads are
+      // batched four at a time (index, then point: two dependent LDS round trips that would otherwise be paid per
+      // point -- the cell with the most points sets the duration of the whole step).
       double sx = 0., sy = 0.;
-      for (int t = 0; t < c; ++t) {
+      int t = 0;
+      for (; t + 4 <= c; t += 4) {
+        const double2 p0 = pts[mine[t]], p1 = pts[mine[t + 1]], p2 = pts[mine[t + 2]], p3 = pts[mine[t + 3]];
+        sx += p0.x;  // s_current_partial_sum += point, ndtcell.cpp:30
+        sy += p0.y;
+        sx += p1.x;
+        sy += p1.y;
+        sx += p2.x;
+        sy += p2.y;
+        sx += p3.x;
+        sy += p3.y;
+      }
+      for (; t < c; ++t) {
         const double2 p = pts[mine[t]];
-        sx += p.x;  // s_current_partial_sum += point, ndtcell.cpp:30
+        sx += p.x;
         sy += p.y;
       }
       mx = sx / (double)c;  // ndtcell.cpp:44
       my = sy / (double)c;
       double c00 = 0., c01 = 0., c10 = 0., c11 = 0.;
-      for (int t = 0; t < c; ++t) {
-        const double2 p = pts[mine[t]];
-        const double d0 = p.x - mx, d1 = p.y - my;  // ndtcell.cpp:49-52
+      auto fold = [&](const double2 p) {  // ndtcell.cpp:49-52
+        const double d0 = p.x - mx, d1 = p.y - my;
         c00 += d0 * d0;
         c01 += d0 * d1;
         c10 += d1 * d0;
         c11 += d1 * d1;
+      };
+      for (t = 0; t + 4 <= c; t += 4) {
+        const double2 p0 = pts[mine[t]], p1 = pts[mine[t + 1]], p2 = pts[mine[t + 2]], p3 = pts[mine[t + 3]];
+        fold(p0);
+        fold(p1);
+        fold(p2);
+        fold(p3);
       }
+      for (; t < c; ++t) fold(pts[mine[t]]);
       // s_calc_covar_inverse, ndtcell.cpp:93-111 (eigenvalues of the 2x2 in closed form)
       const double nn = (double)c;
       c00 = c00 / nn;
@@ -815,6 +878,13 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   }
   if (n_rows_out && tid == 0) *n_rows_out = (uint32_t)n_created;
   __syncthreads();
+#ifdef NDTPSO_PROFILE_SETUP
+  NDTPSO_BT(5);
+  if (tid == 0 && blockIdx.x == 0)
+    printf("table (us): bin %.1f slots %.1f count %.1f offsets %.1f lists %.1f stats %.1f  (n_created %d)\n",
+           (bt[1] - bt[0]) * 0.01, (bt[2] - bt[1]) * 0.01, (bt[3] - bt[2]) * 0.01, (bt[4] - bt[3]) * 0.01,
+           (bt[6] - bt[4]) * 0.01, (bt[5] - bt[6]) * 0.01, n_created);
+#endif
 }
 
 // dense form from a table image in HBM (kernels that stage a prebuilt table): one thread per bitmap word
