@@ -918,8 +918,12 @@ __device__ inline void dense_from_image_wg(const GridP& g, const WinP& wn, const
 // (mod 2^32), output r[i] >> 1, first output r[344].  Unrolling the recurrence ten times gives
 // r[i] = r[i-30] + sum_{m<10} r[i-31-3m], which depends only on values >= 30 back: 30 lanes
 // produce 30 consecutive values per step from a 64-entry LDS history ring.
+// The ring is touched by one wave only (wave 0).  LDS operations of a wave execute in program order, so a value a
+// lane stores is what another lane of the same wave loads afterwards; the wave barriers between steps keep the compiler
+// from moving accesses across them.  (The ring used to be `volatile`, which serialised the eleven loads of a step:
+// 8 us per PSO iteration with only this wave running -- a fifth of a workgroup's time; now about 1 us.)
 struct RngState {
-  volatile uint32_t hist[64];
+  uint32_t hist[64];
 };
 
 __device__ inline void rng_seed_wave0(RngState* st, uint32_t seed) {
@@ -942,13 +946,20 @@ __device__ inline void rng_seed_wave0(RngState* st, uint32_t seed) {
 __device__ inline uint32_t rng_step_wave0(RngState* st, int t, int cnt) {
   const int lane = lane_id();
   uint32_t v = 0;
+  __builtin_amdgcn_wave_barrier();
   if (lane < cnt) {
     const int i = t + lane;
-    v = st->hist[(i - 30) & 63];
+    uint32_t h[11];
+    h[0] = st->hist[(i - 30) & 63];
 #pragma unroll
-    for (int m = 0; m < 10; ++m) v += st->hist[(i - 31 - 3 * m) & 63];
+    for (int m = 0; m < 10; ++m) h[m + 1] = st->hist[(i - 31 - 3 * m) & 63];  // eleven independent loads in flight
+    v = h[0];
+#pragma unroll
+    for (int m = 0; m < 10; ++m) v += h[m + 1];  // same order of additions (mod 2^32: any order gives the same sum)
   }
+  __builtin_amdgcn_wave_barrier();
   if (lane < cnt) st->hist[(t + lane) & 63] = v;
+  __builtin_amdgcn_wave_barrier();
   return v;
 }
 
@@ -1307,11 +1318,24 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   unsigned grp = 0;
   if (tid == 0) sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
   __syncthreads();
+#ifdef NDTPSO_PROFILE_PSO
+  unsigned long long pt[5] = {0, 0, 0, 0, 0}, plast = wall_clock64();
+#define NDTPSO_PSO_MARK(k)                                  \
+  do {                                                      \
+    const unsigned long long now__ = wall_clock64();        \
+    pt[k] += now__ - plast;                                 \
+    plast = now__;                                          \
+  } while (0)
+#else
+#define NDTPSO_PSO_MARK(k) do { } while (0)
+#endif
   for (int it = 0; it < ps.I; ++it) {
+    NDTPSO_PSO_MARK(4);
     if (gen) {
       if (wave_id() == 0) rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 6 * P);
       __syncthreads();
     }
+    NDTPSO_PSO_MARK(0);
     const int32_t* draws = gen ? sw.raw : (table + 3 * S + (size_t)it * 6 * P);
     // Particles are evaluated in index order, G at a time.  Every not-yet-committed particle carries a
     // proposal made against the gbest that was current when it was (re)proposed; when a group contains the
@@ -1347,6 +1371,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         }
         need_propose = false;
         __syncthreads();  // proposals (and the commits before them) visible to every wave
+        NDTPSO_PSO_MARK(1);
       }
 #if NDTPSO_ALTERNATE_PRIO
       // Two workgroups share a CU.  VALU issue is arbitrated by priority, then age, so the earlier-dispatched
@@ -1370,6 +1395,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       n_evals += (uint32_t)(hi_g - lo);
       n_rounds += 1;
       __syncthreads();
+      NDTPSO_PSO_MARK(2);
       if (CLUSTER && sh->timed_out) {
         if (tid == 0 && stats && writer) stats->status |= kStatusClusterTimeout;
         return false;
@@ -1409,11 +1435,17 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       } else {
         lo = hi_g;
       }
+      NDTPSO_PSO_MARK(3);
     }
     __syncthreads();  // all commits of this iteration done before the next draws/proposals
     w *= ps.wdamp;  // core.cpp:108
   }
 
+#ifdef NDTPSO_PROFILE_PSO
+  if (tid == 0 && blockIdx.x == 0)
+    printf("pso phases (us): rng %.1f propose %.1f eval+barrier %.1f commit %.1f other %.1f  rounds %u\n", pt[0] * 0.01,
+           pt[1] * 0.01, pt[2] * 0.01, pt[3] * 0.01, pt[4] * 0.01, n_rounds);
+#endif
 #ifdef NDTPSO_PROFILE_PHASES
   if (CLUSTER && tid == 0 && cl.rank == 0) {
     printf("cluster phases (us): control %.1f eval %.1f exchange %.1f readback %.1f  rounds %u\n", g_phase_ticks[0] * 0.01,
