@@ -1351,23 +1351,24 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     while (lo < P) {
       if (need_propose) {
         // core.cpp:83-90 for every particle not yet committed, against the current gbest
-        for (int j = lo + tid; j < P; j += blockDim.x) {
-          double th = 0.;
-#pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            const double r1 = fabs(uniform_pm1(draws[6 * j + 2 * k]));
-            const double r2 = fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
-            const double p = sw.pos[k * S + j];
-            const double v = w * sw.vel[k * S + j] + ps.c1 * r1 * (sw.pb[k * S + j] - p) + ps.c2 * r2 * (sh->gb[k] - p);
-            const double np = p + v;
-            sw.tvel[k * S + j] = v;
-            sw.tpos[k * S + j] = np;
-            if (k == 2) th = np;
+        // one thread per (particle, coordinate): the three coordinates of a particle are independent (core.cpp:83-90),
+        // and each costs two fp64 divisions (Eigen's Random()) -- a chain three times shorter than one thread per
+        // particle; the heading lanes then take the sine and cosine
+        for (int q = 3 * lo + tid; q < 3 * P; q += blockDim.x) {
+          const int j = q / 3, k = q - 3 * j;
+          const double r1 = fabs(uniform_pm1(draws[6 * j + 2 * k]));
+          const double r2 = fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
+          const double p = sw.pos[k * S + j];
+          const double v = w * sw.vel[k * S + j] + ps.c1 * r1 * (sw.pb[k * S + j] - p) + ps.c2 * r2 * (sh->gb[k] - p);
+          const double np = p + v;
+          sw.tvel[k * S + j] = v;
+          sw.tpos[k * S + j] = np;
+          if (k == 2) {
+            double sn, cn;
+            sincos(np, &sn, &cn);
+            sw.tc[j] = cn;
+            sw.ts[j] = sn;
           }
-          double sn, cn;
-          sincos(th, &sn, &cn);
-          sw.tc[j] = cn;
-          sw.ts[j] = sn;
         }
         need_propose = false;
         __syncthreads();  // proposals (and the commits before them) visible to every wave
