@@ -408,9 +408,18 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   __syncthreads();
   const EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
   // a swarm too large for LDS lives in an HBM workspace, one per workgroup of a cluster (each keeps the whole swarm)
-  const Swarm sw = swarm_carve(L.swarm_global ? ws + (size_t)cl.rank * swarm_bytes(ps.P) : g_lds + L.region_off, ps.P);
-  pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost,
-                                  stats, cl);
+  // Two copies of the PSO, one per home of the swarm, so that in each the compiler knows the address space of the
+  // swarm arrays: selecting the base pointer at run time made every swarm access a FLAT instruction (74 of them), and
+  // the proposal / commit phases -- one or two waves working, the rest waiting -- are chains of exactly those accesses.
+  if (L.swarm_global) {
+    const Swarm sw = swarm_carve(ws + (size_t)cl.rank * swarm_bytes(ps.P), ps.P);
+    pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost,
+                                    stats, cl);
+  } else {
+    const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
+    pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost,
+                                    stats, cl);
+  }
   if (threadIdx.x == 0 && stats && cl.rank == 0) {
     const ImageHeader* h = reinterpret_cast<const ImageHeader*>(g_lds + L.hdr_off);
     stats->n_built = h->n_built;
@@ -490,12 +499,18 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
 #endif
 
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
-  const Swarm sw = swarm_carve(L.swarm_global ? ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride
-                                              : g_lds + L.region_off, ps.P);
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
-  pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                                  tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
-                                  out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+  if (L.swarm_global) {  // (two copies: see k_align)
+    const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P);
+    pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                                    tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
+                                    out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+  } else {
+    const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
+    pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                                    tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
+                                    out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+  }
   if (threadIdx.x == 0 && writer) {
     stats[b].n_built = hdr->n_built;
     stats[b].status |= hdr->status;
