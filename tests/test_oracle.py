@@ -263,3 +263,34 @@ def test_golden_node_sequence(oracle):
         else:
             assert np.array_equal(v, g[k]), k
     assert g["cell_slot"].max() >= 1 and len(g["og_nonzero_index"]) > 50      # the fixture exercises both
+
+
+def test_random_coefficient_division_shortcut_is_exact(tmp_path):
+    """The device forms Eigen's Random() coefficient -1 + 2*rand()/RAND_MAX with a reciprocal and two fused multiply-adds
+    instead of a division (ndtpso_kernels.hpp, uniform_pm1).  Checked here against the division for EVERY possible
+    rand() output (2^31 values, about two seconds with OpenMP)."""
+    import subprocess
+    src = tmp_path / "divtest.c"
+    src.write_text(r"""
+#include <math.h>
+#include <stdio.h>
+#include <stdint.h>
+int main(void) {
+  const double D = 2147483647.0, y = 1.0 / D;
+  uint64_t bad = 0;
+#pragma omp parallel for reduction(+:bad)
+  for (int64_t raw = 0; raw < 2147483648LL; ++raw) {
+    const double a = 2.0 * (double)raw;
+    const double q0 = a * y;
+    const double r = fma(-q0, D, a);
+    const double fast = -1.0 + fma(r, y, q0);
+    const double ref = -1.0 + a / D;
+    if (fast != ref) ++bad;
+  }
+  printf("%llu\n", (unsigned long long)bad);
+  return 0;
+}
+""")
+    exe = tmp_path / "divtest"
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-fopenmp", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
+    assert subprocess.check_output([str(exe)], text=True).strip() == "0"
