@@ -455,31 +455,32 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
 }
 
 double NDTFrame::cost(const Vector3d& trans, const NDTFrame* new_frame) {
-  if (!built) build();
-  if (s_resident) {  // single evaluations are not on the node's path: the built cells go through the staged table
-    uint32_t n = 0;
-    ndtpso_host::check(ndtpso_map_get_cells(d_map_, nullptr, 0, &n), "map cells");
-    std::vector<ndtpso_cell_row> rows(n ? n : 1);
-    ndtpso_host::check(ndtpso_map_get_cells(d_map_, rows.data(), n, &n), "map cells");
-    std::vector<int32_t> index;
-    std::vector<double> mean, icov;
-    for (uint32_t k = 0; k < n; ++k) {
-      if (!rows[k].built) continue;
-      index.push_back(rows[k].index);
-      mean.insert(mean.end(), rows[k].mean, rows[k].mean + 2);
-      icov.insert(icov.end(), rows[k].icov, rows[k].icov + 4);
-    }
-    const ndtpso_grid grid = grid_of(*this);
-    ndtpso_host::check(ndtpso_ref_set_cells(ndtpso_host::device(), &grid, (uint32_t)index.size(), index.data(),
-                                            mean.data(), icov.data()), "reference table upload");
-    ndtpso_host::table_owner() = nullptr;
-  } else {
-    uploadTable();
-  }
-  std::vector<double> xy;
-  new_frame->collectPoints(xy);
   const double pose[3] = {trans.x(), trans.y(), trans.z()};
   double c = 0.;
+  if (s_resident) {
+    ndtpso_map* m = ensureMap();
+    ndtpso_points* tmp = nullptr;
+    uint32_t tmp_cap = 0;
+    ndtpso_points* pts = nullptr;
+    if (new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {
+      pts = new_frame->d_scan_;
+    } else {
+      std::vector<double> xy;
+      new_frame->collectPoints(xy);
+      tmp_cap = std::max(kScanCapacity, (uint32_t)(xy.size() / 2));
+      tmp = ndtpso_host::acquire_scan(tmp_cap);
+      ndtpso_host::check(ndtpso_points_set(tmp, xy.data(), (uint32_t)(xy.size() / 2)), "cost_function");
+      pts = tmp;
+    }
+    ndtpso_host::check(ndtpso_map_cost(m, pts, pose, 1, NDTPSO_SCORE_F64, &c), "cost_function");  // builds if need be
+    built = true;
+    if (tmp) ndtpso_host::release_scan(tmp, tmp_cap);
+    return c;
+  }
+  if (!built) build();
+  uploadTable();
+  std::vector<double> xy;
+  new_frame->collectPoints(xy);
   ndtpso_host::check(ndtpso_cost_batch(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), pose, 1,
                                        NDTPSO_SCORE_F64, &c, nullptr), "cost_function");
   return c;

@@ -228,6 +228,9 @@ int ndtpso_map_speculate_build(ndtpso_map *map);
 int ndtpso_map_align(ndtpso_map *map, const ndtpso_points *new_points, const double guess[3], const double deviation[3],
                      const ndtpso_pso_config *cfg, uint32_t seed, const int32_t *rand_table, int score_mode,
                      double out_pose[3], double *out_cost, ndtpso_align_stats *stats);
+/* cost_function (core.cpp:26-48) of a loaded scan against the map at n_poses candidate poses (3 doubles each) */
+int ndtpso_map_cost(ndtpso_map *map, ndtpso_points *new_points, const double *poses, uint32_t n_poses, int score_mode,
+                    double *costs);
 int ndtpso_map_get_info(ndtpso_map *map, ndtpso_map_info *info);
 /* created cells in ascending index order (row.reserved = the cell's current window slot) */
 int ndtpso_map_get_cells(ndtpso_map *map, ndtpso_cell_row *rows, uint32_t max_rows, uint32_t *n_rows);

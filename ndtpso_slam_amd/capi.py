@@ -92,7 +92,7 @@ EXPORTS = [
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
     "ndtpso_points_create", "ndtpso_points_destroy", "ndtpso_points_load_scan", "ndtpso_points_set", "ndtpso_points_get",
     "ndtpso_map_create", "ndtpso_map_destroy", "ndtpso_map_reset", "ndtpso_map_clear", "ndtpso_map_insert", "ndtpso_map_insert_host",
-    "ndtpso_map_build", "ndtpso_map_speculate_build", "ndtpso_map_align", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
+    "ndtpso_map_build", "ndtpso_map_speculate_build", "ndtpso_map_align", "ndtpso_map_cost", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
     "ndtpso_map_get_occupancy",
 ]
 
@@ -161,6 +161,7 @@ def load(build_if_missing: bool = True):
     L.ndtpso_map_speculate_build.argtypes = [vp]
     L.ndtpso_map_align.argtypes = [vp, vp, dp, dp, C.POINTER(PSOConfig), C.c_uint32, ip, C.c_int, dp, dp,
                                    C.POINTER(AlignStats)]
+    L.ndtpso_map_cost.argtypes = [vp, vp, dp, C.c_uint32, C.c_int, dp]
     L.ndtpso_map_get_info.argtypes = [vp, C.POINTER(MapInfo)]
     L.ndtpso_map_get_cells.argtypes = [vp, C.POINTER(CellRow), C.c_uint32, up]
     L.ndtpso_map_get_points.argtypes = [vp, C.c_int, dp, C.c_uint64, C.POINTER(C.c_uint64)]
@@ -465,6 +466,13 @@ class ResidentMap:
                                                   C.c_uint32(int(seed)), _p(tab, C.c_int32) if tab is not None else None,
                                                   mode, _p(pose, C.c_double), C.byref(cost), C.byref(st)))
         return pose, cost.value, {k: getattr(st, k) for k, _ in AlignStats._fields_}
+
+    def cost(self, scan: ResidentScan, poses, mode=SCORE_F32) -> np.ndarray:
+        poses = _f64(poses).reshape(-1, 3)
+        costs = np.empty(poses.shape[0])
+        self._ctx._chk(self._lib.ndtpso_map_cost(self._h, scan._h, _p(poses, C.c_double), poses.shape[0], mode,
+                                                 _p(costs, C.c_double)))
+        return costs
 
     def info(self) -> dict:
         i = MapInfo()

@@ -1171,27 +1171,22 @@ int ndtpso_cells_build_windowed(ndtpso_ctx* c, uint32_t n_cells, ndtpso_cell_win
 
 // ---- K1 ------------------------------------------------------------------------------------------
 
-int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double* poses, uint32_t m, int mode,
-                      double* costs, int32_t* cell_idx) {
-  if (!c || (!xy && n) || !poses || !costs || m == 0) return fail(c, NDTPSO_E_ARG, "null argument");
-  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
-  if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
-  HIP_TRY(c, hipSetDevice(c->device));
+// cost_function for m poses against a table image and a point list that are both on the device
+static int cost_launch(ndtpso_ctx* c, const unsigned char* image, const GridP& g, const WinP& wn, const double2* d_xy,
+                       uint32_t n, const double* poses, uint32_t m, int mode, double* costs, int32_t* cell_idx) {
   Plan plan;
-  if (!make_plan(mode, c->g, c->wn, std::max<int>((int)n, 1), 0, &plan, false, true, true))
+  if (!make_plan(mode, g, wn, std::max<int>((int)n, 1), 0, &plan, false, true, true))
     return fail(c, NDTPSO_E_CAPACITY, "points do not fit in LDS");
   const Layout& L = plan.L;
-  HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
   HIP_TRY(c, c->poses.reserve((size_t)m * 24));
   HIP_TRY(c, c->costs.reserve((size_t)m * 8));
   if (cell_idx) HIP_TRY(c, c->dump.reserve((size_t)m * std::max<uint32_t>(n, 1) * 4));
-  if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->poses.p, poses, (size_t)m * 24, hipMemcpyHostToDevice, c->stream));
   const int waves = 16;
   const int grid = (int)std::min<uint32_t>((m + waves - 1) / waves, 512u);
 #define LAUNCH_COST(MODE, PATH, DUMP)                                                                             \
   hipLaunchKernelGGL((k_cost_batch<MODE, PATH, DUMP>), dim3(grid), dim3(waves * 64), L.total, c->stream,          \
-                     (const unsigned char*)c->image.p, (const double2*)c->xy2.p, (int)n, c->g, c->wn, L, plan.dn, \
+                     image, d_xy, (int)n, g, wn, L, plan.dn,                                                      \
                      (const double*)c->poses.p, (int)m, (double*)c->costs.p, (int32_t*)c->dump.p)
 #define LAUNCH_COST2(MODE, PATH) \
   do { if (cell_idx) LAUNCH_COST(MODE, PATH, true); else LAUNCH_COST(MODE, PATH, false); } while (0)
@@ -1218,6 +1213,18 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
   if (cell_idx && n) HIP_TRY(c, hipMemcpyAsync(cell_idx, c->dump.p, (size_t)m * n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NDTPSO_OK;
+}
+
+int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double* poses, uint32_t m, int mode,
+                      double* costs, int32_t* cell_idx) {
+  if (!c || (!xy && n) || !poses || !costs || m == 0) return fail(c, NDTPSO_E_ARG, "null argument");
+  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
+  if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
+  if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
+  return cost_launch(c, (const unsigned char*)c->image.p, c->g, c->wn, (const double2*)c->xy2.p, n, poses, m, mode, costs,
+                     cell_idx);
 }
 
 // ---- K2 ------------------------------------------------------------------------------------------

@@ -299,6 +299,11 @@ def test_resident_map_random_operation_sequences(ctx, oracle, seed, frame_w, fra
             table = oracle.glibc_rand(int(rng.integers(1, 1 << 30)), 3 + 3 * 9 + 6 * 9 * 6)
             got, cost, _ = rmap.align(scan, (0, 0, 0), (.2, .2, .05), cfg, rand_table=table, mode=capi.SCORE_F64)
             want, want_cost, _ = ref.pso((0, 0, 0), new, (.2, .2, .05), ocfg, table=table)
+            probes = rng.uniform(-1, 1, (5, 3)) * (.3, .3, .1)
+            got_c = rmap.cost(scan, probes, mode=capi.SCORE_F64)            # cost_function against the resident map
+            want_c = np.array([ref.cost(q, new) for q in probes])
+            fin = np.isfinite(want_c)
+            assert np.array_equal(np.isfinite(got_c), fin) and np.allclose(got_c[fin], want_c[fin], rtol=1e-9, atol=1e-9)
             # (after a resetCells the window's stale partial terms can make a covariance indefinite and a cost infinite --
             # in the reference too; equal infinities count as equal)
             assert np.abs(got - want).max() < 1e-9, (it, got, want)
