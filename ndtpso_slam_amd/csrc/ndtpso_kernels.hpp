@@ -1328,6 +1328,16 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   double w = ps.w;
   unsigned grp = 0;
   if (tid == 0) sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
+  // rand() table from the host (the live node): the draws of an iteration are fetched from HBM one iteration ahead --
+  // the loads are issued at the top of iteration it - 1, sit in two registers per thread while it runs, and land in the
+  // LDS buffer the device generator would otherwise fill -- so the proposal step, where most waves wait for one or
+  // two, starts from LDS instead of paying an HBM round trip every time
+  const bool prefetch = !gen && ps.I > 0 && 6 * P <= 2 * (int)blockDim.x;
+  int32_t pre0 = 0, pre1 = 0;
+  if (prefetch) {
+    const int32_t* first = table + 3 * S;
+    for (int q = tid; q < 6 * P; q += blockDim.x) sw.raw[q] = first[q];
+  }
   __syncthreads();
 #ifdef NDTPSO_PROFILE_PSO
   unsigned long long pt[5] = {0, 0, 0, 0, 0}, plast = wall_clock64();
@@ -1347,7 +1357,12 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       __syncthreads();
     }
     NDTPSO_PSO_MARK(0);
-    const int32_t* draws = gen ? sw.raw : (table + 3 * S + (size_t)it * 6 * P);
+    const int32_t* draws = (gen || prefetch) ? sw.raw : (table + 3 * S + (size_t)it * 6 * P);
+    if (prefetch && it + 1 < ps.I) {
+      const int32_t* next = table + 3 * S + (size_t)(it + 1) * 6 * P;
+      if (tid < 6 * P) pre0 = next[tid];
+      if (tid + (int)blockDim.x < 6 * P) pre1 = next[tid + blockDim.x];
+    }
     // Particles are evaluated in index order, G at a time.  Every not-yet-committed particle carries a
     // proposal made against the gbest that was current when it was (re)proposed; when a group contains the
     // first improver j*, particles up to j* are committed and everything after it is re-proposed -- so only
@@ -1448,6 +1463,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         lo = hi_g;
       }
       NDTPSO_PSO_MARK(3);
+    }
+    if (prefetch && it + 1 < ps.I) {  // every proposal of this iteration has read its draws (barriers above)
+      if (tid < 6 * P) sw.raw[tid] = pre0;
+      if (tid + (int)blockDim.x < 6 * P) sw.raw[tid + blockDim.x] = pre1;
     }
     __syncthreads();  // all commits of this iteration done before the next draws/proposals
     w *= ps.wdamp;  // core.cpp:108
