@@ -46,3 +46,6 @@ if '--oracle' in sys.argv:
     d = np.abs(outs["resident+cluster"] - want)
     first = np.nonzero(d.max(axis=1) > 0)[0]
     print("oracle: %.1f s; resident+cluster vs oracle max |dpose| %.3e, first differing scan %s" % (time.time() - t, d.max(), first[0] if len(first) else None))
+    if len(first):
+        k = first[0]
+        print("  at that scan |dpose| =", d[k], "; ten scans later", d[min(k + 10, n - 1)], "; final poses", outs["resident+cluster"][-1], want[-1])
