@@ -18,6 +18,13 @@
  *     after the results are back on the host.
  *   - there is no CPU fallback: with no usable HIP device every call fails
  *     with NDTPSO_E_HIP.
+ *   - a context, and the resident scans / maps created from it, keep scratch
+ *     buffers between calls and are not safe for concurrent use: one thread at
+ *     a time per context (the reference's NDTFrame is single-threaded too);
+ *     independent threads use independent contexts.
+ *   - a frame may have at most 65535 cells per side (the reference keeps
+ *     widthNumOfCells / heightNumOfCells in uint16_t, ndtframe.h:32); larger
+ *     grids are refused with NDTPSO_E_ARG.
  */
 #ifndef NDTPSO_HIP_H
 #define NDTPSO_HIP_H

@@ -641,8 +641,11 @@ int make_grid(const ndtpso_grid* grid, GridP* g) {
   g->cs = grid->cell_side;
   g->cs_pow2 = is_pow2_double(grid->cell_side) ? 1 : 0;
   g->inv_cs = 1. / grid->cell_side;
-  g->W = (uint16_t)std::ceil(grid->width / grid->cell_side);   // ndtframe.cpp:27
-  g->H = (uint16_t)std::ceil(grid->height / grid->cell_side);  // ndtframe.cpp:28
+  // the reference keeps both counts in uint16_t (include/ndtpso_slam/ndtframe.h:32); a frame that would wrap them is refused
+  const double w = std::ceil(grid->width / grid->cell_side), h = std::ceil(grid->height / grid->cell_side);
+  if (!(w >= 1. && w <= 65535. && h >= 1. && h <= 65535.)) return NDTPSO_E_ARG;
+  g->W = (uint16_t)w;  // ndtframe.cpp:27
+  g->H = (uint16_t)h;  // ndtframe.cpp:28
   return NDTPSO_OK;
 }
 
@@ -907,6 +910,7 @@ int ndtpso_scan_to_points(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_
 }
 
 static int build_from_device_points(ndtpso_ctx* c, const ndtpso_grid* grid, const GridP& g, const WinP& wn, int n) {
+  c->have_ref = false;  // the staged image is about to be overwritten: no table until this one is complete
   const Layout L = make_layout(wn.n_words, wn.rec_cap, std::max(n, 1), 0, 2);
   if (L.total > kMaxLds) return fail(c, NDTPSO_E_CAPACITY, "reference table does not fit in LDS");
   HIP_TRY(c, c->image.reserve(image_bytes(wn.n_words, wn.rec_cap)));
@@ -1042,6 +1046,7 @@ int ndtpso_ref_set_cells(ndtpso_ctx* c, const ndtpso_grid* grid, uint32_t n_cell
   }
   hdr->n_built = n_cells;
   hdr->n_created = n_cells;
+  c->have_ref = false;
   HIP_TRY(c, c->image.reserve(bytes));
   HIP_TRY(c, hipMemcpyAsync(c->image.p, img.data(), bytes, hipMemcpyHostToDevice, c->stream));
   if (n_cells) {

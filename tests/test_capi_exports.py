@@ -51,6 +51,10 @@ def test_rand_draws_and_footprint_without_gpu():
     # a scan whose points alone exceed LDS is refused, loudly
     rc, lds, _ = capi.align_pairs_footprint(capi.ScanGeom(12000, -2.3, 0.0004, 30.0, 0.1), capi.Grid(60, 60, 0.25), big)
     assert rc == capi.E_CAPACITY and lds == 0
+    # a frame whose cell counts would wrap the reference's uint16_t (ndtframe.h:32), or a degenerate one, is refused
+    for bad in (capi.Grid(60000, 60, 0.5), capi.Grid(60, 60, 0.0), capi.Grid(0, 60, 0.5)):
+        rc, _, _ = capi.align_pairs_footprint(geom, bad, cfg)
+        assert rc == capi.E_ARG
 
 
 def test_no_cpu_fallback():
