@@ -1217,6 +1217,12 @@ static int cost_launch(ndtpso_ctx* c, const unsigned char* image, const GridP& g
   HIP_TRY(c, hipMemcpyAsync(costs, c->costs.p, (size_t)m * 8, hipMemcpyDeviceToHost, c->stream));
   if (cell_idx && n) HIP_TRY(c, hipMemcpyAsync(cell_idx, c->dump.p, (size_t)m * n * 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  if (mode == NDTPSO_SCORE_F32) {
+    // a NaN score in the fp32 form: a pose touched a cell whose inverse covariance has no Cholesky factor (make_chol).
+    // The fp64 form evaluates the reference's expression as it stands; the batch is redone with it.
+    for (uint32_t i = 0; i < m; ++i)
+      if (costs[i] != costs[i]) return cost_launch(c, image, g, wn, d_xy, n, poses, m, NDTPSO_SCORE_F64, costs, nullptr);
+  }
   return NDTPSO_OK;
 }
 

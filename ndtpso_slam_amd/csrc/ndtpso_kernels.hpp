@@ -128,10 +128,19 @@ __host__ __device__ inline int image_chol_offset(int n_words, int cap) { return 
 __host__ __device__ inline int image_bytes(int n_words, int cap) { return image_mean_offset(n_words) + 64 * cap; }
 
 // Cholesky factor of 0.5*log2(e)*[[a, (b+c)/2], [(b+c)/2, d]] for the fp32 score path, times `scale`
-// (1 for records in metres, cell_side for records in cell units), rounded to fp32 once
+// (1 for records in metres, cell_side for records in cell units), rounded to fp32 once.
+// Only a positive semi-definite form has one.  An inverse covariance that is not -- NaN entries (three coincident
+// points: covariance 0, determinant 0, ndtcell.cpp:104-110), or the indefinite leftovers of resetCells -- gets
+// out[3] = NaN instead of 0: that term is added to every exponent, so a pose that touches the cell scores NaN in
+// the fp32 form, and the callers hand NaN scores to the fp64 form, which evaluates the reference's expression as
+// it stands (NaN, or an exponential above 1).  Negative values at rounding level (a wall: rank-one covariance,
+// sliding-window cancellation) are clamped as before.
 __host__ __device__ inline void make_chol(double a, double b, double c, double d, float out[4], double scale = 1.) {
   const double k = 0.72134752044448170368;  // 0.5 * log2(e)
   const double A = k * a, B = k * (0.5 * (b + c)), D = k * d;
+  const double T = fabs(A) + fabs(D), tol = 1e-12 * T;
+  // (comparisons are false for NaN, and T = inf makes the last one false: both land in `bad`)
+  const bool ok = (A >= -tol) && (D >= -tol) && (A * D - B * B >= -tol * T) && (T < 1.7e308);
   double l11 = 0., l21 = 0.;
   if (A > 0.) {
     l11 = sqrt(A);
@@ -142,7 +151,7 @@ __host__ __device__ inline void make_chol(double a, double b, double c, double d
   out[0] = (float)(l11 * scale);
   out[1] = (float)(l21 * scale);
   out[2] = (float)(l22 * scale);
-  out[3] = 0.f;
+  out[3] = ok ? 0.f : __builtin_nanf("");
 }
 
 // ---- small device helpers ------------------------------------------------
@@ -267,7 +276,7 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
       const double r0 = d0 * ab[u].x + d1 * cd[u].x;  // (diff^T * inv_covar), ndtcell.cpp:73-75
       const double r1 = d0 * ab[u].y + d1 * cd[u].y;
       const double x = -(r0 * d0 + r1 * d1) / 2.;
-      acc[u] += exp(fmin(x, ok[u] ? (double)__builtin_inff() : -(double)__builtin_inff()));  // exp(-inf) = 0
+      acc[u] += exp(ok[u] ? x : -(double)__builtin_inff());  // exp(-inf) = 0; a NaN exponent stays NaN (select, not fmin)
     }
   } else {
     double2 m[U];
@@ -281,10 +290,11 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
     for (int u = 0; u < U; ++u) {
       const float d0 = (float)(qx[u] - m[u].x), d1 = (float)(qy[u] - m[u].y);
       const float a = fmaf(f[u].x, d0, f[u].y * d1), b = f[u].z * d1;
-      // chol.w is 0: folding it in keeps the gather a single ds_read_b128.  Misses are masked through the
-      // exponent (min with -inf; exp2(-inf) = 0) so the whole body stays straight-line code.
+      // chol.w is 0 (NaN for a cell whose inverse covariance has no Cholesky factor, see make_chol): folding it in
+      // keeps the gather a single ds_read_b128.  Misses are masked through the exponent (-inf; exp2(-inf) = 0) so
+      // the whole body stays straight-line code.
       const float x = -fmaf(a, a, fmaf(b, b, f[u].w));
-      const float q = fminf(x, ok[u] ? __builtin_inff() : -__builtin_inff());
+      const float q = ok[u] ? x : -__builtin_inff();  // (a select, not fminf: a NaN exponent must stay NaN)
       acc[u] += (double)__builtin_amdgcn_exp2f(q);
     }
   }
@@ -630,7 +640,7 @@ __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsi
   r.l11 = l[0];
   r.l21 = l[1];
   r.l22 = l[2];
-  r.w = 0.f;
+  r.w = l[3];  // 0, or NaN when the form has no Cholesky factor
   reinterpret_cast<DenseRec*>(lds0 + dn.rec_off)[slot + 1] = r;
   reinterpret_cast<unsigned short*>(lds0)[(ry + 1) * dense_stride(dn.dw) + (rx + 1)] =
       (unsigned short)(((unsigned)dn.rec_off >> 4) + 2u * (slot + 1));
@@ -1119,7 +1129,7 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
             const float4 f = E.T.chol[slot];
             const double d0 = qx - m.x, d1 = qy - m.y;
             const double a = (double)f.x * d0 + (double)f.y * d1, b = (double)f.z * d1;
-            term = exp2(-(a * a + b * b));
+            term = exp2(-(a * a + b * b + (double)f.w));
           }
         }
       }
@@ -1149,9 +1159,13 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       // A cost in the fp32 underflow regime is only ambiguous when what it is compared with is there too: an
       // outlier particle that left the map scores ~0 against a pbest of -400 and loses in any arithmetic.
       // improver == nullptr is the swarm initialisation, where the cost becomes the particle's pbest.
-      if (MODE == kScoreF32 && cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))
+      // (a NaN cost -- a cell without a Cholesky factor, make_chol -- goes the same way: the fp64 form evaluates it)
+      if (MODE == kScoreF32 && (cost != cost || (cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))))
         *tiny = 1;  // the alignment is handed to the fp64-score kernel (see pso_run_wg)
-      else if (improver && cost < gbc)
+      // core.cpp:94-104: the gbest test sits inside the pbest test.  The two agree (gbest <= pbest) except for a
+      // particle whose pbest cost is NaN (its first position touched a cell with a NaN inverse covariance): that
+      // particle never passes `cost < best_cost`, so it never moves the gbest either.
+      else if (improver && cost < gbc && cost < sw.pbc[j])
         atomicMin(improver, j);
     }
   }
@@ -1238,9 +1252,9 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     for (int j = first + (int)threadIdx.x; j < last; j += blockDim.x) {
       const double cost = __hip_atomic_load(&buf[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       sw.tcost[j] = cost;
-      if (MODE == kScoreF32 && cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))
+      if (MODE == kScoreF32 && (cost != cost || (cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))))
         *tiny = 1;
-      else if (improver && cost < gbc)
+      else if (improver && cost < gbc && cost < sw.pbc[j])  // nested tests of core.cpp:94-104, see eval_items
         atomicMin(improver, j);
     }
     ++epoch;

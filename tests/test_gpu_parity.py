@@ -505,3 +505,79 @@ def test_small_batches_cluster_and_timeout_fallback(ctx, oracle, pairs8, monkeyp
     assert np.array_equal(got[0], want[0][:2]) and (got[2]["status"] == 0).all()
     assert np.array_equal(got_one[0], want_one[0]) and got_one[1] == want_one[1]
     assert 0.3 < waited < 5.0          # two bounded waits of 0.2 s, then the reruns
+
+
+def test_coincident_points_cell_scores_nan_like_the_reference(ctx, oracle, pairs8):
+    """Three identical points in a cell: covariance 0, determinant 0, inverse covariance NaN with built = true
+    (ndtcell.cpp:104-110 -- a noise-free simulator with a standing robot produces exactly this).  The reference's
+    score of any pose that puts a point into that cell is NaN, a NaN cost loses every `<` of the PSO, and the device
+    must do the same in both score modes (the fp32 form hands NaN scores to the fp64 form): through a table built on
+    the device, an uploaded table and the resident map."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    grid = _grid(capi)
+    pts = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+    pts.load_laser(p.ref_ranges[2], p.angle_min, p.angle_inc, p.range_max)
+    ref_xy = pts.points()
+    spot = np.array([0.26, -0.27])                       # an empty cell next to the sensor
+    ref_xy = np.concatenate([ref_xy, np.tile(spot, (3, 1))])
+    ref = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, CELL_SIDE)
+    for q in ref_xy:
+        ref.add_point(q[0], q[1])
+    ref.build()
+    cells = ref.cells()
+    bad = [c for c in cells if c["built"] and np.isnan(c["icov"]).any()]
+    assert len(bad) == 1 and bad[0]["count"] == 3
+
+    newf = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+    newf.load_laser(p.new_ranges[2], p.angle_min, p.angle_inc, p.range_max)
+    new_xy = np.concatenate([newf.points(), [spot + (0.02, 0.01)]])   # one point that lands in the NaN cell near pose 0
+    new = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+    for q in new_xy:
+        new.add_point(q[0], q[1])
+    new_xy = new.points()
+
+    rng = np.random.default_rng(7)
+    poses = np.concatenate([rng.uniform(-1, 1, (40, 3)) * (0.05, 0.05, 0.01),       # the extra point stays in the cell
+                            rng.uniform(-1, 1, (40, 3)) * (0.1, 0.1, 0.01) + (2.0, 2.0, 0.0)])   # ... and leaves it
+    want_c = np.array([ref.cost(q, new) for q in poses])
+    assert np.isnan(want_c).sum() >= 30 and np.isfinite(want_c).sum() >= 30
+    cfg, ocfg = capi.PSOConfig.make(12, 20), oracle.PSOConfig.make(12, 20)
+    table = oracle.glibc_rand(99, 3 + 3 * 20 + 6 * 20 * 12)
+    cases = [((0, 0, 0), (0.1, 0.1, 3.1415e-3)),    # guess inside the NaN region: gbest starts as NaN and never moves
+             ((1.0, 1.0, 0.0), (1.0, 1.0, 0.05))]   # a wide swarm: some particles score NaN, some do not
+    wants = [ref.pso(g, new, d, ocfg, table=table) for g, d in cases]
+    assert np.isnan(wants[0][1]) and np.isfinite(wants[1][1])
+
+    index = np.array([c["index"] for c in cells if c["built"]], dtype=np.int32)
+    mean = np.array([c["mean"] for c in cells if c["built"]])
+    icov = np.array([c["icov"] for c in cells if c["built"]])
+
+    def check(cost_fn, align_fn, label):
+        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+            got_c = cost_fn(poses, mode)
+            assert np.array_equal(np.isnan(got_c), np.isnan(want_c)), (label, mode)
+            fin = np.isfinite(want_c)
+            assert np.allclose(got_c[fin], want_c[fin], rtol=1e-9, atol=1e-9), (label, mode)   # (a batch with a NaN is
+            # evaluated by the fp64 form in either mode; a batch without one keeps its form)
+            got_f = cost_fn(poses[fin], mode)
+            assert np.allclose(got_f, want_c[fin], rtol=0, atol=1e-9 if mode == capi.SCORE_F64 else 1e-4 * len(new_xy))
+            for (g, d), (wpose, wcost, _) in zip(cases, wants):
+                pose, cost, _ = align_fn(g, d, mode)
+                assert np.array_equal(pose, wpose), (label, mode, pose, wpose)
+                assert (np.isnan(cost) and np.isnan(wcost)) or abs(cost - wcost) <= 1e-9 * abs(wcost), (label, mode)
+
+    ctx.ref_from_points(grid, ref_xy)                                   # table built by the device
+    got_cells = ctx.ref_get_cells()
+    assert sum(1 for c in got_cells if c["built"] and np.isnan(c["icov"]).any()) == 1
+    check(lambda q, m: ctx.cost_batch(new_xy, q, mode=m),
+          lambda g, d, m: ctx.align(new_xy, g, d, cfg, rand_table=table, mode=m), "device-built table")
+    ctx.ref_set_cells(grid, index, mean, icov)                          # table uploaded by the host (NaN entries kept)
+    check(lambda q, m: ctx.cost_batch(new_xy, q, mode=m),
+          lambda g, d, m: ctx.align(new_xy, g, d, cfg, rand_table=table, mode=m), "uploaded table")
+    rmap = capi.ResidentMap(ctx, grid)                                  # the resident map
+    scan = capi.ResidentScan(ctx, 4096)
+    rmap.insert_host(ref_xy)
+    scan.set(new_xy)
+    check(lambda q, m: rmap.cost(scan, q, mode=m),
+          lambda g, d, m: rmap.align(scan, g, d, cfg, rand_table=table, mode=m), "resident map")

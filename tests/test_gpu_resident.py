@@ -245,8 +245,16 @@ def _glibc_rand(seed, n):
     return np.array([v >> 1 for v in r[344:344 + n]], dtype=np.int32)
 
 
-@pytest.mark.parametrize("seed,frame_w,frame_h,cs,ogcs", [(1, 20, 12, 0.7, 0.2), (2, 12, 20, 1.0, 0.5), (3, 16, 16, 0.5, 0.0)])
+@pytest.mark.parametrize("seed,frame_w,frame_h,cs,ogcs", [
+    (1, 20, 12, 0.7, 0.2), (2, 12, 20, 1.0, 0.5), (3, 16, 16, 0.5, 0.0),
+    # found by scripts/fuzz_campaign.py: a cell of three coincident points (NaN inverse covariance, NaN scores) --
+    (445622, 30, 12, 0.5, 0.0),    # ... the NaN must survive the masking of the score loop
+    (754063, 30, 30, 0.5, 0.1)])   # ... and a particle whose pbest is NaN never moves the gbest (core.cpp:94-104)
 def test_resident_map_random_operation_sequences(ctx, oracle, seed, frame_w, frame_h, cs, ogcs):
+    run_operation_sequence(ctx, oracle, seed, frame_w, frame_h, cs, ogcs)
+
+
+def run_operation_sequence(ctx, oracle, seed, frame_w, frame_h, cs, ogcs):
     """Differential fuzz of the resident map against the oracle's NDTFrame: random sequences of addPoint batches
     (empty, single, several tiles, points on cell edges and frame borders), updates with a pose, builds, alignments
     (which build lazily), resetCells -- on non-square frames and a cell side that is not a power of two.  After every
@@ -270,7 +278,7 @@ def test_resident_map_random_operation_sequences(ctx, oracle, seed, frame_w, fra
             xy[rng.integers(0, n, size=max(1, n // 5))] *= 0.2   # a dense centre: cells that rotate
         return xy
 
-    n_builds = n_aligns = 0
+    n_builds = n_aligns = n_exact32 = 0
     for it in range(140):
         op = rng.choice(["add", "add", "update", "build", "align", "reset"], p=[.3, .2, .2, .15, .1, .05])
         if op in ("add", "update"):
@@ -308,7 +316,12 @@ def test_resident_map_random_operation_sequences(ctx, oracle, seed, frame_w, fra
             # (after a resetCells the window's stale partial terms can make a covariance indefinite and a cost infinite --
             # in the reference too; equal infinities count as equal)
             assert np.abs(got - want).max() < 1e-9, (it, got, want)
-            assert cost == want_cost or abs(cost - want_cost) < 1e-9 * max(1.0, abs(want_cost)), (it, cost, want_cost)
+            got32, _, _ = rmap.align(scan, (0, 0, 0), (.2, .2, .05), cfg, rand_table=table, mode=capi.SCORE_F32)
+            assert np.abs(got32 - want).max() < 1e-3, (it, got32, want)     # BASELINE tolerance of the fp32 score
+            n_exact32 += int(np.array_equal(got32, want))
+            # (a cell of coincident points has a NaN inverse covariance: NaN costs on both sides count as equal)
+            assert (cost == want_cost or (np.isnan(cost) and np.isnan(want_cost))
+                    or abs(cost - want_cost) < 1e-9 * max(1.0, abs(want_cost))), (it, cost, want_cost)
             n_aligns += 1
             _compare_cells(rmap.cells(), ref.cells())
         else:
@@ -325,6 +338,7 @@ def test_resident_map_random_operation_sequences(ctx, oracle, seed, frame_w, fra
         d = np.abs(og.astype(int) - want.astype(int))
         assert d.max() <= 1 and (d > 0).sum() <= max(2, 0.01 * (want != 0).sum())
     assert rmap.info()["status"] & 1 == 0 and n_builds > 5 and n_aligns > 3
+    return n_aligns, n_exact32
 
 
 def test_speculative_build_is_invisible(ctx, oracle):
