@@ -16,7 +16,10 @@ double cost_function(Vector3d trans, NDTFrame* const ref_frame, const NDTFrame* 
 
 // geometry helpers of the public header (reference: core.h:28-31, :40-42, :45-47)
 Vector2d transform_point(const Vector2d& point, const Vector3d& trans) {
-  const double c = std::cos(trans.z()), s = std::sin(trans.z());
+  // one sincos() call, as GCC compiles the reference's cos / sin of the same argument (glibc's sincos is not always
+  // bit-identical to its cos and sin)
+  double c, s;
+  ::sincos(trans.z(), &s, &c);
   return Vector2d(point.x() * c - point.y() * s + trans.x(), point.x() * s + point.y() * c + trans.y());
 }
 
@@ -24,7 +27,9 @@ float index_to_angle(unsigned int idx, float step, float min_angle) { return idx
 
 Vector2d laser_to_point(float r, float theta) {
   const double t = double(theta);
-  return Vector2d(double(r) * std::cos(t), double(r) * std::sin(t));
+  double c, s;
+  ::sincos(t, &s, &c);
+  return Vector2d(double(r) * c, double(r) * s);
 }
 
 vector<double> origin_at(Vector2d& point, double& cell_side) {

@@ -169,6 +169,7 @@ void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle
       }
     }
     ndtpso_map* m = ensureMap();
+    ndtpso_host::check(ndtpso_map_mark_unbuilt(m), "loadLaser");  // ndtframe.cpp:145
     const uint32_t cap = std::max(kScanCapacity, n);
     ndtpso_points* tmp = ndtpso_host::acquire_scan(cap);
     ndtpso_host::check(ndtpso_points_load_scan(tmp, laser_data.data(), &geom, t, nullptr, 0), "loadLaser");
@@ -212,6 +213,7 @@ void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
   if (s_resident) {
     const double pose[3] = {trans.x(), trans.y(), trans.z()};
     ndtpso_map* m = ensureMap();
+    ndtpso_host::check(ndtpso_map_mark_unbuilt(m), "update");  // ndtframe.cpp:188, also when no point follows
     if (new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {  // device to device, nothing to wait for
       ndtpso_host::check(ndtpso_map_insert(m, new_frame->d_scan_, pose), "update");
     } else {
@@ -222,7 +224,11 @@ void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
     // A frame that is aligned against gets its cells built and its table packed right away, off the next align()'s
     // critical path; should something other than align / build come first, the device takes the build back
     // (ndtpso_map_speculate_build), so the lazy build of the reference is what every caller still observes.
-    if (s_iter > 0) ndtpso_host::check(ndtpso_map_speculate_build(m), "update");
+    static const bool speculate = [] {
+      const char* e = std::getenv("NDTPSO_SPECULATE");  // =0: leave every build to the call that asks for it
+      return !(e && e[0] == '0');
+    }();
+    if (s_iter > 0 && speculate) ndtpso_host::check(ndtpso_map_speculate_build(m), "update");
     return;
   }
   std::vector<double> xy;
@@ -247,6 +253,7 @@ int NDTFrame::getCellIndex(Vector2d point, int grid_width, double cell_side_) {
 // reference: addPoint, ndtframe.cpp:215-235
 void NDTFrame::addPoint(Vector2d& point) {
   if (s_resident) {
+    if (getCellIndex(point, widthNumOfCells, cell_side) == -1) return;  // outside the frame: dropped, `built` untouched
     const double p[2] = {point.x(), point.y()};
     ndtpso_host::check(ndtpso_map_insert_host(ensureMap(), p, 1, nullptr), "addPoint");
     built = false;
@@ -530,7 +537,7 @@ void NDTFrame::transform(Vector3d trans) {
     std::vector<double> pts;
     residentPoints(false, pts);
     ndtpso_map* m = ensureMap();
-    ndtpso_host::check(ndtpso_map_clear(m), "transform");  // fresh cells (ndtframe.cpp:123)
+    ndtpso_host::check(ndtpso_map_clear(m), "transform");  // fresh cells (ndtframe.cpp:123): not built
     const double t[3] = {trans.x(), trans.y(), trans.z()};
     ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), t), "transform");
     built = false;

@@ -183,8 +183,13 @@ int ndtpso_align(ndtpso_ctx *ctx, const double *xy, uint32_t n_points, const dou
  * 100-slot sliding-window cells, ndtcell.h:62-70) and the loaded scan stay in HBM; per scan the host sends the ranges
  * and the std::rand() table and receives the pose.
  *   ndtpso_points_*      the node's one-cell per-scan frame (ndtpso_slam_node.cpp:229-230): a point list on the device
- *   ndtpso_map_insert    NDTFrame::update (ndtframe.cpp:187-198; pose != NULL) / loadLaser + addPoint into a multi-cell
- *                        frame (:144-185, 215-235; pose == NULL): NDTCell::addPoint (ndtcell.cpp:21-34) per point
+ *   ndtpso_map_insert    the addPoint loop of NDTFrame::update (ndtframe.cpp:190-197; pose != NULL: transform_point
+ *                        first) / of loadLaser and addPoint on a multi-cell frame (:144-185, 215-235; pose == NULL):
+ *                        NDTCell::addPoint (ndtcell.cpp:21-34) per point.  Like NDTFrame::addPoint it clears the
+ *                        frame's `built` flag only if a point lands in the frame (:219-224)
+ *   ndtpso_map_mark_unbuilt   the unconditional `built = false` at the top of update (:188) and loadLaser (:145) --
+ *                        it decides whether the next cost_function builds again, and a build repeated on unchanged
+ *                        cells is not a no-op in floating point (WINDOW_ADD, ndtcell.h:13-15)
  *   ndtpso_map_build     NDTFrame::build (:68-117): NDTCell::build (ndtcell.cpp:36-68) on every created cell, the
  *                        occupancy grid (:79-112), and the alignment table of the built cells
  *   ndtpso_map_align     NDTFrame::align's pso_optimization (core.cpp:50-116) against the map, building it first when
@@ -223,6 +228,7 @@ void ndtpso_map_destroy(ndtpso_map *map);
  * and point vectors are cleared, the window's partial terms and created / built / mean / inverse covariance are kept */
 int ndtpso_map_reset(ndtpso_map *map);
 int ndtpso_map_clear(ndtpso_map *map); /* back to a freshly constructed frame */
+int ndtpso_map_mark_unbuilt(ndtpso_map *map);
 int ndtpso_map_insert(ndtpso_map *map, const ndtpso_points *pts, const double pose[3]);
 int ndtpso_map_insert_host(ndtpso_map *map, const double *xy, uint32_t n, const double pose[3]);
 int ndtpso_map_build(ndtpso_map *map);

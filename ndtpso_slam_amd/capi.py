@@ -91,7 +91,7 @@ EXPORTS = [
     "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_scan_to_cells", "ndtpso_cells_build_windowed", "ndtpso_occupancy_values", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
     "ndtpso_points_create", "ndtpso_points_destroy", "ndtpso_points_load_scan", "ndtpso_points_set", "ndtpso_points_get",
-    "ndtpso_map_create", "ndtpso_map_destroy", "ndtpso_map_reset", "ndtpso_map_clear", "ndtpso_map_insert", "ndtpso_map_insert_host",
+    "ndtpso_map_create", "ndtpso_map_destroy", "ndtpso_map_reset", "ndtpso_map_clear", "ndtpso_map_mark_unbuilt", "ndtpso_map_insert", "ndtpso_map_insert_host",
     "ndtpso_map_build", "ndtpso_map_speculate_build", "ndtpso_map_align", "ndtpso_map_cost", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
     "ndtpso_map_get_occupancy",
 ]
@@ -155,6 +155,7 @@ def load(build_if_missing: bool = True):
     L.ndtpso_map_destroy.restype = None
     L.ndtpso_map_reset.argtypes = [vp]
     L.ndtpso_map_clear.argtypes = [vp]
+    L.ndtpso_map_mark_unbuilt.argtypes = [vp]
     L.ndtpso_map_insert.argtypes = [vp, vp, dp]
     L.ndtpso_map_insert_host.argtypes = [vp, dp, C.c_uint32, dp]
     L.ndtpso_map_build.argtypes = [vp]
@@ -438,12 +439,22 @@ class ResidentMap:
     def clear(self):
         self._ctx._chk(self._lib.ndtpso_map_clear(self._h))
 
+    def mark_unbuilt(self):
+        """the unconditional `built = false` of NDTFrame::update / loadLaser"""
+        self._ctx._chk(self._lib.ndtpso_map_mark_unbuilt(self._h))
+
     def insert(self, scan: ResidentScan, pose=None):
+        """pose given: NDTFrame::update(pose, scan frame); None: addPoint for every point of the scan"""
+        if pose is not None:
+            self.mark_unbuilt()
         self._ctx._chk(self._lib.ndtpso_map_insert(self._h, scan._h,
                                                    _p(_f64(pose, 3), C.c_double) if pose is not None else None))
 
     def insert_host(self, xy, pose=None):
+        """pose given: NDTFrame::update(pose, a frame holding xy); None: NDTFrame::addPoint for every point"""
         xy = _f64(xy).reshape(-1, 2)
+        if pose is not None:
+            self.mark_unbuilt()
         self._ctx._chk(self._lib.ndtpso_map_insert_host(self._h, _p(xy, C.c_double), xy.shape[0],
                                                         _p(_f64(pose, 3), C.c_double) if pose is not None else None))
 

@@ -784,6 +784,19 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
   return false;
 }
 
+// cos and sin of a pose's heading as the reference obtains them.  transform_point (core.h:28-31) takes both of the
+// same argument, which GCC -- the compiler the reference is built with -- turns into ONE sincos() call; glibc's sincos
+// differs from its cos / sin in the last bit for about 0.15 % of arguments (measured), enough to move a transformed
+// point by an ulp.  So: sincos, explicitly, whatever this translation unit's compiler would have made of two calls.
+struct CosSin {
+  double c, s;
+};
+CosSin host_cos_sin(double th) {
+  CosSin r;
+  ::sincos(th, &r.s, &r.c);
+  return r;
+}
+
 bool trans_is_zero(const double t[3]) {  // Vector3d::isZero(1e-6), ndtframe.cpp:152
   return std::fabs(t[0]) <= 1e-6 && std::fabs(t[1]) <= 1e-6 && std::fabs(t[2]) <= 1e-6;
 }
@@ -899,8 +912,9 @@ int ndtpso_scan_to_points(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_
   const double zero[3] = {0., 0., 0.};
   const double* t = trans ? trans : zero;
   const int do_trans = trans_is_zero(t) ? 0 : 1;
+  const CosSin cs = host_cos_sin(t[2]);
   hipLaunchKernelGGL(k_scan_to_points, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p,
-                     make_scan(geom), do_trans, std::cos(t[2]), std::sin(t[2]), t[0], t[1], (double2*)c->xy.p,
+                     make_scan(geom), do_trans, cs.c, cs.s, t[0], t[1], (double2*)c->xy.p,
                      (uint32_t*)c->small.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(n_out, c->small.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -975,8 +989,9 @@ int ndtpso_ref_from_scan(ndtpso_ctx* c, const ndtpso_grid* grid, const float* ra
   HIP_TRY(c, c->small.reserve(256));
   HIP_TRY(c, hipMemcpyAsync(c->ranges.p, ranges, nb * 4, hipMemcpyHostToDevice, c->stream));
   const int do_trans = trans_is_zero(t) ? 0 : 1;
+  const CosSin cs = host_cos_sin(t[2]);
   hipLaunchKernelGGL(k_scan_to_points, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p,
-                     make_scan(geom), do_trans, std::cos(t[2]), std::sin(t[2]), t[0], t[1], (double2*)c->xy.p,
+                     make_scan(geom), do_trans, cs.c, cs.s, t[0], t[1], (double2*)c->xy.p,
                      (uint32_t*)c->small.p);
   HIP_TRY(c, hipGetLastError());
   uint32_t n = 0;
@@ -1087,7 +1102,8 @@ int ndtpso_points_to_cells(ndtpso_ctx* c, const ndtpso_grid* grid, const double*
   HIP_TRY(c, c->dump.reserve((size_t)n * 4));
   HIP_TRY(c, hipMemcpyAsync(c->xy.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   const int do_trans = trans ? 1 : 0;
-  const double tc = trans ? std::cos(trans[2]) : 1., ts = trans ? std::sin(trans[2]) : 0.;
+  const CosSin cs = host_cos_sin(trans ? trans[2] : 0.);
+  const double tc = trans ? cs.c : 1., ts = trans ? cs.s : 0.;
   hipLaunchKernelGGL(k_points_to_cells, dim3((n + 255) / 256), dim3(256), 0, c->stream, (const double2*)c->xy.p, (int)n,
                      g, do_trans, tc, ts, trans ? trans[0] : 0., trans ? trans[1] : 0., (double2*)c->xy2.p,
                      (int32_t*)c->dump.p);
@@ -1114,8 +1130,9 @@ int ndtpso_scan_to_cells(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_g
   const double zero[3] = {0., 0., 0.};
   const double* t = trans ? trans : zero;
   const int do_trans = trans_is_zero(t) ? 0 : 1;
+  const CosSin cs = host_cos_sin(t[2]);
   hipLaunchKernelGGL(k_scan_to_cells, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p, make_scan(geom),
-                     do_trans, std::cos(t[2]), std::sin(t[2]), t[0], t[1], g, (double2*)c->xy.p, (int32_t*)c->dump.p,
+                     do_trans, cs.c, cs.s, t[0], t[1], g, (double2*)c->xy.p, (int32_t*)c->dump.p,
                      (uint32_t*)c->small.p);
   HIP_TRY(c, hipGetLastError());
   // one synchronisation: the count travels with the (full-size) payload

@@ -9,6 +9,7 @@
  *
  * Citations are file:line in the reference repository.
  */
+#define _GNU_SOURCE /* sincos() */
 #include "ndtpso_oracle.h"
 
 #include <math.h>
@@ -17,6 +18,13 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+
+/* cos and sin of one angle as the reference obtains them: transform_point (core.h:28-31) and laser_to_point
+ * (core.h:45-47) take both of the same argument, and GCC -- the compiler the reference is built with (catkin,
+ * CMakeLists.txt:5-9) -- turns such a pair into ONE sincos() call.  glibc's sincos is not always bit-identical to its
+ * cos() / sin() (last bit, about 0.15 % of arguments), so the call is spelled out here instead of being left to
+ * this file's optimisation level. */
+static void ref_cos_sin(double th, double *c, double *s) { sincos(th, s, c); }
 
 /* ------------------------------------------------------------------ */
 /* small containers                                                    */
@@ -317,15 +325,18 @@ void orc_frame_load_laser(orc_frame *f, const float *ranges, unsigned n, float m
                           float angle_increment, float max_range) {
   unsigned i;
   int do_trans = !vec3_is_zero(f->trans, 1e-6); /* ndtframe.cpp:152-153 */
-  double tc = cos(f->trans[2]), ts = sin(f->trans[2]);
+  double tc, ts;
+  ref_cos_sin(f->trans[2], &tc, &ts);
   f->built = 0;
   for (i = 0; i < n; ++i) {
     /* ndtframe.cpp:165 */
     if ((ranges[i] > 0.) && (ranges[i] < max_range) && (ranges[i] > f->laser_ignore_epsilon)) {
       float theta = (float)i * angle_increment + min_angle; /* index_to_angle, core.h:40-42 (fp32) */
       v2 p;                                                  /* laser_to_point, core.h:45-47 */
-      p.x = (double)ranges[i] * cos((double)theta);
-      p.y = (double)ranges[i] * sin((double)theta);
+      double lc, ls;
+      ref_cos_sin((double)theta, &lc, &ls);
+      p.x = (double)ranges[i] * lc;
+      p.y = (double)ranges[i] * ls;
       if (do_trans) p = transform_point_cs(p, tc, ts, f->trans[0], f->trans[1]); /* ndtframe.cpp:175-176 */
       orc_frame_add_point(f, p.x, p.y);
     }
@@ -334,7 +345,8 @@ void orc_frame_load_laser(orc_frame *f, const float *ranges, unsigned n, float m
 
 void orc_frame_update(orc_frame *ref, const double trans[3], const orc_frame *nf) {
   unsigned ci, i;
-  double c = cos(trans[2]), s = sin(trans[2]);
+  double c, s;
+  ref_cos_sin(trans[2], &c, &s);
   ref->built = 0;
   for (ci = 0; ci < nf->num_cells; ++ci) {
     const orc_cell *cell = nf->cells[ci];
@@ -472,8 +484,7 @@ double orc_cost_function(const double trans[3], orc_frame *ref, const orc_frame 
   double c, s;
   unsigned ci, i, k = 0;
   if (!ref->built) orc_frame_build(ref); /* core.cpp:27-28 */
-  c = cos(trans[2]);
-  s = sin(trans[2]);
+  ref_cos_sin(trans[2], &c, &s);
   for (ci = 0; ci < nf->num_cells; ++ci) { /* core.cpp:33 */
     const orc_cell *nc = nf->cells[ci];
     if (!nc) continue;

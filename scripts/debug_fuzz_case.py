@@ -6,6 +6,7 @@ sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 from ndtpso_slam_amd import capi
 from oracle import pyoracle as oracle
+import np_ref
 seed, frame_w, frame_h = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 cs, stop = float(sys.argv[4]), int(sys.argv[5])
 ctx = capi.Context(0)
@@ -35,7 +36,7 @@ for it in range(stop + 1):
         pose = None if op == "add" else rng.uniform(-1, 1, 3) * (0.3, 0.3, 0.2)
         rmap.insert_host(xy, pose)
         if pose is not None and n:
-            c, s = np.cos(pose[2]), np.sin(pose[2])
+            c, s = np_ref.cos_sin(pose[2])   # one sincos(), like the reference built by GCC
             xy = np.stack([xy[:, 0] * c - xy[:, 1] * s + pose[0], xy[:, 0] * s + xy[:, 1] * c + pose[1]], axis=1)
         for q in xy:
             ref.add_point(q[0], q[1])

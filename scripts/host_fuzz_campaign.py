@@ -1,0 +1,26 @@
+"""One-off: the differential fuzz of the C++ drop-in (tests/test_host_library.py::run_host_operation_sequence, driven
+through host/replay/frame_fuzz) on many seeds and frame shapes.  usage: python scripts/host_fuzz_campaign.py [n] [seed]"""
+import os, sys, tempfile
+sys.path.insert(0, '.')
+sys.path.insert(0, 'tests')
+import numpy as np
+from oracle import pyoracle
+import test_host_library as T
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+T._build()
+ok = aligns = exact32 = 0
+with tempfile.TemporaryDirectory() as tmp:
+    for k in range(n):
+        seed = int(rng.integers(10, 10**6))
+        fw, fh = int(rng.choice([8, 12, 16, 20, 30])), int(rng.choice([8, 12, 16, 20, 30]))
+        cs = float(rng.choice([0.4, 0.5, 0.7, 1.0, 1.3, 2.0]))
+        ogcs = float(rng.choice([0.0, 0.1, 0.2, 0.25, 0.5]))
+        if ogcs > cs: ogcs = 0.0
+        na, ne = T.run_host_operation_sequence(pyoracle, tmp, seed, fw, fh, cs, ogcs)
+        os.remove(os.path.join(tmp, f"ops_{seed}.txt"))
+        aligns += na
+        exact32 += ne
+        ok += 1
+        print(f"case {k}: seed {seed} frame {fw}x{fh} cs {cs} og {ogcs}: ok", flush=True)
+print(f"{ok}/{n} sequences identical to the oracle; fp32-score alignments bit-identical: {exact32}/{aligns}")

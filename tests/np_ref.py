@@ -3,11 +3,27 @@
 Written separately from oracle/ndtpso_oracle.c (different data structures: dictionaries of point lists),
 used only to cross-check the C oracle on small cases.  Citations are reference file:line.
 """
+import ctypes
+import ctypes.util
 import math
 
 import numpy as np
 
 RAND_MAX = 2147483647
+
+_libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+_libm.sincos.argtypes = [ctypes.c_double, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+_libm.sincos.restype = None
+
+
+def cos_sin(theta):
+    """(cos, sin) of one angle from ONE glibc sincos() call: what GCC, the reference's compiler, makes of cos(x) and
+    sin(x) of the same argument (transform_point core.h:28-31, laser_to_point core.h:45-47).  glibc's sincos differs
+    from its cos / sin in the last bit for about 0.15 % of arguments, so math.cos / math.sin are not a faithful
+    restatement."""
+    s, c = ctypes.c_double(), ctypes.c_double()
+    _libm.sincos(float(theta), ctypes.byref(s), ctypes.byref(c))
+    return c.value, s.value
 
 
 def uniform_pm1(raw):
@@ -23,8 +39,9 @@ def laser_points(ranges, amin, ainc, rmax, eps=0.1, trans=(0.0, 0.0, 0.0)):
     for i, r in enumerate(np.asarray(ranges, dtype=np.float32)):
         if float(r) > 0.0 and r < rmax and r > eps:
             theta = np.float32(np.float32(i) * ainc) + amin           # fp32 multiply, then fp32 add
-            x = float(r) * math.cos(float(theta))
-            y = float(r) * math.sin(float(theta))
+            c, s = cos_sin(float(theta))
+            x = float(r) * c
+            y = float(r) * s
             if do_trans:
                 x, y = transform_point(x, y, trans)
             out.append((x, y))
@@ -33,7 +50,7 @@ def laser_points(ranges, amin, ainc, rmax, eps=0.1, trans=(0.0, 0.0, 0.0)):
 
 def transform_point(x, y, t):
     """core.h:28-31"""
-    c, s = math.cos(t[2]), math.sin(t[2])
+    c, s = cos_sin(t[2])
     return x * c - y * s + t[0], x * s + y * c + t[1]
 
 

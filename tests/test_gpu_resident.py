@@ -4,6 +4,8 @@ its sliding windows and the loaded scan never leaving the GPU."""
 import numpy as np
 import pytest
 
+import np_ref
+
 from conftest import FRAME_M
 
 pytestmark = pytest.mark.gpu
@@ -112,7 +114,7 @@ def test_resident_map_window_wraps_and_pool_recycles(ctx, oracle):
             for p in xy:
                 ref.add_point(p[0], p[1])
         else:
-            c, s = np.cos(pose[2]), np.sin(pose[2])
+            c, s = np_ref.cos_sin(pose[2])   # one sincos(), like the reference built by GCC
             for p in xy:
                 ref.add_point(p[0] * c - p[1] * s + pose[0], p[0] * s + p[1] * c + pose[1])
         if it % 5:
@@ -278,6 +280,7 @@ def run_operation_sequence(ctx, oracle, seed, frame_w, frame_h, cs, ogcs):
             xy[rng.integers(0, n, size=max(1, n // 5))] *= 0.2   # a dense centre: cells that rotate
         return xy
 
+    empty = oracle.Frame((0, 0, 0), frame_w, frame_h, float(max(frame_w, frame_h)))
     n_builds = n_aligns = n_exact32 = 0
     for it in range(140):
         op = rng.choice(["add", "add", "update", "build", "align", "reset"], p=[.3, .2, .2, .15, .1, .05])
@@ -287,10 +290,12 @@ def run_operation_sequence(ctx, oracle, seed, frame_w, frame_h, cs, ogcs):
             pose = None if op == "add" else rng.uniform(-1, 1, 3) * (0.3, 0.3, 0.2)
             rmap.insert_host(xy, pose)
             if pose is not None and n:
-                c, s = np.cos(pose[2]), np.sin(pose[2])
+                c, s = np_ref.cos_sin(pose[2])   # one sincos(), like the reference built by GCC
                 xy = np.stack([xy[:, 0] * c - xy[:, 1] * s + pose[0], xy[:, 0] * s + xy[:, 1] * c + pose[1]], axis=1)
             for q in xy:
                 ref.add_point(q[0], q[1])
+            if pose is not None:     # update() clears `built` whether or not a point follows (ndtframe.cpp:188);
+                ref.update((0, 0, 0), empty)   # addPoint only when the point lands in the frame (:219-224)
         elif op == "build":
             rmap.build()
             ref.build()

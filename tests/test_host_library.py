@@ -6,6 +6,8 @@ import subprocess
 import numpy as np
 import pytest
 
+import np_ref
+
 from conftest import FRAME_M
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -149,7 +151,7 @@ def test_node_replay_map_export(tmp_path, oracle, resident, monkeypatch):
         prev = pose
         ref.update(pose, cur)
         # what a one-cell global map keeps of this scan: the points that fall strictly inside the frame
-        c, s = np.cos(pose[2]), np.sin(pose[2])
+        c, s = np_ref.cos_sin(pose[2])   # one sincos(), like the reference built by GCC
         pts = cur.points()
         gx, gy = pts[:, 0] * c - pts[:, 1] * s + pose[0], pts[:, 0] * s + pts[:, 1] * c + pose[1]
         n_map_points += int(((np.abs(gx) < FRAME_M / 2) & (np.abs(gy) < FRAME_M / 2)).sum())
@@ -283,3 +285,137 @@ def test_node_replay_through_window_wrap_around(tmp_path, oracle, resident):
     first = np.nonzero(d.max(axis=1) > 0)[0]
     print("window wrap replay: max |dpose| %.3e, first differing scan %s, busiest cell at slot %d" % (d.max(), first[:1], laps))
     assert d.max() < 1e-9
+
+
+def run_host_operation_sequence(oracle, workdir, seed, frame_w, frame_h, cs, ogcs, n_ops=60):
+    """Differential fuzz of the C++ drop-in (host/replay/frame_fuzz.cpp drives the public NDTFrame / core.h API from a
+    script) against the oracle: random addPoint batches (cell edges, frame borders, a dense centre whose cells rotate
+    their windows, coincident points), update with a pose, build, resetCells, cost_function, pso_optimization and
+    NDTFrame::align with its deviation rule.  Frames resident on the GPU and frames kept by the host, fp64 and fp32
+    score.  Returns (alignments compared, fp32-score alignments that were bit-identical)."""
+    rng = np.random.default_rng(seed)
+    hw, hh = frame_w / 2, frame_h / 2
+    ref = oracle.Frame((0, 0, 0), frame_w, frame_h, cs)
+    if ogcs > 0:
+        ref.enable_occupancy_grid(ogcs)
+    hx = float.hex
+    script = [f"frame {frame_w} {frame_h} {hx(float(cs))} {hx(float(ogcs))}"]
+    expect = [("frame",) + ref.dims()]
+
+    def cloud(n):
+        xy = np.stack([rng.uniform(-hw * 1.1, hw * 1.1, n), rng.uniform(-hh * 1.1, hh * 1.1, n)], axis=1)
+        if n:
+            k = rng.integers(0, n, size=max(1, n // 9))
+            xy[k] = np.round(xy[k] / cs) * cs                     # exactly on cell edges / frame borders
+            xy[rng.integers(0, n, size=max(1, n // 5))] *= 0.2    # a dense centre: cells that rotate
+            if n >= 7 and rng.random() < 0.3:
+                xy[:3] = xy[0]                                    # three coincident points (NaN inverse covariance)
+        return xy
+
+    def pts(xy):
+        return f"{len(xy)} " + " ".join(hx(float(v)) for v in xy.reshape(-1))
+
+    def new_frame(xy):
+        nf = oracle.Frame((0, 0, 0), frame_w, frame_h, float(max(frame_w, frame_h)))
+        for q in xy:
+            nf.add_point(q[0], q[1])
+        return nf
+
+    for _ in range(n_ops):
+        op = rng.choice(["add", "update", "build", "reset", "cost", "pso", "align", "points"],
+                        p=[.3, .2, .12, .04, .1, .08, .1, .06])
+        if op == "add":
+            xy = cloud(int(rng.choice([0, 1, 2, 7, 64, 300, 1100])))
+            script.append("add " + pts(xy))
+            for q in xy:
+                ref.add_point(q[0], q[1])
+            expect.append(("add", len(xy)))
+        elif op == "update":
+            xy = cloud(int(rng.choice([0, 3, 64, 300, 1100])))
+            pose = rng.uniform(-1, 1, 3) * (0.3, 0.3, 0.2)
+            script.append("update " + " ".join(hx(float(v)) for v in pose) + " " + pts(xy))
+            ref.update(pose, new_frame(xy))
+            expect.append(("update",))
+        elif op == "build":
+            script.append("build")
+            ref.build()
+            expect.append(("build", [(c["index"], c["built"], c["mean"]) for c in ref.cells()]))
+        elif op == "reset":
+            script.append("reset")
+            ref.reset_cells()
+            expect.append(("reset",))
+        elif op == "points":
+            script.append("points")
+            xy = ref.points()
+            sx = sy = 0.0
+            for q in xy:
+                sx += q[0]
+                sy += q[1]
+            expect.append(("points", len(xy), sx, sy))
+        else:
+            xy = cloud(200) * 0.5
+            nf = new_frame(xy)
+            if op == "cost":
+                pose = rng.uniform(-1, 1, 3) * (.3, .3, .1)
+                script.append("cost " + " ".join(hx(float(v)) for v in pose) + " " + pts(xy))
+                expect.append(("cost", ref.cost(pose, nf), len(nf.points())))
+            elif op == "pso":
+                sd = int(rng.integers(1, 1 << 30))
+                g, d = rng.uniform(-1, 1, 3) * (.1, .1, .02), (.2, .2, .05)
+                I, P = int(rng.integers(0, 9)), int(rng.integers(1, 25))
+                script.append(f"pso {sd} " + " ".join(hx(float(v)) for v in (*g, *d)) + f" {I} {P} " + pts(xy))
+                pose, _, _ = ref.pso(g, nf, d, oracle.PSOConfig.make(I, P), seed=sd)
+                expect.append(("pso", pose))
+            else:
+                sd = int(rng.integers(1, 1 << 30))
+                g = rng.uniform(-1, 1, 3) * (.1, .1, .02)
+                script.append(f"align {sd} " + " ".join(hx(float(v)) for v in g) + " " + pts(xy))
+                expect.append(("align", ref.align(g, nf, None, seed=sd)))
+    script.append("end")
+    path = os.path.join(str(workdir), f"ops_{seed}.txt")
+    with open(path, "w") as f:
+        f.write("\n".join(script) + "\n")
+
+    n_aligns = n_exact32 = 0
+    for resident in ("1", "0"):
+        for score in ("f64", "f32"):
+            out = subprocess.check_output([os.path.join(HOST, "replay", "frame_fuzz"), path], text=True,
+                                          env=dict(os.environ, NDTPSO_RESIDENT=resident, NDTPSO_SCORE=score))
+            lines = [l.split() for l in out.splitlines()]
+            assert len(lines) == len(expect), (resident, score, len(lines), len(expect))
+            for k, (got, want) in enumerate(zip(lines, expect)):
+                tag = (seed, resident, score, k, want[0])
+                assert got[0] == want[0], tag
+                if want[0] == "frame":
+                    assert (int(got[1]), int(got[2])) == want[1:], tag
+                elif want[0] == "build":
+                    cells = want[1]
+                    assert int(got[1]) == len(cells), tag
+                    for i, (index, built, mean) in enumerate(cells):
+                        gi, gb, gx, gy = got[2 + 4 * i: 6 + 4 * i]
+                        assert (int(gi), bool(int(gb))) == (index, built), tag + (i,)
+                        if built:
+                            assert np.array_equal([float.fromhex(gx), float.fromhex(gy)], mean, equal_nan=True), \
+                                tag + (i, index, float.fromhex(gx), float.fromhex(gy), mean)
+                elif want[0] == "points":
+                    assert int(got[1]) == want[1], tag
+                    assert (float.fromhex(got[2]), float.fromhex(got[3])) == (want[2], want[3]), tag
+                elif want[0] == "cost":
+                    g, w = float.fromhex(got[1]), want[1]
+                    tol = 1e-9 * max(1.0, abs(w)) if score == "f64" else max(1e-4 * max(1, want[2]), 1e-6 * abs(w))
+                    assert (np.isnan(g) and np.isnan(w)) or g == w or abs(g - w) <= tol, tag + (g, w)
+                elif want[0] in ("pso", "align"):
+                    g = np.array([float.fromhex(v) for v in got[1:4]])
+                    assert np.abs(g - want[1]).max() < (1e-9 if score == "f64" else 1e-3), tag + (g, want[1])
+                    if score == "f32":
+                        n_aligns += 1
+                        n_exact32 += int(np.array_equal(g, want[1]))
+    return n_aligns, n_exact32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,frame_w,frame_h,cs,ogcs", [(11, 20, 12, 0.7, 0.2), (12, 16, 16, 0.5, 0.0), (13, 12, 30, 1.0, 0.5)])
+def test_frame_api_random_operation_sequences(tmp_path, oracle, seed, frame_w, frame_h, cs, ogcs):
+    _build()
+    n_aligns, _ = run_host_operation_sequence(oracle, tmp_path, seed, frame_w, frame_h, cs, ogcs)
+    assert n_aligns > 0

@@ -46,8 +46,9 @@ def test_beam_filter_and_points(oracle):
     assert len(got) == len(keep)
     for row, i in zip(got, keep):
         th = np.float32(np.float32(i) * ainc) + amin
-        assert row[0] == float(r[i]) * math.cos(float(th))
-        assert row[1] == float(r[i]) * math.sin(float(th))
+        c, s = np_ref.cos_sin(float(th))      # one sincos() call, as GCC compiles laser_to_point (core.h:45-47)
+        assert row[0] == float(r[i]) * c
+        assert row[1] == float(r[i]) * s
     want = np_ref.laser_points(r, amin, ainc, 30.0)
     assert np.array_equal(got, np.array(want))
     # s_trans applied at load (ndtframe.cpp:152-153,175-176); |t| <= 1e-6 counts as zero
