@@ -182,10 +182,10 @@ __device__ __forceinline__ void stage_image(const unsigned char* __restrict__ im
 
 // ---- K3a -------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
-k_scan_to_points(const float* __restrict__ ranges, ScanP sp, int do_trans, double tc, double ts, double ttx,
+k_scan_to_points(const float* __restrict__ ranges, ScanP sp, const double2* __restrict__ dirs, int do_trans, double tc, double ts, double ttx,
                  double tty, double2* __restrict__ out_xy, uint32_t* __restrict__ out_n) {
   const size_t b = blockIdx.x;
-  const int n = scan_to_points_wg(ranges + b * sp.n_beams, sp, do_trans != 0, tc, ts, ttx, tty,
+  const int n = scan_to_points_wg(ranges + b * sp.n_beams, sp, dirs, do_trans != 0, tc, ts, ttx, tty,
                                   out_xy + b * sp.n_beams, lds_cnt(0));
   if (threadIdx.x == 0) out_n[b] = (uint32_t)n;
 }
@@ -231,9 +231,9 @@ k_points_to_cells(const double2* __restrict__ xy, int n, GridP g, int do_trans, 
 
 // ---- K3a+K3c fused: NDTFrame::loadLaser (ndtframe.cpp:144-185) -> points and their cells, one workgroup ----
 __global__ void __launch_bounds__(1024)
-k_scan_to_cells(const float* __restrict__ ranges, ScanP sp, int do_trans, double tc, double ts, double ttx, double tty,
+k_scan_to_cells(const float* __restrict__ ranges, ScanP sp, const double2* __restrict__ dirs, int do_trans, double tc, double ts, double ttx, double tty,
                 GridP g, double2* __restrict__ out_xy, int32_t* __restrict__ out_idx, uint32_t* __restrict__ out_n) {
-  const int n = scan_to_points_wg(ranges, sp, do_trans != 0, tc, ts, ttx, tty, out_xy, lds_cnt(0));
+  const int n = scan_to_points_wg(ranges, sp, dirs, do_trans != 0, tc, ts, ttx, tty, out_xy, lds_cnt(0));
   __syncthreads();  // out_xy was written by this workgroup (global memory, workgroup scope)
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
     int ix, iy, idx = -1;
@@ -443,7 +443,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
               Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
               const double* __restrict__ dev, const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables,
               size_t table_stride, unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
-              double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl) {
+              double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl,
+              const double2* __restrict__ beam_dirs) {
   const size_t b = CLUSTER ? blockIdx.x / (unsigned)cl.K : blockIdx.x;
   if constexpr (CLUSTER) {
     cl.rank = (int)(blockIdx.x % (unsigned)cl.K);
@@ -465,7 +466,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
 #else
 #define NDTPSO_SETUP_MARK(i) do { } while (0)
 #endif
-  const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
+  const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
   __syncthreads();
   NDTPSO_SETUP_MARK(1);
   if constexpr (PATH == 2) {
@@ -487,7 +488,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
                  nullptr, nullptr, PATH == 2 ? &dn : nullptr, g_lds);
   NDTPSO_SETUP_MARK(3);
   // new frame <- scan B (one-cell frame of the same size: the point list inside the frame, ndtpso_slam_node.cpp:229-230)
-  const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
+  const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
                                       g.hw, g.hh);
   pad_points_wg(pts, n_new);
   __syncthreads();
@@ -599,6 +600,12 @@ struct PinnedRing {
   }
 };
 
+struct BeamDirs {
+  uint32_t n = 0;
+  float amin = 0.f, ainc = 0.f;
+  DevBuf buf;
+};
+
 struct ndtpso_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -613,6 +620,8 @@ struct ndtpso_ctx {
   size_t cluster_next = 0;  // next unused arrival counter of the ring in `cluster`
   DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster, cluster_xc;
   PinnedRing pinned;
+  BeamDirs beam_dirs[4];  // cached beam directions of the scan geometries in use (beam_directions)
+  unsigned beam_dirs_next = 0;
 };
 
 namespace {
@@ -666,14 +675,42 @@ WinP make_window(const GridP& g, double xmin, double xmax, double ymin, double y
   return w;
 }
 
-ScanP make_scan(const ndtpso_scan_geom* s) {
-  ScanP p;
-  p.n_beams = (int)s->n_beams;
-  p.amin = s->min_angle;
-  p.ainc = s->angle_increment;
-  p.rmax = s->max_range;
-  p.eps = s->laser_ignore_epsilon;
-  return p;
+// The beam directions of a scan geometry, on the device: (cos, sin) of index_to_angle(i) (core.h:40-42: fp32 multiply,
+// fp32 add) from one glibc sincos() of the widened angle each -- what laser_to_point (core.h:45-47) compiles to with
+// GCC.  They depend on the geometry only, so they are computed once per geometry on the host (the same libm the
+// reference would run on) and kept in HBM; a few geometries are cached (a robot with a front and a back lidar
+// alternates between two, launch/lidar_front.launch / lidar_back.launch).
+int beam_directions(ndtpso_ctx* c, const ndtpso_scan_geom* s, const double2** out) {
+  BeamDirs* hit = nullptr;
+  for (BeamDirs& b : c->beam_dirs)
+    if (b.n == s->n_beams && b.amin == s->min_angle && b.ainc == s->angle_increment && b.buf.p) hit = &b;
+  if (!hit) {
+    BeamDirs& b = c->beam_dirs[c->beam_dirs_next];
+    c->beam_dirs_next = (c->beam_dirs_next + 1) % (unsigned)(sizeof(c->beam_dirs) / sizeof(c->beam_dirs[0]));
+    std::vector<double> host(2 * (size_t)s->n_beams);
+    for (uint32_t i = 0; i < s->n_beams; ++i) {
+      const float theta = (float)i * s->angle_increment + s->min_angle;  // (this file is built with -ffp-contract=off)
+      ::sincos((double)theta, &host[2 * i + 1], &host[2 * i]);
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // a launch still reading the slot's previous table
+    HIP_TRY(c, b.buf.reserve(host.size() * 8));
+    HIP_TRY(c, hipMemcpy(b.buf.p, host.data(), host.size() * 8, hipMemcpyHostToDevice));
+    b.n = s->n_beams;
+    b.amin = s->min_angle;
+    b.ainc = s->angle_increment;
+    hit = &b;
+  }
+  *out = (const double2*)hit->buf.p;
+  return NDTPSO_OK;
+}
+
+int make_scan(ndtpso_ctx* c, const ndtpso_scan_geom* s, ScanP* p, const double2** dirs) {
+  p->n_beams = (int)s->n_beams;
+  p->amin = s->min_angle;
+  p->ainc = s->angle_increment;
+  p->rmax = s->max_range;
+  p->eps = s->laser_ignore_epsilon;
+  return beam_directions(c, s, dirs);
 }
 
 PsoP make_pso(const ndtpso_pso_config* c, int waves) {
@@ -874,6 +911,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
                     &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate, &c->cluster, &c->cluster_xc})
     b->release();
+  for (BeamDirs& b : c->beam_dirs) b.buf.release();
   c->pinned.release();
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
@@ -913,8 +951,11 @@ int ndtpso_scan_to_points(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_
   const double* t = trans ? trans : zero;
   const int do_trans = trans_is_zero(t) ? 0 : 1;
   const CosSin cs = host_cos_sin(t[2]);
+  ScanP sp;
+  const double2* dirs = nullptr;
+  if (int rc = make_scan(c, geom, &sp, &dirs)) return rc;
   hipLaunchKernelGGL(k_scan_to_points, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p,
-                     make_scan(geom), do_trans, cs.c, cs.s, t[0], t[1], (double2*)c->xy.p,
+                     sp, dirs, do_trans, cs.c, cs.s, t[0], t[1], (double2*)c->xy.p,
                      (uint32_t*)c->small.p);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(n_out, c->small.p, 4, hipMemcpyDeviceToHost, c->stream));
@@ -990,8 +1031,11 @@ int ndtpso_ref_from_scan(ndtpso_ctx* c, const ndtpso_grid* grid, const float* ra
   HIP_TRY(c, hipMemcpyAsync(c->ranges.p, ranges, nb * 4, hipMemcpyHostToDevice, c->stream));
   const int do_trans = trans_is_zero(t) ? 0 : 1;
   const CosSin cs = host_cos_sin(t[2]);
+  ScanP sp;
+  const double2* dirs = nullptr;
+  if (int rc = make_scan(c, geom, &sp, &dirs)) return rc;
   hipLaunchKernelGGL(k_scan_to_points, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p,
-                     make_scan(geom), do_trans, cs.c, cs.s, t[0], t[1], (double2*)c->xy.p,
+                     sp, dirs, do_trans, cs.c, cs.s, t[0], t[1], (double2*)c->xy.p,
                      (uint32_t*)c->small.p);
   HIP_TRY(c, hipGetLastError());
   uint32_t n = 0;
@@ -1131,7 +1175,10 @@ int ndtpso_scan_to_cells(ndtpso_ctx* c, const float* ranges, const ndtpso_scan_g
   const double* t = trans ? trans : zero;
   const int do_trans = trans_is_zero(t) ? 0 : 1;
   const CosSin cs = host_cos_sin(t[2]);
-  hipLaunchKernelGGL(k_scan_to_cells, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p, make_scan(geom),
+  ScanP sp;
+  const double2* dirs = nullptr;
+  if (int rc = make_scan(c, geom, &sp, &dirs)) return rc;
+  hipLaunchKernelGGL(k_scan_to_cells, dim3(1), dim3(1024), kCtrlBytes, c->stream, (const float*)c->ranges.p, sp, dirs,
                      do_trans, cs.c, cs.s, t[0], t[1], g, (double2*)c->xy.p, (int32_t*)c->dump.p,
                      (uint32_t*)c->small.p);
   HIP_TRY(c, hipGetLastError());
@@ -1490,7 +1537,9 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (path_out) *path_out = plan.path;
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
-  const ScanP sp = make_scan(geom);
+  ScanP sp;
+  const double2* dirs = nullptr;
+  if (int rc = make_scan(c, geom, &sp, &dirs)) return rc;
   // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
   int K = 1, cw = 4;
   cluster_shape(cfg->population, true, allow_cluster && gate == 0, &K, &cw);
@@ -1513,7 +1562,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL>), dim3(n_pairs * (unsigned)K), dim3(waves * 64), plan.L.total, \
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
                      d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
-                     cl)
+                     cl, dirs)
 #define LAUNCH_PAIRS(MODE, PATH) \
   do { if (K > 1) LAUNCH_PAIRS_C(MODE, PATH, true); else LAUNCH_PAIRS_C(MODE, PATH, false); } while (0)
   if (mode == NDTPSO_SCORE_F32) {

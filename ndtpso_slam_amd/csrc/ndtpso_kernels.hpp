@@ -473,7 +473,11 @@ __device__ inline void pad_points_wg(double2* pts, int n) {
 // Returns the number of surviving points (uniform).  `s_cnt` is a >= 17-int LDS scratch.
 // clip_hw/clip_hh > 0: additionally drop points outside that frame, as NDTFrame::addPoint does when the scan is
 // loaded into a frame of that size (ndtframe.cpp:215-235; the node's per-scan frame has the map's frame size).
-__device__ inline int scan_to_points_wg(const float* __restrict__ ranges, const ScanP& sp, bool do_trans,
+// dirs: (cos, sin) of every beam's angle -- index_to_angle (core.h:40-42) in fp32, then ONE glibc sincos() of the
+// widened value -- computed by the host (beam_directions in ndtpso_hip.hip): the device's own sincos is within an ulp
+// of glibc's but not always equal, and laser_to_point (core.h:45-47) must give the reference's points bit for bit.
+__device__ inline int scan_to_points_wg(const float* __restrict__ ranges, const ScanP& sp,
+                                        const double2* __restrict__ dirs, bool do_trans,
                                         double tc, double ts, double ttx, double tty, double2* out,
                                         int* s_cnt, double clip_hw = 0., double clip_hh = 0.) {
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id(), n_waves = blockDim.x >> 6;
@@ -487,11 +491,9 @@ __device__ inline int scan_to_points_wg(const float* __restrict__ ranges, const 
       // ndtframe.cpp:165
       valid = ((double)r > 0.) && (r < sp.rmax) && (r > sp.eps);
       if (valid) {
-        const float theta = (float)(unsigned)i * sp.ainc + sp.amin;  // index_to_angle, core.h:40-42 (fp32, no fma)
-        double sn, cn;
-        sincos((double)theta, &sn, &cn);
-        p.x = (double)r * cn;  // laser_to_point, core.h:45-47
-        p.y = (double)r * sn;
+        const double2 d = dirs[i];     // index_to_angle + the cosine and sine of laser_to_point, from the host
+        p.x = (double)r * d.x;         // laser_to_point, core.h:45-47
+        p.y = (double)r * d.y;
         if (do_trans) {  // transform_point by s_trans, ndtframe.cpp:175-176
           const double x = p.x * tc - p.y * ts + ttx;
           const double y = p.x * ts + p.y * tc + tty;
@@ -1149,6 +1151,8 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
   for (int j = first + wave_id(); j < last; j += n_waves) {
     const double c = sw.tc[j], s = sw.ts[j];
     const double tx = sw.tpos[j], ty = sw.tpos[S + j];
+    const double pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
+                                     // initialisation, where it is not looked at)
     double cost;
     if constexpr (PATH == 2)
       cost = eval_pose_wave_dense<false>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
@@ -1160,12 +1164,12 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       // outlier particle that left the map scores ~0 against a pbest of -400 and loses in any arithmetic.
       // improver == nullptr is the swarm initialisation, where the cost becomes the particle's pbest.
       // (a NaN cost -- a cell without a Cholesky factor, make_chol -- goes the same way: the fp64 form evaluates it)
-      if (MODE == kScoreF32 && (cost != cost || (cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))))
+      if (MODE == kScoreF32 && (cost != cost || (cost > -kTinyCost && (!improver || pbc_j > -kTinyCost))))
         *tiny = 1;  // the alignment is handed to the fp64-score kernel (see pso_run_wg)
       // core.cpp:94-104: the gbest test sits inside the pbest test.  The two agree (gbest <= pbest) except for a
       // particle whose pbest cost is NaN (its first position touched a cell with a NaN inverse covariance): that
       // particle never passes `cost < best_cost`, so it never moves the gbest either.
-      else if (improver && cost < gbc && cost < sw.pbc[j])
+      else if (improver && cost < gbc && cost < pbc_j)
         atomicMin(improver, j);
     }
   }
