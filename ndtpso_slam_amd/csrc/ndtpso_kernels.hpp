@@ -1164,13 +1164,20 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       // outlier particle that left the map scores ~0 against a pbest of -400 and loses in any arithmetic.
       // improver == nullptr is the swarm initialisation, where the cost becomes the particle's pbest.
       // (a NaN cost -- a cell without a Cholesky factor, make_chol -- goes the same way: the fp64 form evaluates it)
-      if (MODE == kScoreF32 && (cost != cost || (cost > -kTinyCost && (!improver || pbc_j > -kTinyCost))))
-        *tiny = 1;  // the alignment is handed to the fp64-score kernel (see pso_run_wg)
+      // (written so that the usual evaluation -- a real cost that does not beat the gbest -- passes two comparisons:
+      // these few instructions are issued once per evaluation by every wave, about 1 % of the kernel)
+      bool ordinary = true;
+      if (MODE == kScoreF32 && !(cost <= -kTinyCost)) {  // NaN, or the underflow regime
+        if (cost != cost || !improver || pbc_j > -kTinyCost) {
+          *tiny = 1;  // the alignment is handed to the fp64-score kernel (see pso_run_wg)
+          ordinary = false;
+        }
+      }
       // core.cpp:94-104: the gbest test sits inside the pbest test.  The two agree (gbest <= pbest) except for a
       // particle whose pbest cost is NaN (its first position touched a cell with a NaN inverse covariance): that
       // particle never passes `cost < best_cost`, so it never moves the gbest either.
-      else if (improver && cost < gbc && cost < pbc_j)
-        atomicMin(improver, j);
+      if (ordinary && improver && cost < gbc)
+        if (cost < pbc_j) atomicMin(improver, j);
     }
   }
 }
