@@ -581,3 +581,23 @@ def test_coincident_points_cell_scores_nan_like_the_reference(ctx, oracle, pairs
     scan.set(new_xy)
     check(lambda q, m: rmap.cost(scan, q, mode=m),
           lambda g, d, m: rmap.align(scan, g, d, cfg, rand_table=table, mode=m), "resident map")
+
+
+def test_beam_direction_cache_across_scan_geometries(ctx, oracle):
+    """The beam directions are computed on the host once per scan geometry and a few geometries stay cached on the
+    device (a robot with several lidars alternates between them): more geometries than cache slots, revisited in turn,
+    must each give the oracle's points bit for bit."""
+    from ndtpso_slam_amd import capi
+    rng = np.random.default_rng(3)
+    geoms = [(181, -1.5, 3.0 / 180), (361, -3.1, 6.2 / 360), (720, -2.0, 4.0 / 719), (1081, -2.356194, 4.712389 / 1080),
+             (1500, -3.14, 6.28 / 1499), (90, 0.25, 0.01), (1081, -2.356194, 4.712389 / 1081)]
+    scans = [rng.uniform(0.0, 35.0, n).astype(np.float32) for n, _, _ in geoms]
+    for rep in range(3):
+        for k in ([0, 1, 2, 3, 4, 5, 6] if rep != 1 else [6, 0, 5, 1, 4, 2, 3]):
+            n, amin, ainc = geoms[k]
+            geom = capi.ScanGeom(n, float(np.float32(amin)), float(np.float32(ainc)), 30.0, 0.1)
+            for trans in [(0, 0, 0), (0.7, -1.1, 0.4321)]:
+                of = oracle.Frame(trans, 100, 100, 100.0)
+                of.load_laser(scans[k], np.float32(amin), np.float32(ainc), 30.0)
+                got = ctx.scan_to_points(scans[k], geom, trans)
+                assert np.array_equal(got, of.points()), (rep, k, trans)
