@@ -1463,6 +1463,11 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       for (int j = lo + tid; j <= last; j += blockDim.x) {
         const double cst = sw.tcost[j];
         const bool better = cst < sw.pbc[j];  // core.cpp:94
+#ifdef NDTPSO_COUNT_AMBIG  // diagnostic builds: comparisons closer than a relative NDTPSO_COUNT_AMBIG (one-workgroup kernels)
+        if (fabs(cst - sw.pbc[j]) <= NDTPSO_COUNT_AMBIG * fabs(sw.pbc[j]) ||
+            fabs(cst - sh->gbc) <= NDTPSO_COUNT_AMBIG * fabs(sh->gbc))
+          atomicAdd(&sh->timed_out, 1);
+#endif
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const double np = sw.tpos[k * S + j];
@@ -1517,6 +1522,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       stats->cost_evals = n_evals;
       stats->rounds = n_rounds;
       stats->gbest_updates = n_gb;
+#ifdef NDTPSO_COUNT_AMBIG
+      if (!CLUSTER) stats->gbest_updates = (uint32_t)sh->timed_out;
+#endif
     }
   }
   return true;
