@@ -1464,6 +1464,8 @@ static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_con
   AlignStats st;
   std::memcpy(&st, host + 4, sizeof(st));
   if (mode == NDTPSO_SCORE_F32 && (st.status & kStatusNeedsF64)) {
+    static const bool log_redo = std::getenv("NDTPSO_LOG_REDO") != nullptr;  // diagnostics: how often this happens
+    if (log_redo) std::fprintf(stderr, "ndtpso: alignment handed to the fp64-score kernel\n");
     rc = align_once(c, src, cfg, seed, have_table, NDTPSO_SCORE_F64, host);
     if (rc != NDTPSO_OK) return rc;
   }
