@@ -295,3 +295,34 @@ int main(void) {
     exe = tmp_path / "divtest"
     subprocess.check_call(["gcc", "-O2", "-mfma", "-fopenmp", "-ffp-contract=off", "-o", str(exe), str(src), "-lm"])
     assert subprocess.check_output([str(exe)], text=True).strip() == "0"
+
+
+def test_headings_and_beam_directions_go_through_one_sincos(oracle):
+    """transform_point and laser_to_point (core.h:28-31, 45-47) take the cosine and the sine of the same angle; GCC, the
+    reference's compiler, makes one sincos() call of each pair, and glibc's sincos is not always its cos and sin.  The
+    oracle spells sincos out: a full scan of beams and a few hundred update poses must equal r x sincos and the
+    sincos-transformed points bit for bit (np_ref.cos_sin calls libm's sincos directly)."""
+    rng = np.random.default_rng(12)
+    n = 4000
+    r = rng.uniform(0.2, 29.0, n).astype(np.float32)
+    amin, ainc = np.float32(-3.1), np.float32(6.2 / (n - 1))
+    f = oracle.Frame((0, 0, 0), 100, 100, 100.0)
+    f.load_laser(r, amin, ainc, 30.0)
+    got = f.points()
+    assert len(got) == n
+    want = np.empty((n, 2))
+    for i in range(n):
+        th = np.float32(np.float32(i) * ainc) + amin
+        c, s = np_ref.cos_sin(float(th))
+        want[i] = (float(r[i]) * c, float(r[i]) * s)
+    assert np.array_equal(got, want)
+    src = oracle.Frame((0, 0, 0), 100, 100, 100.0)
+    xy = rng.uniform(-20, 20, (50, 2))
+    for q in xy:
+        src.add_point(q[0], q[1])
+    for pose in rng.uniform(-1, 1, (300, 3)) * (5.0, 5.0, 3.1):
+        ref = oracle.Frame((0, 0, 0), 100, 100, 100.0)
+        ref.update(pose, src)
+        c, s = np_ref.cos_sin(pose[2])
+        want = np.stack([xy[:, 0] * c - xy[:, 1] * s + pose[0], xy[:, 0] * s + xy[:, 1] * c + pose[1]], axis=1)
+        assert np.array_equal(ref.points(), want)
