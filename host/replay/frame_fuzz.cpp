@@ -1,5 +1,5 @@
 // Op-stream interpreter over the public NDTFrame / core.h API, for differential testing against the oracle
-// (tests/test_host_library.py::test_frame_api_random_operation_sequences, scripts/host_fuzz_campaign.py).
+// (tests/test_host_library.py::test_frame_api_random_operation_sequences, tests/campaigns/host_fuzz_campaign.py).
 // The script is a whitespace-separated token stream (numbers as C hex floats, so they arrive bit for bit):
 //   frame W H CS OG                    the reference frame (multi-cell), occupancy grid cell OG (0: none)
 //   add N x y ...                      NDTFrame::addPoint for each point

@@ -1326,7 +1326,7 @@ struct AlignSrc {
 
 // How many workgroups share one alignment (cluster mode, see ClusterP).  One item per wave and round: enough waves
 // for the whole swarm (P + 1 items in the first round), 4 per workgroup (one per SIMD) for small swarms, 8 for larger
-// ones, at most 32 workgroups -- the shapes scripts/cluster_sweep.py found fastest (30 x 50: 8 x 4 waves, 0.43 ms vs
+// ones, at most 32 workgroups -- the shapes tests/campaigns/cluster_sweep.py found fastest (30 x 50: 8 x 4 waves, 0.43 ms vs
 // 0.63 ms on one workgroup; 70 x 70: 0.64 ms vs 1.49 ms).  NDTPSO_CLUSTER=0 keeps a lone alignment on one
 // workgroup, =K forces K workgroups; NDTPSO_CLUSTER_WAVES sets the waves per workgroup.
 static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw) {

@@ -1,6 +1,6 @@
 """Debug helper: replays one sequence of tests/test_gpu_resident.py::test_resident_map_random_operation_sequences up to a
 given operation and compares scores / alignments of the resident map with the oracle's in detail.
-usage: python scripts/debug_fuzz_case.py seed frame_w frame_h cs stop_it"""
+usage: python tests/campaigns/debug_fuzz_case.py seed frame_w frame_h cs stop_it"""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np

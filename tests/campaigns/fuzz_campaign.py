@@ -1,5 +1,5 @@
 """One-off: the resident-map differential fuzz (tests/test_gpu_resident.py) and the speculative-build test on many more
-seeds and frame shapes than the suite runs.  usage: python scripts/fuzz_campaign.py [n] [seed]"""
+seeds and frame shapes than the suite runs.  usage: python tests/campaigns/fuzz_campaign.py [n] [seed]"""
 import sys, os
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')

@@ -1,5 +1,5 @@
 """One-off: the differential fuzz of the C++ drop-in (tests/test_host_library.py::run_host_operation_sequence, driven
-through host/replay/frame_fuzz) on many seeds and frame shapes.  usage: python scripts/host_fuzz_campaign.py [n] [seed]"""
+through host/replay/frame_fuzz) on many seeds and frame shapes.  usage: python tests/campaigns/host_fuzz_campaign.py [n] [seed]"""
 import os, sys, tempfile
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')

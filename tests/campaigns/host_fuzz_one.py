@@ -1,4 +1,4 @@
-"""Debug helper: one sequence of the host-library fuzz.  usage: python scripts/host_fuzz_one.py seed w h cs og"""
+"""Debug helper: one sequence of the host-library fuzz.  usage: python tests/campaigns/host_fuzz_one.py seed w h cs og"""
 import sys, tempfile
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 from oracle import pyoracle

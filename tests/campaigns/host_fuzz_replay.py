@@ -1,6 +1,6 @@
 """Debug helper: re-runs an op script of host/replay/frame_fuzz (as written by tests/test_host_library.py) against the
 oracle with a `build` inserted after every op, and reports the first build whose cells differ.
-usage: python scripts/host_fuzz_replay.py ops.txt [resident=1] [score=f64]"""
+usage: python tests/campaigns/host_fuzz_replay.py ops.txt [resident=1] [score=f64]"""
 import os, subprocess, sys, tempfile
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np

@@ -1,5 +1,5 @@
 """Long node replay: resident frames (clustered alignment) vs host-kept frames vs the oracle, pose by pose.
-usage: python scripts/soak_replay.py [n_scans] [--oracle]"""
+usage: python tests/campaigns/soak_replay.py [n_scans] [--oracle]"""
 import os, subprocess, sys, time
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')

@@ -249,7 +249,7 @@ def _glibc_rand(seed, n):
 
 @pytest.mark.parametrize("seed,frame_w,frame_h,cs,ogcs", [
     (1, 20, 12, 0.7, 0.2), (2, 12, 20, 1.0, 0.5), (3, 16, 16, 0.5, 0.0),
-    # found by scripts/fuzz_campaign.py: a cell of three coincident points (NaN inverse covariance, NaN scores) --
+    # found by tests/campaigns/fuzz_campaign.py: a cell of three coincident points (NaN inverse covariance, NaN scores) --
     (445622, 30, 12, 0.5, 0.0),    # ... the NaN must survive the masking of the score loop
     (754063, 30, 30, 0.5, 0.1)])   # ... and a particle whose pbest is NaN never moves the gbest (core.cpp:94-104)
 def test_resident_map_random_operation_sequences(ctx, oracle, seed, frame_w, frame_h, cs, ogcs):
