@@ -469,7 +469,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
   __syncthreads();
   NDTPSO_SETUP_MARK(1);
-  if constexpr (PATH == 2) {
+  if constexpr (path_is_dense(PATH)) {
     wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
     dn.dw = wn.w + 1;
     dn.dh = wn.h + 1;
@@ -485,7 +485,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
                  reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
                  reinterpret_cast<uint2*>(g_lds + L.bm2_off), reinterpret_cast<unsigned short*>(g_lds + L.plist_off),
-                 nullptr, nullptr, PATH == 2 ? &dn : nullptr, g_lds);
+                 nullptr, nullptr, path_is_dense(PATH) ? &dn : nullptr, g_lds, PATH == 3);
   NDTPSO_SETUP_MARK(3);
   // new frame <- scan B (one-cell frame of the same size: the point list inside the frame, ndtpso_slam_node.cpp:229-230)
   const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
@@ -883,6 +883,8 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   BIG_PATHS(k_align, COMMA true)
   BIG_PATHS(k_align_pairs, COMMA false)
   BIG_PATHS(k_align_pairs, COMMA true)
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, true>);
 #define GLOBAL_PATHS(K, ...)                                                   \
   if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 4 __VA_ARGS__>);         \
   if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 5 __VA_ARGS__>);         \
@@ -1567,8 +1569,15 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
                      cl, dirs)
 #define LAUNCH_PAIRS(MODE, PATH) \
   do { if (K > 1) LAUNCH_PAIRS_C(MODE, PATH, true); else LAUNCH_PAIRS_C(MODE, PATH, false); } while (0)
+  // dense form: when every record lies below 64 KB of LDS the table entries can be the records' byte addresses
+  // (PATH 3: one shift less per point in the score loop); NDTPSO_BYTE_ENTRIES=0 keeps the general form
+  static const bool allow_byte_entries = [] {
+    const char* e = std::getenv("NDTPSO_BYTE_ENTRIES");
+    return !(e && e[0] == '0');
+  }();
+  const bool byte_entries = plan.path == 2 && allow_byte_entries && plan.dn.rec_off + 32 * (wn.rec_cap + 1) <= 65536;
   if (mode == NDTPSO_SCORE_F32) {
-    if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
+    if (byte_entries) LAUNCH_PAIRS(kScoreF32, 3); else if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
   } else {
     if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
   }

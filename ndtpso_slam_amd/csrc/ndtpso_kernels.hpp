@@ -334,7 +334,9 @@ __device__ __forceinline__ DenseItem dense_item(const GridP& g, const DenseP& dn
   return it;
 }
 
-template <int U, bool DUMP, bool CLIP>
+// BYTE: the table entries are the records' LDS byte addresses themselves (possible when every record lies below
+// 64 KB: PATH 3, the fused pairs kernel) instead of addresses in 16-byte units -- one shift less per point.
+template <int U, bool DUMP, bool CLIP, bool BYTE = false>
 __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                  const double2* __restrict__ pts, int base, int n,
                                                  const DenseItem& it, double (&acc)[4], int32_t* __restrict__ dump) {
@@ -370,7 +372,7 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   float4 f[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const unsigned r = e[u] << 4;
+    const unsigned r = BYTE ? e[u] : e[u] << 4;
     const v2d_t mm = *(lds_d2_t)(uintptr_t)r;
     const v4f_t ff = *(lds_f4_t)(uintptr_t)(r + 16u);
     m[u] = make_double2(mm.x, mm.y);
@@ -394,7 +396,7 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   else
     acc[0] += (double)t[0];
   if (DUMP) {
-    const unsigned null16 = (unsigned)dn.rec_off >> 4;
+    const unsigned null16 = BYTE ? (unsigned)dn.rec_off : (unsigned)dn.rec_off >> 4;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = base + u * kWave + lane;
@@ -408,7 +410,7 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
 
 // WIDE: a wave that has its SIMD to itself (cluster mode) keeps eight chunks in flight instead of four to cover the
 // LDS latency; the terms are folded in exactly the order of the U = 4 loop, so the sum is the same bit for bit.
-template <bool DUMP, bool CLIP, bool WIDE = false>
+template <bool DUMP, bool CLIP, bool WIDE = false, bool BYTE = false>
 __device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                          const double2* __restrict__ pts, int n, double c, double s,
                                                          double tx, double ty, int32_t* __restrict__ dump) {
@@ -419,18 +421,18 @@ __device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const D
   int base = 0;
   if constexpr (WIDE && U == 4 && !DUMP)
     for (; base + 8 * kWave <= n_pad; base += 8 * kWave)
-      score_trip_dense<8, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
+      score_trip_dense<8, DUMP, CLIP, BYTE>(g, dn, lds0, pts, base, n, it, acc, dump);
   for (; base + U * kWave <= n_pad; base += U * kWave)
-    score_trip_dense<U, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
-  for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP, CLIP>(g, dn, lds0, pts, base, n, it, acc, dump);
+    score_trip_dense<U, DUMP, CLIP, BYTE>(g, dn, lds0, pts, base, n, it, acc, dump);
+  for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP, CLIP, BYTE>(g, dn, lds0, pts, base, n, it, acc, dump);
   return -wave_sum(acc[0]);
 }
-template <bool DUMP, bool WIDE = false>
+template <bool DUMP, bool WIDE = false, bool BYTE = false>
 __device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                        const double2* __restrict__ pts, int n, double c, double s,
                                                        double tx, double ty, int32_t* __restrict__ dump) {
-  if (dn.clip) return eval_pose_wave_dense_c<DUMP, true, WIDE>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
-  return eval_pose_wave_dense_c<DUMP, false, WIDE>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
+  if (dn.clip) return eval_pose_wave_dense_c<DUMP, true, WIDE, BYTE>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
+  return eval_pose_wave_dense_c<DUMP, false, WIDE, BYTE>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
 }
 
 // pts must be padded to a multiple of kPointPad with out-of-frame sentinels (pad_points_wg)
@@ -617,8 +619,8 @@ __device__ __forceinline__ unsigned bm_slot(const uint2* bm, int k) {
 // scratch: key[n], cellkey[n], cnt[n] ints (rounded up to 4), plist[n] u16 and bm2[n_words] uint2
 // hdr/out: where the table goes (LDS); out.ab/out.cd or out.chol may be null when a kernel needs one score form
 // dn/lds0 (optional): also emit the dense form (u16 table at lds0, DenseRec[] at lds0 + dn->rec_off)
-__device__ inline void dense_clear_wg(const DenseP& dn, unsigned char* lds0) {
-  const unsigned null16 = (unsigned)dn.rec_off >> 4;
+__device__ inline void dense_clear_wg(const DenseP& dn, unsigned char* lds0, bool byte_entries = false) {
+  const unsigned null16 = byte_entries ? (unsigned)dn.rec_off : (unsigned)dn.rec_off >> 4;
   uint32_t* t32 = reinterpret_cast<uint32_t*>(lds0);
   const int n32 = dense_tab_bytes(dn.dw, dn.dh) >> 2;
   for (int i = threadIdx.x; i < n32; i += blockDim.x) t32[i] = null16 | (null16 << 16);
@@ -633,7 +635,8 @@ __device__ inline void dense_clear_wg(const DenseP& dn, unsigned char* lds0) {
 }
 // one built cell -> dense record `slot + 1` and its table entry; (rx, ry) = cell inside the staging window
 __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsigned char* lds0, unsigned slot, int rx,
-                                          int ry, double mx, double my, double ia, double ib, double ic, double id) {
+                                          int ry, double mx, double my, double ia, double ib, double ic, double id,
+                                          bool byte_entries = false) {
   float l[4];
   make_chol(ia, ib, ic, id, l, g.cs);  // Cholesky factor in cell units
   DenseRec r;
@@ -645,16 +648,17 @@ __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsi
   r.w = l[3];  // 0, or NaN when the form has no Cholesky factor
   reinterpret_cast<DenseRec*>(lds0 + dn.rec_off)[slot + 1] = r;
   reinterpret_cast<unsigned short*>(lds0)[(ry + 1) * dense_stride(dn.dw) + (rx + 1)] =
-      (unsigned short)(((unsigned)dn.rec_off >> 4) + 2u * (slot + 1));
+      byte_entries ? (unsigned short)((unsigned)dn.rec_off + 32u * (slot + 1))
+                   : (unsigned short)(((unsigned)dn.rec_off >> 4) + 2u * (slot + 1));
 }
 
 __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const double2* pts, int n,
                                       ImageHeader* hdr, const TableOut& out, int* key, int* cellkey, int* cnt,
                                       uint2* bm2, unsigned short* plist, CellRow* rows, uint32_t* n_rows_out,
-                                      const DenseP* dn, unsigned char* lds0) {
+                                      const DenseP* dn, unsigned char* lds0, bool byte_entries = false) {
   const int tid = threadIdx.x, nt = blockDim.x;
   uint2* bm = out.bm;
-  if (dn) dense_clear_wg(*dn, lds0);
+  if (dn) dense_clear_wg(*dn, lds0, byte_entries);
 
   for (int w = tid; w < wn.n_words; w += nt) {
     bm[w] = make_uint2(0u, 0u);
@@ -859,7 +863,7 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
       id = c00 / det;
       const unsigned slot = bm_slot(bm, mykey);
       if ((int)slot < wn.rec_cap) {
-        if (dn) dense_put(g, *dn, lds0, slot, mykey % wn.w, mykey / wn.w, mx, my, ia, ib, ic, id);
+        if (dn) dense_put(g, *dn, lds0, slot, mykey % wn.w, mykey / wn.w, mx, my, ia, ib, ic, id, byte_entries);
         if (out.mean) out.mean[slot] = make_double2(mx, my);
         if (out.ab) {
           out.ab[slot] = make_double2(ia, ib);
@@ -1080,6 +1084,8 @@ struct EvalCtx {
 // The PSO kernels therefore stop as soon as an fp32 cost lands above -kTinyCost and flag the alignment
 // (kStatusNeedsF64); the host side re-runs flagged alignments with the fp64-score kernel, gated on that flag.
 // ndtpso_cost_batch re-evaluates such a pose in place (eval_pose_wave_tiny: same records, fp64 exponential).
+// PATH 2 and 3 are the dense form (3: table entries are byte addresses, see score_trip_dense)
+__host__ __device__ constexpr bool path_is_dense(int path) { return path == 2 || path == 3; }
 constexpr uint32_t kStatusNeedsF64 = 4u;
 constexpr uint32_t kStatusNeedsBitmap = 8u;  // dense form: the occupied box exceeds the provisioned cell table
 constexpr double kTinyCost = 1e-28;
@@ -1090,7 +1096,7 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
   const int lane = lane_id();
   const int n_pad = round_up(n, kWave);
   double acc = 0.;
-  if constexpr (PATH == 2) {
+  if constexpr (path_is_dense(PATH)) {
     const DenseItem it = dense_item(E.g, E.dn, c, s, tx, ty);
     for (int base = 0; base < n_pad; base += kWave) {
       const double2 p = pts[base + lane];
@@ -1100,7 +1106,7 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
       const bool ok = (rx < (unsigned)E.dn.dw) && (ry < (unsigned)E.dn.dh) && (!E.dn.clip || (gx < it.XMAX && gy < it.YMAX));
       const unsigned lin = ok ? ry * (unsigned)dense_stride(E.dn.dw) + rx : 0u;
       const unsigned e = reinterpret_cast<const unsigned short*>(E.lds0)[lin];
-      const DenseRec* r = reinterpret_cast<const DenseRec*>(E.lds0 + (e << 4));
+      const DenseRec* r = reinterpret_cast<const DenseRec*>(E.lds0 + (PATH == 3 ? e : e << 4));
       const double d0 = gx - r->mgx, d1 = gy - r->mgy;
       const double a = (double)r->l11 * d0 + (double)r->l21 * d1, b = (double)r->l22 * d1;
       acc += exp2(-(a * a + b * b + (double)r->w));  // null record: w = +inf -> 0
@@ -1154,8 +1160,8 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
     const double pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
                                      // initialisation, where it is not looked at)
     double cost;
-    if constexpr (PATH == 2)
-      cost = eval_pose_wave_dense<false>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
+    if constexpr (path_is_dense(PATH))
+      cost = eval_pose_wave_dense<false, false, PATH == 3>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
     else
       cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
     if (lane_id() == 0) {
@@ -1237,8 +1243,8 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
       const double c = sw.tc[j], s = sw.ts[j];
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       double cost;
-      if constexpr (PATH == 2)
-        cost = eval_pose_wave_dense<false, true>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
+      if constexpr (path_is_dense(PATH))
+        cost = eval_pose_wave_dense<false, true, PATH == 3>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
       else
         cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
       if (lane_id() == 0) __hip_atomic_store(&buf[j], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
