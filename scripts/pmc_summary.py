@@ -6,7 +6,10 @@ import csv, json, sys, collections, math
 
 src, dst = sys.argv[1], sys.argv[2]
 pairs, P, I, beams = (int(v) for v in (sys.argv[3:7] if len(sys.argv) >= 7 else (512, 70, 70, 1081)))
-KERNEL = "k_align_pairs<0, 2, false>"
+import os
+KERNEL = "k_align_pairs<0, 3, false>"   # dense form with byte-address entries (what config 3 runs); else the general dense form
+if not any(KERNEL in r["Kernel_Name"] for r in csv.DictReader(open(f"{src}/p1/p_counter_collection.csv"))):
+    KERNEL = "k_align_pairs<0, 2, false>"
 vals = collections.defaultdict(list)
 disp = {}
 for p in ("p1", "p2", "p3", "p4", "p5"):
