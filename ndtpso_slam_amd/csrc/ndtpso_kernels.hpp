@@ -427,6 +427,32 @@ __device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const D
   for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP, CLIP, BYTE>(g, dn, lds0, pts, base, n, it, acc, dump);
   return -wave_sum(acc[0]);
 }
+// the same with the folded constants already at hand (the PSO keeps them with each proposal)
+template <bool WIDE, bool BYTE>
+__device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
+                                                       const double2* __restrict__ pts, int n, const DenseItem& it) {
+  constexpr int U = NDTPSO_UNROLL;
+  double acc[4] = {0., 0., 0., 0.};
+  const int n_pad = round_up(n, kWave);
+  int base = 0;
+  if (dn.clip) {
+    if constexpr (WIDE && U == 4)
+      for (; base + 8 * kWave <= n_pad; base += 8 * kWave)
+        score_trip_dense<8, false, true, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+    for (; base + U * kWave <= n_pad; base += U * kWave)
+      score_trip_dense<U, false, true, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+    for (; base < n_pad; base += kWave) score_trip_dense<1, false, true, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+  } else {
+    if constexpr (WIDE && U == 4)
+      for (; base + 8 * kWave <= n_pad; base += 8 * kWave)
+        score_trip_dense<8, false, false, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+    for (; base + U * kWave <= n_pad; base += U * kWave)
+      score_trip_dense<U, false, false, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+    for (; base < n_pad; base += kWave) score_trip_dense<1, false, false, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+  }
+  return -wave_sum(acc[0]);
+}
+
 template <bool DUMP, bool WIDE = false, bool BYTE = false>
 __device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                        const double2* __restrict__ pts, int n, double c, double s,
@@ -1031,12 +1057,14 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
   double* pbc;    // [S]    best_cost
   double* tpos;   // [3][S] proposed position
   double* tvel;   // [3][S]
-  double* tc;     // [S] cos(theta) of the proposal
-  double* ts;     // [S]
+  double* tc;     // [S] cos(theta) of the proposal -- dense form: the folded transform constants C, S, TX, TY of the
+  double* ts;     // [S] proposal (DenseItem), computed once where the proposal is made instead of by every wave
+  double* ttx;    // [S] that evaluates it (dense form only)
+  double* tty;    // [S]
   double* tcost;  // [S]
   int32_t* raw;   // [max(3(P+1), 6P)] rand() outputs of the current phase
 };
-__host__ __device__ inline int swarm_doubles(int P) { return 19 * (P + 1); }
+__host__ __device__ inline int swarm_doubles(int P) { return 21 * (P + 1); }
 __host__ __device__ inline int swarm_raw_ints(int P) { return (6 * P > 3 * (P + 1)) ? 6 * P : 3 * (P + 1); }
 __host__ __device__ inline int swarm_bytes(int P) { return align16(swarm_doubles(P) * 8) + align16(swarm_raw_ints(P) * 4); }
 
@@ -1053,6 +1081,8 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P) {
   sw.tc = d + 16 * S;
   sw.ts = d + 17 * S;
   sw.tcost = d + 18 * S;
+  sw.ttx = d + 19 * S;
+  sw.tty = d + 20 * S;
   sw.raw = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P) * 8));
   return sw;
 }
@@ -1156,14 +1186,16 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
   const int n_waves = blockDim.x >> 6;
   for (int j = first + wave_id(); j < last; j += n_waves) {
     const double c = sw.tc[j], s = sw.ts[j];
-    const double tx = sw.tpos[j], ty = sw.tpos[S + j];
     const double pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
                                      // initialisation, where it is not looked at)
     double cost;
-    if constexpr (path_is_dense(PATH))
-      cost = eval_pose_wave_dense<false, false, PATH == 3>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
-    else
+    if constexpr (path_is_dense(PATH)) {
+      const DenseItem it{c, s, sw.ttx[j], sw.tty[j], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
+      cost = eval_item_wave_dense<false, PATH == 3>(E.g, E.dn, E.lds0, pts, n, it);
+    } else {
+      const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+    }
     if (lane_id() == 0) {
       sw.tcost[j] = cost;
       // A cost in the fp32 underflow regime is only ambiguous when what it is compared with is there too: an
@@ -1243,7 +1275,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
       const double c = sw.tc[j], s = sw.ts[j];
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       double cost;
-      if constexpr (path_is_dense(PATH))
+      if constexpr (path_is_dense(PATH))  // (a cluster folds the constants here: its proposal step is on the critical path)
         cost = eval_pose_wave_dense<false, true, PATH == 3>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
       else
         cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
@@ -1316,8 +1348,15 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       }
       double sn, cn;
       sincos(th, &sn, &cn);
-      sw.tc[slot] = cn;
-      sw.ts[slot] = sn;
+      if constexpr (path_is_dense(PATH) && !CLUSTER) {  // DenseItem of this pose (dense_item), kept with it
+        sw.tc[slot] = cn * E.g.inv_cs;
+        sw.ts[slot] = sn * E.g.inv_cs;
+        sw.ttx[slot] = (sw.tpos[slot] + E.g.hw) * E.g.inv_cs - (double)E.dn.ox;
+        sw.tty[slot] = (sw.tpos[S + slot] + E.g.hh) * E.g.inv_cs - (double)E.dn.oy;
+      } else {
+        sw.tc[slot] = cn;
+        sw.ts[slot] = sn;
+      }
     }
   }
   __syncthreads();
@@ -1420,11 +1459,16 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           const double np = p + v;
           sw.tvel[k * S + j] = v;
           sw.tpos[k * S + j] = np;
+          constexpr bool fold = path_is_dense(PATH) && !CLUSTER;
+          if constexpr (fold) {  // each coordinate's share of the proposal's DenseItem (dense_item)
+            if (k == 0) sw.ttx[j] = (np + E.g.hw) * E.g.inv_cs - (double)E.dn.ox;
+            if (k == 1) sw.tty[j] = (np + E.g.hh) * E.g.inv_cs - (double)E.dn.oy;
+          }
           if (k == 2) {
             double sn, cn;
             sincos(np, &sn, &cn);
-            sw.tc[j] = cn;
-            sw.ts[j] = sn;
+            sw.tc[j] = fold ? cn * E.g.inv_cs : cn;
+            sw.ts[j] = fold ? sn * E.g.inv_cs : sn;
           }
         }
         need_propose = false;
