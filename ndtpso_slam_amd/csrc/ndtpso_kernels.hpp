@@ -389,6 +389,9 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   if constexpr (U == 8) {  // two groups of four in flight together, folded in the order two U = 4 trips would be
     acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));
     acc[0] += (double)((t[4] + t[5]) + (t[6] + t[7]));
+  } else if constexpr (U == 5) {  // the last group of four and the one chunk behind it in one trip, folded as they
+    acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));  // would be by a U = 4 trip followed by a U = 1 trip
+    acc[0] += (double)t[4];
   } else if constexpr (U == 4)
     acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));
   else if constexpr (U == 2)
@@ -435,19 +438,30 @@ __device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const Den
   double acc[4] = {0., 0., 0., 0.};
   const int n_pad = round_up(n, kWave);
   int base = 0;
+  // a remainder of exactly five chunks (1081 beams are 17) goes as one trip instead of a trip of four and a lonely one
   if (dn.clip) {
     if constexpr (WIDE && U == 4)
       for (; base + 8 * kWave <= n_pad; base += 8 * kWave)
         score_trip_dense<8, false, true, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-    for (; base + U * kWave <= n_pad; base += U * kWave)
+    for (; base + U * kWave <= n_pad && (U != 4 || WIDE || n_pad - base != 5 * kWave); base += U * kWave)
       score_trip_dense<U, false, true, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+    if constexpr (U == 4 && !WIDE)
+      if (n_pad - base == 5 * kWave) {
+        score_trip_dense<5, false, true, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+        base += 5 * kWave;
+      }
     for (; base < n_pad; base += kWave) score_trip_dense<1, false, true, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
   } else {
     if constexpr (WIDE && U == 4)
       for (; base + 8 * kWave <= n_pad; base += 8 * kWave)
         score_trip_dense<8, false, false, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-    for (; base + U * kWave <= n_pad; base += U * kWave)
+    for (; base + U * kWave <= n_pad && (U != 4 || WIDE || n_pad - base != 5 * kWave); base += U * kWave)
       score_trip_dense<U, false, false, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+    if constexpr (U == 4 && !WIDE)
+      if (n_pad - base == 5 * kWave) {
+        score_trip_dense<5, false, false, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+        base += 5 * kWave;
+      }
     for (; base < n_pad; base += kWave) score_trip_dense<1, false, false, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
   }
   return -wave_sum(acc[0]);
