@@ -32,8 +32,8 @@ DEVIATION = (0.1, 0.1, 3.1415e-3)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)   # (a step is 2.6 ms: the first few run before the clocks settle)
     ap.add_argument("--pairs", type=int, default=512, help="scan pairs per GPU per step")
     ap.add_argument("--particles", type=int, default=70)
     ap.add_argument("--iterations", type=int, default=70)
