@@ -5,11 +5,32 @@
 #ifndef NDTPSO_SLAM_AMD_LINALG_H
 #define NDTPSO_SLAM_AMD_LINALG_H
 
-#if defined(__has_include)
+// Which of the two it is decides the layout of NDTCell and NDTFrame (Eigen's Vector2d is 16-byte aligned, the fallback
+// 8), so the library and everything compiled against its headers must agree.  The choice is therefore
+//   - forced by NDTPSO_USE_EIGEN=0/1 when that is defined (the CMake build bakes it into the target's PUBLIC compile
+//     definitions, so consumers inherit the library's choice), else taken from __has_include, and
+//   - recorded in the library as a symbol, ndtpso_slam_abi_with_eigen or ndtpso_slam_abi_without_eigen, that every
+//     translation unit including this header references: a node built with Eigen against a library built without
+//     (or the reverse) fails at LINK time with that name in the message instead of corrupting `cells` silently.
+#if defined(NDTPSO_USE_EIGEN)
+#if NDTPSO_USE_EIGEN
+#define NDTPSO_HAVE_EIGEN 1
+#endif
+#elif defined(__has_include)
 #if __has_include(<eigen3/Eigen/Core>)
 #define NDTPSO_HAVE_EIGEN 1
 #endif
 #endif
+
+#ifdef NDTPSO_HAVE_EIGEN
+#define NDTPSO_ABI_TAG ndtpso_slam_abi_with_eigen
+#else
+#define NDTPSO_ABI_TAG ndtpso_slam_abi_without_eigen
+#endif
+extern "C" int NDTPSO_ABI_TAG;  // defined by libndtpso_slam (host/src/device.cpp) for the choice IT was built with
+namespace ndtpso_abi {
+__attribute__((used)) static int* const linalg_choice = &NDTPSO_ABI_TAG;
+}
 
 #ifdef NDTPSO_HAVE_EIGEN
 #include <eigen3/Eigen/Core>

@@ -21,9 +21,10 @@ using std::vector;
 struct ndtpso_points;  // device-resident scan (include/ndtpso_hip.h)
 struct ndtpso_map;     // device-resident map
 
-// Creates the process-wide device context now instead of at the first frame operation (optional).  Call it
-// before srand() when the std::rand() stream must be reproducible: runtime start-up may itself call rand().
-extern "C" void ndtpso_slam_device_init(void);
+// ndtpso_slam_device_init(): creates the process-wide device context now instead of at the first frame operation
+// (optional).  Call it before srand() when the std::rand() stream must be reproducible: runtime start-up may itself
+// call rand().  ndtpso_slam_last_error() / ndtpso_slam_error_count(): what a failed (skipped) device call left behind.
+#include "ndtpso_slam/status.h"
 
 class NDTFrame {
  public:
@@ -65,6 +66,13 @@ class NDTFrame {
   void resetCells();
 
   // ---- additions of this build (not in the reference) ----
+  // BASELINE.json's north star names an `addScan()`; the reference has no such method -- its ingest is loadLaser() into
+  // a per-scan frame followed by update() of the map with that frame at the estimated pose (ndtpso_slam_node.cpp:186,
+  // 194-198).  addScan() is that pair in one call: the scan, taken at `pose` in this frame's coordinates, is merged
+  // into this frame.  Equivalent to { NDTFrame f(Vector3d::Zero(), width, height, max(width, height), false, config());
+  // f.loadLaser(...); update(pose, &f); } -- same points, same order, same bits.
+  void addScan(const Vector3d& pose, const vector<float>& laser_data, const float& min_angle, const float& angle_increment,
+               const float& max_range);
   // new-frame points in the order cost_function visits them (cells, then insertion; core.cpp:33-36)
   void collectPoints(std::vector<double>& xy) const;
   const NDTPSOConfig& config() const { return s_config; }
@@ -101,7 +109,7 @@ class NDTFrame {
   std::vector<uint32_t> s_created;  // indices of created cells, in creation order
   bool s_table_dirty{true};         // the device reference table must be re-uploaded before the next align
   void append(const double* xy, const int32_t* idx, uint32_t n);
-  void uploadTable();
+  bool uploadTable();  // false: the device refused the table (error recorded, see status.h)
   // resident mode
   bool s_resident{false};
   ndtpso_points* d_scan_{nullptr};  // a one-cell frame that only ever had scans loaded: its point list

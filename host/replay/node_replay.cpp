@@ -7,9 +7,11 @@
 //          [pixels_per_metre]]]
 //   NODE_REPLAY_PACE_HZ=f in the environment delivers the scans at f Hz like a sensor would (the time a scan takes is
 //   then the latency a robot sees, with whatever the library does between scans off the clock)
-// With a dump prefix the shutdown export of the node (:141-172) runs too: a one-cell global map collects every scan
-// and pose and is dumped as <prefix>.{pose.csv,map.csv,gnuplot,png}; the reference frame (with its occupancy grid) as
+// With a dump prefix the shutdown export of the node (:141-172) runs too: a one-cell global map collects every 10th
+// scan (SAVE_DATA_TO_FILE_EACH_NUM_ITERS, ndtpso_slam_node.hpp:18; NODE_REPLAY_SAVE_EACH=n overrides) and every
+// pose and is dumped as <prefix>.{pose.csv,map.csv,gnuplot,png}; the reference frame (with its occupancy grid) as
 // <prefix>-ref-frame.*, plus the raw grid as <prefix>-ref-frame.og.bin for the tests.
+#include <algorithm>
 #include <chrono>
 #include <thread>
 #include <cstdio>
@@ -50,6 +52,8 @@ int main(int argc, char** argv) {
   NDTFrame* current_frame = new NDTFrame(initial_pose, frame_size, frame_size, cell_side, false);
   Vector3d previous_pose = initial_pose, current_pose = initial_pose;
   bool first_iteration = true;
+  unsigned iter_num = 0;
+  const unsigned kSaveEachNumIters = std::getenv("NODE_REPLAY_SAVE_EACH") ? (unsigned)std::max(1, std::atoi(std::getenv("NODE_REPLAY_SAVE_EACH"))) : 10u;
   std::vector<float> ranges((size_t)n_beams);
   double busy_s = 0.;
   const double pace_hz = std::getenv("NODE_REPLAY_PACE_HZ") ? std::atof(std::getenv("NODE_REPLAY_PACE_HZ")) : 0.;
@@ -70,7 +74,10 @@ int main(int argc, char** argv) {
     ref_frame->update(current_pose, current_frame);                            // :198
     if (k > 0) busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (global_map) {                                                          // :200-206
-      global_map->update(current_pose, current_frame);
+      // the node merges every SAVE_DATA_TO_FILE_EACH_NUM_ITERS-th scan (10, ndtpso_slam_node.hpp:18) into the global
+      // map, starting with the first, and records every pose
+      if (iter_num == 0) global_map->update(current_pose, current_frame);
+      iter_num = (iter_num + 1) % kSaveEachNumIters;
       global_map->addPose(0.025 * k, current_pose);
     }
     std::printf("%d %.17g %.17g %.17g\n", k, current_pose.x(), current_pose.y(), current_pose.z());

@@ -1,9 +1,14 @@
 #include "device.h"
 
+#include "ndtpso_slam/linalg.h"
+
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
+#include <set>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -15,6 +20,37 @@ std::once_flag g_once;
 bool g_alive = false;
 std::vector<std::pair<ndtpso_points*, uint32_t>> g_scan_pool;
 std::mutex g_pool_mutex;
+
+// error state of the library (ndtpso_slam/status.h)
+std::mutex g_err_mutex;
+std::string g_last_error;            // text of the most recent failure
+std::set<std::string> g_err_logged;  // call sites already reported on stderr
+std::atomic<unsigned long> g_err_count{0};
+
+bool abort_on_error() {
+  static const bool v = [] {
+    const char* e = std::getenv("NDTPSO_ABORT_ON_ERROR");
+    return e && e[0] == '1';
+  }();
+  return v;
+}
+
+void record_error(const char* what, int rc, const char* text) {
+  char buf[512];
+  std::snprintf(buf, sizeof(buf), "%s failed: %d %s", what, rc, text ? text : "");
+  bool first;
+  {
+    std::lock_guard<std::mutex> lock(g_err_mutex);
+    g_last_error = buf;
+    first = g_err_logged.insert(what).second;
+  }
+  ++g_err_count;
+  if (first || abort_on_error())
+    std::fprintf(stderr, "libndtpso_slam (MI355X build): %s%s\n", buf,
+                 abort_on_error() ? "" : " -- the call is skipped (further failures of this call are counted, not printed; "
+                                         "see ndtpso_slam_last_error())");
+  if (abort_on_error()) std::abort();
+}
 }  // namespace
 
 ndtpso_ctx* device() {
@@ -23,9 +59,11 @@ ndtpso_ctx* device() {
     if (const char* e = std::getenv("NDTPSO_DEVICE")) dev = std::atoi(e);
     const int rc = ndtpso_ctx_create(dev, &g_ctx);
     if (rc != NDTPSO_OK || !g_ctx) {
-      std::fprintf(stderr, "libndtpso_slam (MI355X build): no usable HIP device %d (error %d); there is no CPU path\n",
-                   dev, rc);
-      std::abort();
+      g_ctx = nullptr;  // every later device call fails with NDTPSO_E_ARG and is skipped: there is no CPU path
+      char what[96];
+      std::snprintf(what, sizeof(what), "creating a context on HIP device %d", dev);
+      record_error(what, rc, "no usable HIP device");
+      return;
     }
     g_alive = true;
     std::atexit([] {
@@ -63,7 +101,7 @@ ndtpso_points* acquire_scan(uint32_t capacity) {
       }
   }
   ndtpso_points* p = nullptr;
-  check(ndtpso_points_create(c, capacity, &p), "scan buffer");
+  if (!check(ndtpso_points_create(c, capacity, &p), "scan buffer")) return nullptr;
   return p;
 }
 
@@ -151,12 +189,33 @@ int score_mode() {
   return (e && std::strcmp(e, "f64") == 0) ? NDTPSO_SCORE_F64 : NDTPSO_SCORE_F32;
 }
 
-void check(int rc, const char* what) {
-  if (rc == NDTPSO_OK) return;
-  std::fprintf(stderr, "libndtpso_slam (MI355X build): %s failed: %d %s\n", what, rc, ndtpso_last_error(g_ctx));
-  std::abort();
+bool check(int rc, const char* what) {
+  if (rc == NDTPSO_OK) return true;
+  record_error(what, rc, g_ctx ? ndtpso_last_error(g_ctx) : "no device context");
+  return false;
 }
 
 }  // namespace ndtpso_host
 
-extern "C" void ndtpso_slam_device_init(void) { (void)ndtpso_host::device(); }
+extern "C" {
+// the Eigen-or-fallback choice this library was compiled with (ndtpso_slam/linalg.h): consumers reference the symbol
+// of THEIR choice, so a mismatch is an undefined reference at link time
+int NDTPSO_ABI_TAG = 1;
+
+void ndtpso_slam_device_init(void) { (void)ndtpso_host::device(); }
+
+// ndtpso_slam/status.h
+const char* ndtpso_slam_last_error(void) {
+  static thread_local std::string copy;
+  std::lock_guard<std::mutex> lock(ndtpso_host::g_err_mutex);
+  copy = ndtpso_host::g_last_error;
+  return copy.c_str();
+}
+unsigned long ndtpso_slam_error_count(void) { return ndtpso_host::g_err_count.load(); }
+void ndtpso_slam_clear_error(void) {
+  std::lock_guard<std::mutex> lock(ndtpso_host::g_err_mutex);
+  ndtpso_host::g_last_error.clear();
+  ndtpso_host::g_err_logged.clear();
+  ndtpso_host::g_err_count = 0;
+}
+}

@@ -1,5 +1,8 @@
-// Process-wide device context of the host library.  No CPU fallback: if the HIP library cannot create a
-// context the process reports the error and aborts.
+// Process-wide device context of the host library.  No CPU fallback: when the HIP library cannot create a context, or
+// a device call fails, the error is recorded (ndtpso_slam_last_error(), ndtpso_slam/status.h) and logged once per call
+// site, and the API call degrades -- align() returns its initial guess, update() / loadLaser() / build() do nothing --
+// so that a robot process survives a transient device fault the reference could never have had.  Nothing is ever
+// computed on the CPU instead.  NDTPSO_ABORT_ON_ERROR=1 restores abort-at-first-error (tests, debugging).
 #ifndef NDTPSO_HOST_DEVICE_H
 #define NDTPSO_HOST_DEVICE_H
 
@@ -9,9 +12,9 @@
 #include "../../include/ndtpso_hip.h"
 
 namespace ndtpso_host {
-ndtpso_ctx* device();                 // lazily created on HIP device $NDTPSO_DEVICE (default 0)
+ndtpso_ctx* device();                 // lazily created on HIP device $NDTPSO_DEVICE (default 0); nullptr if there is none
 int score_mode();                     // $NDTPSO_SCORE = f32 (default) | f64
-void check(int rc, const char* what); // abort with the C-ABI error text unless rc == NDTPSO_OK
+bool check(int rc, const char* what); // true if rc == NDTPSO_OK; otherwise records + logs the C-ABI error text, returns false
 const void*& table_owner();           // which frame's cell table currently sits in the device context
 bool resident_default();              // $NDTPSO_RESIDENT != 0
 bool alive();                         // false once the process-wide context has been torn down (atexit)

@@ -11,6 +11,10 @@ std::vector<Vector2d> g_no_points;  // what points_vector[slot] of a never-touch
 }
 
 NDTCell::Window::Window() : current_count(0), global_count(0), current_window_id(0) {
+  // Eigen's fixed-size vectors are NOT zero-initialised by their default constructor (the fallback types of linalg.h
+  // are): the reference zeroes them explicitly (NDTCell::NDTCell, ndtcell.cpp:5-19), and WINDOW_ADD starts from them
+  global_sum = Vector2d::Zero();
+  for (Vector2d& v : partial_sums) v = Vector2d::Zero();
   std::memset(partial_covars, 0, sizeof(partial_covars));
   std::memset(partial_counts, 0, sizeof(partial_counts));
   std::memset(global_covar_sum, 0, sizeof(global_covar_sum));
@@ -81,7 +85,8 @@ bool NDTCell::build() {
     xy[2 * i + 1] = pts[i].y();
   }
   const uint32_t off[2] = {0u, (uint32_t)pts.size()};
-  ndtpso_host::check(ndtpso_cells_build_windowed(ndtpso_host::device(), 1, &cw, off, xy.data()), "NDTCell::build");
+  if (!ndtpso_host::check(ndtpso_cells_build_windowed(ndtpso_host::device(), 1, &cw, off, xy.data()), "NDTCell::build"))
+    return built;  // device fault: the cell keeps its previous statistics
   w.global_sum = Vector2d(cw.global_sum[0], cw.global_sum[1]);
   w.partial_sums[id] = Vector2d(cw.slot_sum[0], cw.slot_sum[1]);
   for (int k = 0; k < 4; ++k) {
@@ -120,10 +125,12 @@ double NDTCell::normalDistribution(const Vector2d& point) {
     grid.cell_side = (double)side;
   }
   ndtpso_host::table_owner() = nullptr;
-  ndtpso_host::check(ndtpso_ref_set_cells(ndtpso_host::device(), &grid, 1, &index, m, win_->inv_covar), "normalDistribution");
+  if (!ndtpso_host::check(ndtpso_ref_set_cells(ndtpso_host::device(), &grid, 1, &index, m, win_->inv_covar), "normalDistribution"))
+    return 0.;
   const double pose[3] = {0., 0., 0.};
   double cost = 0.;
-  ndtpso_host::check(ndtpso_cost_batch(ndtpso_host::device(), p, 1, pose, 1, NDTPSO_SCORE_F64, &cost, nullptr), "normalDistribution");
+  if (!ndtpso_host::check(ndtpso_cost_batch(ndtpso_host::device(), p, 1, pose, 1, NDTPSO_SCORE_F64, &cost, nullptr), "normalDistribution"))
+    return 0.;
   return -cost;
 }
 

@@ -83,8 +83,11 @@ ndtpso_map* NDTFrame::ensureMap() {
 #if BUILD_OCCUPANCY_GRID
     og_cell_size = s_occupancy_grid.cell_size;
 #endif
-    ndtpso_host::check(ndtpso_map_create(ndtpso_host::device(), &grid, og_cell_size, map_pool_bytes(numOfCells), &d_map_),
-                       "device map");
+    if (!ndtpso_host::check(ndtpso_map_create(ndtpso_host::device(), &grid, og_cell_size, map_pool_bytes(numOfCells), &d_map_),
+                            "device map")) {
+      d_map_ = nullptr;  // every map call on this frame is then refused by the C-ABI (null handle) and skipped
+      return nullptr;
+    }
     if (d_scan_) {
       ndtpso_host::check(ndtpso_map_insert(d_map_, d_scan_, nullptr), "device map");
       ndtpso_host::release_scan(d_scan_, d_scan_cap_);
@@ -99,13 +102,13 @@ void NDTFrame::residentPoints(bool slot0_only, std::vector<double>& xy) const {
   xy.clear();
   if (d_map_) {
     uint64_t n = 0;
-    ndtpso_host::check(ndtpso_map_get_points(d_map_, slot0_only ? 1 : 0, nullptr, 0, &n), "map points");
+    if (!ndtpso_host::check(ndtpso_map_get_points(d_map_, slot0_only ? 1 : 0, nullptr, 0, &n), "map points")) return;
     xy.resize(2 * (size_t)n);
-    if (n) ndtpso_host::check(ndtpso_map_get_points(d_map_, slot0_only ? 1 : 0, xy.data(), n, &n), "map points");
+    if (n && !ndtpso_host::check(ndtpso_map_get_points(d_map_, slot0_only ? 1 : 0, xy.data(), n, &n), "map points")) xy.clear();
   } else if (d_scan_) {
     uint32_t n = 0;
     xy.resize(2 * (size_t)d_scan_upper_);
-    ndtpso_host::check(ndtpso_points_get(d_scan_, xy.data(), d_scan_upper_, &n), "scan points");
+    if (!ndtpso_host::check(ndtpso_points_get(d_scan_, xy.data(), d_scan_upper_, &n), "scan points")) n = 0;
     xy.resize(2 * (size_t)n);
   }
 }
@@ -115,15 +118,15 @@ void NDTFrame::syncHostView() {
   if (!d_map_) {
     if (d_scan_) {  // a one-cell frame holding loaded scans: its only cell exists as soon as one point survived
       uint32_t n = 0;
-      ndtpso_host::check(ndtpso_points_get(d_scan_, nullptr, 0, &n), "scan points");
+      if (!ndtpso_host::check(ndtpso_points_get(d_scan_, nullptr, 0, &n), "scan points")) return;
       cells[0].created = cells[0].created || n > 0;
     }
     return;
   }
   uint32_t n = 0;
-  ndtpso_host::check(ndtpso_map_get_cells(d_map_, nullptr, 0, &n), "map cells");
+  if (!ndtpso_host::check(ndtpso_map_get_cells(d_map_, nullptr, 0, &n), "map cells")) return;
   std::vector<ndtpso_cell_row> rows(n ? n : 1);
-  ndtpso_host::check(ndtpso_map_get_cells(d_map_, rows.data(), n, &n), "map cells");
+  if (!ndtpso_host::check(ndtpso_map_get_cells(d_map_, rows.data(), n, &n), "map cells")) return;
   for (NDTCell& c : cells) c.created = c.built = false;
   for (uint32_t k = 0; k < n; ++k) {
     NDTCell& c = cells[(size_t)rows[k].index];
@@ -150,7 +153,12 @@ void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle
                          const float& max_range) {
   built = false;
   const uint32_t n = (uint32_t)laser_data.size();
-  if (n == 0) return;
+  if (n == 0) {
+    // ndtframe.cpp:145 clears `built` before anything else: an empty scan still makes the next cost_function() build
+    // again, and a build repeated on unchanged cells is not a no-op in floating point (include/ndtpso_hip.h)
+    if (s_resident && d_map_) ndtpso_host::check(ndtpso_map_mark_unbuilt(d_map_), "loadLaser");
+    return;
+  }
   ndtpso_ctx* dev = ndtpso_host::device();
   ndtpso_scan_geom geom{n, min_angle, angle_increment, max_range, s_config.laserIgnoreEpsilon};
   const double t[3] = {s_trans.x(), s_trans.y(), s_trans.z()};
@@ -161,19 +169,20 @@ void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle
         d_scan_cap_ = std::max(kScanCapacity, n);
         d_scan_ = ndtpso_host::acquire_scan(d_scan_cap_);
         d_scan_upper_ = 0;
+        if (!d_scan_) return;  // no device memory: the scan is dropped (error recorded)
       }
       if (d_scan_upper_ + n <= d_scan_cap_) {
-        ndtpso_host::check(ndtpso_points_load_scan(d_scan_, laser_data.data(), &geom, t, &frame, d_scan_upper_ > 0), "loadLaser");
-        d_scan_upper_ += n;
+        if (ndtpso_host::check(ndtpso_points_load_scan(d_scan_, laser_data.data(), &geom, t, &frame, d_scan_upper_ > 0), "loadLaser"))
+          d_scan_upper_ += n;
         return;
       }
     }
     ndtpso_map* m = ensureMap();
-    ndtpso_host::check(ndtpso_map_mark_unbuilt(m), "loadLaser");  // ndtframe.cpp:145
+    if (!ndtpso_host::check(ndtpso_map_mark_unbuilt(m), "loadLaser")) return;  // ndtframe.cpp:145
     const uint32_t cap = std::max(kScanCapacity, n);
     ndtpso_points* tmp = ndtpso_host::acquire_scan(cap);
-    ndtpso_host::check(ndtpso_points_load_scan(tmp, laser_data.data(), &geom, t, nullptr, 0), "loadLaser");
-    ndtpso_host::check(ndtpso_map_insert(m, tmp, nullptr), "loadLaser");
+    if (ndtpso_host::check(ndtpso_points_load_scan(tmp, laser_data.data(), &geom, t, nullptr, 0), "loadLaser"))
+      ndtpso_host::check(ndtpso_map_insert(m, tmp, nullptr), "loadLaser");
     ndtpso_host::release_scan(tmp, cap);  // stream order keeps the buffer intact until the insert has read it
     return;
   }
@@ -181,7 +190,8 @@ void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle
   std::vector<int32_t> idx(n);
   uint32_t kept = 0;
   const ndtpso_grid grid = grid_of(*this);
-  ndtpso_host::check(ndtpso_scan_to_cells(dev, laser_data.data(), &geom, t, &grid, xy.data(), idx.data(), &kept), "loadLaser");
+  if (!ndtpso_host::check(ndtpso_scan_to_cells(dev, laser_data.data(), &geom, t, &grid, xy.data(), idx.data(), &kept), "loadLaser"))
+    return;
   append(xy.data(), idx.data(), kept);
 }
 
@@ -213,13 +223,13 @@ void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
   if (s_resident) {
     const double pose[3] = {trans.x(), trans.y(), trans.z()};
     ndtpso_map* m = ensureMap();
-    ndtpso_host::check(ndtpso_map_mark_unbuilt(m), "update");  // ndtframe.cpp:188, also when no point follows
+    if (!ndtpso_host::check(ndtpso_map_mark_unbuilt(m), "update")) return;  // ndtframe.cpp:188, also when no point follows
     if (new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {  // device to device, nothing to wait for
-      ndtpso_host::check(ndtpso_map_insert(m, new_frame->d_scan_, pose), "update");
+      if (!ndtpso_host::check(ndtpso_map_insert(m, new_frame->d_scan_, pose), "update")) return;
     } else {
       std::vector<double> pts;
       new_frame->collectPoints(pts);
-      ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), pose), "update");
+      if (!ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), pose), "update")) return;
     }
     // A frame that is aligned against gets its cells built and its table packed right away, off the next align()'s
     // critical path; should something other than align / build come first, the device takes the build back
@@ -238,8 +248,17 @@ void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
   std::vector<int32_t> idx(n);
   const double t[3] = {trans.x(), trans.y(), trans.z()};
   const ndtpso_grid grid = grid_of(*this);
-  ndtpso_host::check(ndtpso_points_to_cells(ndtpso_host::device(), &grid, xy.data(), n, t, xy.data(), idx.data()), "update");
+  if (!ndtpso_host::check(ndtpso_points_to_cells(ndtpso_host::device(), &grid, xy.data(), n, t, xy.data(), idx.data()), "update"))
+    return;
   append(xy.data(), idx.data(), n);
+}
+
+// north star's addScan(): loadLaser() into a one-cell per-scan frame + update() with it (see ndtframe.h)
+void NDTFrame::addScan(const Vector3d& pose, const vector<float>& laser_data, const float& min_angle,
+                       const float& angle_increment, const float& max_range) {
+  NDTFrame scan(Vector3d::Zero(), width, height, (double)std::max(width, height), false, s_config);  // ndtpso_slam_node.cpp:229-230
+  scan.loadLaser(laser_data, min_angle, angle_increment, max_range);
+  update(pose, &scan);
 }
 
 // reference: getCellIndex, ndtframe.cpp:240-249 (public single-point utility)
@@ -255,8 +274,7 @@ void NDTFrame::addPoint(Vector2d& point) {
   if (s_resident) {
     if (getCellIndex(point, widthNumOfCells, cell_side) == -1) return;  // outside the frame: dropped, `built` untouched
     const double p[2] = {point.x(), point.y()};
-    ndtpso_host::check(ndtpso_map_insert_host(ensureMap(), p, 1, nullptr), "addPoint");
-    built = false;
+    if (ndtpso_host::check(ndtpso_map_insert_host(ensureMap(), p, 1, nullptr), "addPoint")) built = false;
     return;
   }
   const int32_t idx = getCellIndex(point, widthNumOfCells, cell_side);
@@ -267,8 +285,7 @@ void NDTFrame::addPoint(Vector2d& point) {
 // reference: build, ndtframe.cpp:68-117 -- NDTCell::build for every created cell, batched into one device call
 void NDTFrame::build() {
   if (s_resident) {
-    ndtpso_host::check(ndtpso_map_build(ensureMap()), "build");
-    built = true;
+    if (ndtpso_host::check(ndtpso_map_build(ensureMap()), "build")) built = true;
     return;
   }
   const uint32_t n = (uint32_t)s_created.size();
@@ -300,7 +317,8 @@ void NDTFrame::build() {
       }
       off[k + 1] = (uint32_t)(xy.size() / 2);
     }
-    ndtpso_host::check(ndtpso_cells_build_windowed(ndtpso_host::device(), n, cw.data(), off.data(), xy.data()), "build");
+    if (!ndtpso_host::check(ndtpso_cells_build_windowed(ndtpso_host::device(), n, cw.data(), off.data(), xy.data()), "build"))
+      return;  // the cells keep their previous statistics; the frame stays un-built
     for (uint32_t k = 0; k < n; ++k) {
       NDTCell& c = cells[s_created[k]];
       NDTCell::Window& w = *c.win_;
@@ -355,9 +373,10 @@ void NDTFrame::rasteriseOccupancy() {
   if (index.empty()) return;
   std::vector<int8_t> v(index.size() * per_cell * per_cell);
   const ndtpso_grid grid = grid_of(*this);
-  ndtpso_host::check(ndtpso_occupancy_values(ndtpso_host::device(), &grid, g.cell_size, (uint32_t)index.size(),
-                                             index.data(), mean.data(), icov.data(), v.data()),
-                     "occupancy grid");
+  if (!ndtpso_host::check(ndtpso_occupancy_values(ndtpso_host::device(), &grid, g.cell_size, (uint32_t)index.size(),
+                                                  index.data(), mean.data(), icov.data(), v.data()),
+                          "occupancy grid"))
+    return;
   size_t t = 0;
   for (int32_t i : index) {
     const uint32_t cx = (uint32_t)i % widthNumOfCells, cy = (uint32_t)i / heightNumOfCells;
@@ -379,7 +398,8 @@ void NDTFrame::fetchOccupancy() const {
   auto& g = s_occupancy_grid;
   if (!s_resident || !d_map_ || !(g.cell_size > 0.)) return;
   uint32_t ext[4] = {UINT32_MAX, 0, UINT32_MAX, 0};
-  ndtpso_host::check(ndtpso_map_get_occupancy(d_map_, g.og.data(), g.og.size(), nullptr, nullptr, ext), "occupancy grid");
+  if (!ndtpso_host::check(ndtpso_map_get_occupancy(d_map_, g.og.data(), g.og.size(), nullptr, nullptr, ext), "occupancy grid"))
+    return;
   g.min_x_ind = ext[0], g.max_x_ind = ext[1], g.min_y_ind = ext[2], g.max_y_ind = ext[3];
 }
 
@@ -396,8 +416,8 @@ const vector<int8_t>& NDTFrame::occupancyGrid(uint32_t* og_width, uint32_t* og_h
 #endif
 
 // built cells -> device reference table (LDS image packed by ndtpso_ref_set_cells)
-void NDTFrame::uploadTable() {
-  if (!s_table_dirty && ndtpso_host::table_owner() == this) return;
+bool NDTFrame::uploadTable() {
+  if (!s_table_dirty && ndtpso_host::table_owner() == this) return true;
   std::vector<int32_t> index;
   std::vector<double> mean, icov;
   for (uint32_t i : s_created) {
@@ -409,10 +429,14 @@ void NDTFrame::uploadTable() {
     for (int j = 0; j < 4; ++j) icov.push_back(c.win_->inv_covar[j]);
   }
   const ndtpso_grid grid = grid_of(*this);
-  ndtpso_host::check(ndtpso_ref_set_cells(ndtpso_host::device(), &grid, (uint32_t)index.size(), index.data(),
-                                          mean.data(), icov.data()), "reference table upload");
+  if (!ndtpso_host::check(ndtpso_ref_set_cells(ndtpso_host::device(), &grid, (uint32_t)index.size(), index.data(),
+                                               mean.data(), icov.data()), "reference table upload")) {
+    ndtpso_host::table_owner() = nullptr;
+    return false;
+  }
   ndtpso_host::table_owner() = this;
   s_table_dirty = false;
+  return true;
 }
 
 // pso_optimization against this frame, core.cpp:50-116.  The std::rand() stream is drawn here, in the order and
@@ -436,18 +460,18 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
     }
     const ndtpso_pso_config abi = to_abi(cfg);
     std::vector<int32_t> draws(ndtpso_rand_draws(&abi));
-    ndtpso_host::draw_rand(draws.data(), draws.size());
+    ndtpso_host::draw_rand(draws.data(), draws.size());  // drawn even if the device call fails: the caller's stream moves on as it would have
     const double g[3] = {guess.x(), guess.y(), guess.z()};
     const double dv[3] = {deviation.x(), deviation.y(), deviation.z()};
-    double pose[3] = {0., 0., 0.};
-    ndtpso_host::check(ndtpso_map_align(m, pts, g, dv, &abi, 0u, draws.data(), ndtpso_host::score_mode(), pose, nullptr,
-                                        nullptr), "align");
-    built = true;
+    double pose[3] = {g[0], g[1], g[2]};
+    const bool ok = ndtpso_host::check(ndtpso_map_align(m, pts, g, dv, &abi, 0u, draws.data(), ndtpso_host::score_mode(), pose,
+                                                        nullptr, nullptr), "align");
+    if (ok) built = true;
     if (tmp) ndtpso_host::release_scan(tmp, tmp_cap);
-    return Vector3d(pose[0], pose[1], pose[2]);
+    return ok ? Vector3d(pose[0], pose[1], pose[2]) : guess;  // device fault: the initial guess, never a CPU estimate
   }
   if (!built) build();  // core.cpp:27-28 (lazy build inside cost_function)
-  uploadTable();
+  const bool table_ok = uploadTable();
   std::vector<double> xy;
   new_frame->collectPoints(xy);
   const ndtpso_pso_config abi = to_abi(cfg);
@@ -455,9 +479,10 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
   ndtpso_host::draw_rand(draws.data(), draws.size());
   const double g[3] = {guess.x(), guess.y(), guess.z()};
   const double dv[3] = {deviation.x(), deviation.y(), deviation.z()};
-  double pose[3] = {0., 0., 0.};
-  ndtpso_host::check(ndtpso_align(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), g, dv, &abi, 0u,
-                                  draws.data(), ndtpso_host::score_mode(), pose, nullptr, nullptr), "align");
+  double pose[3] = {g[0], g[1], g[2]};
+  if (!table_ok || !ndtpso_host::check(ndtpso_align(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), g, dv, &abi, 0u,
+                                                    draws.data(), ndtpso_host::score_mode(), pose, nullptr, nullptr), "align"))
+    return guess;
   return Vector3d(pose[0], pose[1], pose[2]);
 }
 
@@ -479,17 +504,20 @@ double NDTFrame::cost(const Vector3d& trans, const NDTFrame* new_frame) {
       ndtpso_host::check(ndtpso_points_set(tmp, xy.data(), (uint32_t)(xy.size() / 2)), "cost_function");
       pts = tmp;
     }
-    ndtpso_host::check(ndtpso_map_cost(m, pts, pose, 1, NDTPSO_SCORE_F64, &c), "cost_function");  // builds if need be
-    built = true;
+    if (ndtpso_host::check(ndtpso_map_cost(m, pts, pose, 1, NDTPSO_SCORE_F64, &c), "cost_function"))  // builds if need be
+      built = true;
+    else
+      c = 0.;
     if (tmp) ndtpso_host::release_scan(tmp, tmp_cap);
     return c;
   }
   if (!built) build();
-  uploadTable();
+  if (!uploadTable()) return 0.;
   std::vector<double> xy;
   new_frame->collectPoints(xy);
-  ndtpso_host::check(ndtpso_cost_batch(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), pose, 1,
-                                       NDTPSO_SCORE_F64, &c, nullptr), "cost_function");
+  if (!ndtpso_host::check(ndtpso_cost_batch(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), pose, 1,
+                                            NDTPSO_SCORE_F64, &c, nullptr), "cost_function"))
+    return 0.;
   return c;
 }
 
@@ -537,7 +565,7 @@ void NDTFrame::transform(Vector3d trans) {
     std::vector<double> pts;
     residentPoints(false, pts);
     ndtpso_map* m = ensureMap();
-    ndtpso_host::check(ndtpso_map_clear(m), "transform");  // fresh cells (ndtframe.cpp:123): not built
+    if (!ndtpso_host::check(ndtpso_map_clear(m), "transform")) return;  // fresh cells (ndtframe.cpp:123): not built
     const double t[3] = {trans.x(), trans.y(), trans.z()};
     ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), t), "transform");
     built = false;
@@ -559,8 +587,8 @@ void NDTFrame::transform(Vector3d trans) {
     std::vector<int32_t> idx(n);
     const double t[3] = {trans.x(), trans.y(), trans.z()};
     const ndtpso_grid grid = grid_of(*this);
-    ndtpso_host::check(ndtpso_points_to_cells(ndtpso_host::device(), &grid, xy.data(), n, t, xy.data(), idx.data()), "transform");
-    append(xy.data(), idx.data(), n);
+    if (ndtpso_host::check(ndtpso_points_to_cells(ndtpso_host::device(), &grid, xy.data(), n, t, xy.data(), idx.data()), "transform"))
+      append(xy.data(), idx.data(), n);
   }
   built = false;
 }

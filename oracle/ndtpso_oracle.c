@@ -582,6 +582,68 @@ void orc_pso_optimization(const double guess[3], orc_frame *ref, const orc_frame
   free(ps);
 }
 
+/* pso_optimization in the reference's PARALLEL shape, core.cpp:72-109: `#pragma omp parallel for schedule(auto)`
+ * over the particles of an iteration, unlocked reads of the global best (core.cpp:87), `omp critical` around its
+ * update (core.cpp:97-104), live std::rand() from every thread (glibc's lock included).  Racy and irreproducible
+ * exactly like the original with OMP_NUM_THREADS > 1 -- TIMING ONLY (bench.py's cpu_baseline), never a parity oracle. */
+void orc_pso_optimization_omp(const double guess[3], orc_frame *ref, const orc_frame *nf, const double deviation[3],
+                              const orc_pso_config *cfg, int n_threads, double out_pose[3], double *out_cost) {
+  const double zero_devi[3] = {1E-4, 1E-4, 1E-5};
+  double w = cfg->w;
+  int P = cfg->population, I = cfg->iterations, i, j;
+  orc_rand live = {NULL, 0, 0}; /* table == NULL: libc rand() */
+  orc_particle gbest, *ps = (orc_particle *)malloc((size_t)(P > 0 ? P : 1) * sizeof(orc_particle));
+  particle_init(&gbest, guess, zero_devi, ref, nf, &live, NULL);
+  for (i = 0; i < P; ++i) { /* serial, core.cpp:60-69 */
+    particle_init(&ps[i], guess, deviation, ref, nf, &live, NULL);
+    if (ps[i].cost < gbest.best_cost) {
+      gbest.best_cost = ps[i].best_cost;
+      memcpy(gbest.best_position, ps[i].best_position, sizeof(gbest.best_position));
+    }
+  }
+#ifdef _OPENMP
+  { /* core.cpp:75-76 */
+    int mx = omp_get_max_threads();
+    n_threads = (n_threads > 0 && n_threads < mx) ? n_threads : mx;
+  }
+#else
+  n_threads = 1;
+#endif
+  for (i = 0; i < I; ++i) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(auto) num_threads(n_threads)
+#endif
+    for (j = 0; j < P; ++j) {
+      orc_particle *p = &ps[j];
+      orc_rand mine = {NULL, 0, 0};
+      int k;
+      for (k = 0; k < 3; ++k) {
+        double r1 = fabs(orc_uniform_pm1(&mine));
+        double r2 = fabs(orc_uniform_pm1(&mine));
+        p->velocity[k] = w * p->velocity[k] + cfg->c1 * r1 * (p->best_position[k] - p->position[k]) +
+                         cfg->c2 * r2 * (gbest.best_position[k] - p->position[k]);
+        p->position[k] = p->position[k] + p->velocity[k];
+      }
+      p->cost = orc_cost_function(p->position, ref, nf, NULL);
+      if (p->cost < p->best_cost) {
+        p->best_cost = p->cost;
+        memcpy(p->best_position, p->position, sizeof(p->position));
+#ifdef _OPENMP
+#pragma omp critical(orc_gbest)
+#endif
+        if (p->cost < gbest.best_cost) {
+          gbest.best_cost = p->best_cost;
+          memcpy(gbest.best_position, p->best_position, sizeof(gbest.best_position));
+        }
+      }
+    }
+    w *= cfg->w_damping;
+  }
+  memcpy(out_pose, gbest.best_position, 3 * sizeof(double));
+  if (out_cost) *out_cost = gbest.best_cost;
+  free(ps);
+}
+
 /* NDTFrame::align, ndtframe.cpp:251-266 */
 void orc_frame_align(orc_frame *ref, const double guess[3], const orc_frame *nf, const orc_pso_config *cfg,
                      orc_rand *g, double out_pose[3]) {

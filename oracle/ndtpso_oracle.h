@@ -121,6 +121,12 @@ void orc_pso_optimization(const double guess[3], orc_frame *ref, const orc_frame
                           const double deviation[3], const orc_pso_config *cfg, orc_rand *rng,
                           double out_pose[3], double *out_cost, orc_pso_stats *stats);
 
+/* pso_optimization in the reference's parallel shape (core.cpp:72-109: OpenMP over the particles of an iteration,
+ * racy global best, live rand()): irreproducible like the original -- TIMING ONLY, never used as a checker. */
+void orc_pso_optimization_omp(const double guess[3], orc_frame *ref, const orc_frame *new_frame,
+                              const double deviation[3], const orc_pso_config *cfg, int n_threads,
+                              double out_pose[3], double *out_cost);
+
 /* occupancy grid of NDTFrame (ndtframe.h:22-29, ctor ndtframe.cpp:32-46, rasterised in build() :79-112).
  * Enable before build(); og is width_cells x height_cells int8 (index x + height*y as the reference writes it). */
 void orc_frame_enable_occupancy_grid(orc_frame *f, double og_cell_size);

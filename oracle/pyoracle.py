@@ -74,6 +74,7 @@ def lib():
     L.orc_cost_function.argtypes = [dp, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     L.orc_pso_optimization.argtypes = [dp, C.c_void_p, C.c_void_p, dp, C.POINTER(PSOConfig), C.POINTER(Rand),
                                        dp, dp, C.POINTER(PSOStats)]
+    L.orc_pso_optimization_omp.argtypes = [dp, C.c_void_p, C.c_void_p, dp, C.POINTER(PSOConfig), C.c_int, dp, dp]
     L.orc_frame_num_points.restype = C.c_uint
     L.orc_frame_num_points.argtypes = [C.c_void_p]
     L.orc_frame_get_points.restype = C.c_uint
@@ -214,6 +215,15 @@ class Frame:
         stats = dict(cost_evals=st.cost_evals, pbest_updates=st.pbest_updates,
                      gbest_updates=st.gbest_updates, rand_draws=st.rand_draws)
         return pose, cost.value, stats
+
+    def pso_omp(self, guess, new_frame: "Frame", deviation, cfg: PSOConfig, n_threads=0):
+        """pso_optimization in the reference's parallel shape (OpenMP over particles, live rand(), racy gbest,
+        core.cpp:72-109): irreproducible like the original -- for TIMING the CPU baseline only."""
+        pose = np.empty(3)
+        cost = C.c_double()
+        lib().orc_pso_optimization_omp(_dp(_vec3(guess)), self._h, new_frame._h, _dp(_vec3(deviation)), C.byref(cfg),
+                                       int(n_threads), _dp(pose), C.byref(cost))
+        return pose, cost.value
 
     def align(self, guess, new_frame: "Frame", cfg: PSOConfig | None, seed=None, table=None):
         c = cfg if cfg is not None else PSOConfig.make()

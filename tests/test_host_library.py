@@ -34,6 +34,48 @@ def test_host_library_exports_reference_api():
     assert "libndtpso_hip.so" in needed
 
 
+def test_abi_tag_records_the_vector_type_choice():
+    """ndtpso_slam/linalg.h: the library defines ndtpso_slam_abi_with_eigen or ndtpso_slam_abi_without_eigen for the
+    vector types IT was built with, and every consumer references the symbol of its own choice -- a node compiled with
+    Eigen against a library compiled without (different NDTCell layout) fails at link time instead of at run time."""
+    _build()
+    out = subprocess.check_output(["nm", "-D", os.path.join(HOST, "libndtpso_slam.so")], text=True)
+    tags = [l.split()[-1] for l in out.splitlines() if "ndtpso_slam_abi_" in l and " U " not in l]
+    assert len(tags) == 1 and tags[0] in ("ndtpso_slam_abi_with_eigen", "ndtpso_slam_abi_without_eigen"), tags
+    other = "ndtpso_slam_abi_with_eigen" if tags[0].endswith("without_eigen") else "ndtpso_slam_abi_without_eigen"
+    # the consumers built here reference the library's tag; one that was compiled for the other choice does not link
+    und = subprocess.check_output(["nm", "-D", os.path.join(HOST, "replay", "node_api_compile")], text=True)
+    assert tags[0] in und
+    src = 'extern "C" int %s; int main() { return %s; }' % (other, other)
+    r = subprocess.run(["g++", "-x", "c++", "-", "-o", "/dev/null", "-L" + HOST, "-lndtpso_slam",
+                        "-L" + os.path.join(ROOT, "ndtpso_slam_amd", "lib"), "-lndtpso_hip"], input=src, text=True,
+                       capture_output=True)
+    assert r.returncode != 0 and other in r.stderr
+
+
+def test_node_call_sequence_links_and_survives_a_missing_device(tmp_path):
+    """host/replay/node_api_compile.cpp makes exactly the calls ndtpso_slam_node.cpp makes (:64-78, 110, 155, 167, 186,
+    194, 198, 202, 206, 229-230).  Without arguments: link check.  On a device that does not exist every device call
+    fails: nothing aborts, align() returns its initial guess, the failures are counted and the text is available
+    (ndtpso_slam/status.h) -- and nothing is computed on the CPU instead."""
+    _build()
+    exe = os.path.join(HOST, "replay", "node_api_compile")
+    out = subprocess.check_output([exe], text=True)
+    assert out.startswith("NDT_WINDOW_SIZE 100 PSO 30 x 50")
+    env = {k: v for k, v in os.environ.items() if k != "NDTPSO_ABORT_ON_ERROR"}
+    r = subprocess.run([exe, str(tmp_path)], text=True, capture_output=True, env=dict(env, NDTPSO_DEVICE="99"))
+    assert r.returncode == 1, (r.stdout, r.stderr)                      # errors were counted, the process lived
+    last = r.stdout.strip().splitlines()[-1].split()
+    assert last[0] == "pose" and [float(v) for v in last[1:4]] == [0.0, 0.0, 0.0] and int(last[5]) > 0
+    assert "align failed" in r.stderr and "the call is skipped" in r.stderr
+    assert r.stderr.count("align failed") == 1                          # logged once per call site
+    assert os.path.exists(str(tmp_path / "node_api.pose.csv"))         # the shutdown export still ran
+    # NDTPSO_ABORT_ON_ERROR=1: the old behaviour for tests and debugging
+    r = subprocess.run([exe, str(tmp_path)], text=True, capture_output=True,
+                       env=dict(os.environ, NDTPSO_DEVICE="99", NDTPSO_ABORT_ON_ERROR="1"))
+    assert r.returncode < 0
+
+
 def test_bulk_rand_draw_is_indistinguishable_from_rand():
     """host/replay/rand_check.cpp: the bulk draw of the std::rand() stream (glibc state advanced in place) gives the
     outputs of n rand() calls and leaves the generator where they would; also with the slow path forced."""
@@ -124,6 +166,7 @@ def test_node_replay_map_export(tmp_path, oracle, resident, monkeypatch):
     _build()
     monkeypatch.setenv("NDTPSO_RESIDENT", resident)
     n_scans, P, I, seed, cs, ogcs = 8, 20, 20, 3, 0.5, 0.1
+    SAVE_EACH = 3   # the node's SAVE_DATA_TO_FILE_EACH_NUM_ITERS is 10; 3 puts three merges into an 8-scan replay
     ranges, _ = _trajectory(n_scans)
     path = tmp_path / "scans.bin"
     with open(path, "wb") as f:
@@ -133,7 +176,8 @@ def test_node_replay_map_export(tmp_path, oracle, resident, monkeypatch):
     prefix = str(tmp_path / "run")
     out = subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs), str(I),
                                    str(P), str(seed), str(ogcs), prefix, "20"], text=True,
-                                  env=dict(os.environ, NDTPSO_SCORE="f64", NDTPSO_ALIGN_FRAME_CONFIG="1"))
+                                  env=dict(os.environ, NDTPSO_SCORE="f64", NDTPSO_ALIGN_FRAME_CONFIG="1",
+                                           NODE_REPLAY_SAVE_EACH=str(SAVE_EACH)))
     got = np.array([[float(v) for v in line.split()[1:]] for line in out.strip().splitlines()])
 
     # the same run on the oracle (a short 20 x 20 PSO: NDTPSO_ALIGN_FRAME_CONFIG lets align() use the frame's config)
@@ -150,11 +194,13 @@ def test_node_replay_map_export(tmp_path, oracle, resident, monkeypatch):
         pose = prev.copy() if k == 0 else ref.align(prev, cur, cfg, table=stream[(k - 1) * n_draw:k * n_draw])
         prev = pose
         ref.update(pose, cur)
-        # what a one-cell global map keeps of this scan: the points that fall strictly inside the frame
-        c, s = np_ref.cos_sin(pose[2])   # one sincos(), like the reference built by GCC
-        pts = cur.points()
-        gx, gy = pts[:, 0] * c - pts[:, 1] * s + pose[0], pts[:, 0] * s + pts[:, 1] * c + pose[1]
-        n_map_points += int(((np.abs(gx) < FRAME_M / 2) & (np.abs(gy) < FRAME_M / 2)).sum())
+        # what the one-cell global map keeps: the node merges every SAVE_EACH-th scan, starting with the first
+        # (ndtpso_slam_node.cpp:200-205), and of it the points that fall strictly inside the frame
+        if k % SAVE_EACH == 0:
+            c, s = np_ref.cos_sin(pose[2])   # one sincos(), like the reference built by GCC
+            pts = cur.points()
+            gx, gy = pts[:, 0] * c - pts[:, 1] * s + pose[0], pts[:, 0] * s + pts[:, 1] * c + pose[1]
+            n_map_points += int(((np.abs(gx) < FRAME_M / 2) & (np.abs(gy) < FRAME_M / 2)).sum())
         cur = oracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
     assert np.abs(got[-1] - prev).max() < 1e-6
 

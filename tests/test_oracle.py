@@ -246,6 +246,25 @@ def test_oracle_batch_threads_agree(oracle, pairs8):
     assert np.array_equal(a, b) and np.array_equal(ca, cb) and used >= 1
 
 
+def test_parallel_shape_timing_mode_is_the_same_algorithm(oracle, pairs8):
+    """orc_pso_optimization_omp (the reference's OpenMP-over-particles shape, core.cpp:72-109; bench.py times it as the
+    CPU baseline) draws from the live libc rand(): on ONE thread after srand(seed) it must walk exactly the path of the
+    sequential oracle on the same stream; on several threads it is racy like the original and only has to land nearby."""
+    import ctypes
+    from conftest import oracle_frames
+    libc = ctypes.CDLL(None)
+    cfg = oracle.PSOConfig.make(20, 16)
+    ref, new = oracle_frames(oracle, pairs8, 0)
+    want, want_cost, _ = ref.pso((0, 0, 0), new, DEVIATION, cfg, seed=1234)
+    ref1, new1 = oracle_frames(oracle, pairs8, 0)
+    libc.srand(1234)
+    got, got_cost = ref1.pso_omp((0, 0, 0), new1, DEVIATION, cfg, n_threads=1)
+    assert np.array_equal(got, want) and got_cost == want_cost
+    ref4, new4 = oracle_frames(oracle, pairs8, 0)
+    many, many_cost = ref4.pso_omp((0, 0, 0), new4, DEVIATION, cfg, n_threads=4)
+    assert np.abs(many - want).max() < 0.05 and many_cost < 0.8 * want_cost  # costs are negative: a comparable optimum
+
+
 def test_golden_node_sequence(oracle):
     """Fixture G5 (tests/golden/make_golden_sequence.py): the node's loadLaser -> align -> update sequence with
     sliding-window cells, the occupancy grid and resetCells, recomputed and compared with the committed vectors."""
