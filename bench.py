@@ -37,7 +37,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=512, help="scan pairs per GPU per step")
     ap.add_argument("--particles", type=int, default=70)
     ap.add_argument("--iterations", type=int, default=70)
-    ap.add_argument("--score", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--score", choices=["f32", "f64", "exact"], default="f32")
     ap.add_argument("--cpu-sample", type=int, default=96, help="pairs timed on the host oracle (0 = skip)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency measurement")
     ap.add_argument("--identical", action="store_true", help="diagnostic: replicate pair 0 (no load imbalance)")
@@ -70,7 +70,7 @@ def main():
     from ndtpso_slam_amd import capi, sharding, synth
 
     B, P, I = args.pairs, args.particles, args.iterations
-    mode = capi.SCORE_F32 if args.score == "f32" else capi.SCORE_F64
+    mode = {"f32": capi.SCORE_F32, "f64": capi.SCORE_F64, "exact": capi.SCORE_EXACT}[args.score]
     first, last = sharding.shard_range(world * B, rank, world)   # weak scaling: B pairs per GPU
     pairs = synth.make_pairs(last - first, seed=2024, first_pair=first, total_pairs=world * B)
     if args.identical:

@@ -45,6 +45,15 @@ extern "C" {
 /* score arithmetic after the fp64 transform + cell lookup */
 #define NDTPSO_SCORE_F32 0 /* Mahalanobis + exp in fp32, fp64 accumulation (BASELINE config 2: "fp32") */
 #define NDTPSO_SCORE_F64 1 /* everything in fp64, reference operation order */
+/* NDTPSO_SCORE_EXACT: the results of NDTPSO_SCORE_F64 at (nearly) the speed of NDTPSO_SCORE_F32.  The PSO only ever
+ * COMPARES costs (core.cpp:63,94,97), so the fp32 score decides every comparison whose two sides are further apart
+ * than 2e-5 relative -- three orders of magnitude above its error -- and the rest ("near-ties", 0.1-1 per 70 x 70
+ * alignment) are arbitrated with the fp64 score of the poses involved, evaluated exactly as SCORE_F64 evaluates them;
+ * the returned cost is the fp64 score of the returned pose.  Pose and cost equal SCORE_F64's bit for bit (tests:
+ * every pair of BASELINE configs 3, 4 and 5).  Where the fp32 kernel cannot arbitrate (tables too large for the dense
+ * LDS form, degenerate overlaps, swarms of near-identical costs) the fp64-score kernel does the alignment.
+ * ndtpso_cost_batch / ndtpso_map_cost treat it as SCORE_F64. */
+#define NDTPSO_SCORE_EXACT 2
 
 typedef struct ndtpso_ctx ndtpso_ctx;
 
@@ -87,7 +96,9 @@ typedef struct {
   uint32_t gbest_updates; /* in-iteration gbest improvements */
   uint32_t status;        /* 0 ok; bit0: a reference point fell outside the staging window; bit1: more built cells
                              than record capacity; bit2: fp32 costs underflowed and the
-                             fp64 redo did not fit; bit3: dense-table overflow and the bitmap redo did not fit */
+                             fp64 redo did not fit; bit3: dense-table overflow and the bitmap redo did not fit.
+                             Bits 16-31 (NDTPSO_SCORE_EXACT): number of pbest / gbest comparisons of this alignment
+                             that were arbitrated with the fp64 score (saturating); flags = status & 0xffff */
   uint32_t t_start, t_end; /* low 32 bits of the device's 100 MHz real-time counter when the alignment's workgroup
                               started / finished (fused pairs kernel; load-balance diagnostics) */
 } ndtpso_align_stats;

@@ -14,6 +14,7 @@ from . import build as _build
 
 SCORE_F32 = 0
 SCORE_F64 = 1
+SCORE_EXACT = 2   # fp32 score + fp64 arbitration of undecidable comparisons: SCORE_F64's results (include/ndtpso_hip.h)
 
 OK, E_HIP, E_ARG, E_CAPACITY, E_STATE = 0, -1, -2, -3, -4
 
@@ -67,6 +68,15 @@ class AlignStats(C.Structure):
                 ("t_start", C.c_uint32), ("t_end", C.c_uint32)]
 
 
+def _stats_dict(st: "AlignStats") -> dict:
+    """The C struct as a dict, its `status` word split like STATS_DTYPE: flags (low half), SCORE_EXACT's count of
+    arbitrated comparisons (high half)."""
+    d = {k: getattr(st, k) for k, _ in AlignStats._fields_}
+    d["arbitrated"] = d["status"] >> 16
+    d["status"] &= 0xFFFF
+    return d
+
+
 class PairsPlan(C.Structure):
     _fields_ = [("lds_bytes", C.c_uint32), ("block_threads", C.c_uint32), ("workgroups_per_cu", C.c_uint32),
                 ("table_form", C.c_uint32), ("swarm_in_hbm", C.c_uint32), ("window_w", C.c_uint32),
@@ -81,7 +91,8 @@ class MapInfo(C.Structure):
 
 
 STATS_DTYPE = np.dtype([("n_points", "<u4"), ("n_built", "<u4"), ("cost_evals", "<u4"), ("rounds", "<u4"),
-                        ("gbest_updates", "<u4"), ("status", "<u4"), ("t_start", "<u4"), ("t_end", "<u4")])
+                        ("gbest_updates", "<u4"), ("status", "<u2"), ("arbitrated", "<u2"), ("t_start", "<u4"),
+                        ("t_end", "<u4")])   # the C struct's `status` word: flags in its low half, SCORE_EXACT's count above
 assert STATS_DTYPE.itemsize == C.sizeof(AlignStats)
 assert CELL_WINDOW_DTYPE.itemsize == C.sizeof(CellWindow) == 160
 
@@ -321,8 +332,7 @@ class Context:
                                          _p(_f64(deviation, 3), C.c_double), C.byref(cfg), C.c_uint32(int(seed)),
                                          _p(tab, C.c_int32) if tab is not None else None, mode,
                                          _p(pose, C.c_double), C.byref(cost), C.byref(st)))
-        stats = {k: getattr(st, k) for k, _ in AlignStats._fields_}
-        return pose, cost.value, stats
+        return pose, cost.value, _stats_dict(st)
 
     # ---- fused pairs ----
     def align_pairs(self, ref_ranges, new_ranges, geom: ScanGeom, grid: Grid, guess, deviation, cfg: PSOConfig,
@@ -476,7 +486,7 @@ class ResidentMap:
                                                   _p(_f64(deviation, 3), C.c_double), C.byref(cfg),
                                                   C.c_uint32(int(seed)), _p(tab, C.c_int32) if tab is not None else None,
                                                   mode, _p(pose, C.c_double), C.byref(cost), C.byref(st)))
-        return pose, cost.value, {k: getattr(st, k) for k, _ in AlignStats._fields_}
+        return pose, cost.value, _stats_dict(st)
 
     def cost(self, scan: ResidentScan, poses, mode=SCORE_F32) -> np.ndarray:
         poses = _f64(poses).reshape(-1, 3)

@@ -21,7 +21,7 @@ static_assert(sizeof(AlignStats) == sizeof(ndtpso_align_stats), "stats ABI");
 namespace {
 
 constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
-constexpr int kCtrlBytes = 512;      // control block (PsoShared + compaction counters)
+constexpr int kCtrlBytes = 832;      // control block (PsoShared + compaction counters)
 
 // LDS layout shared by every kernel.
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
@@ -147,17 +147,34 @@ __device__ __forceinline__ EvalCtx make_eval_ctx(const GridP& g, const WinP& wn,
   return E;
 }
 
+// bitmap-form table views into an image in HBM: [header | bitmap | mean | ab | cd | chol]
+__device__ __forceinline__ TableView image_table_view(const WinP& wn, const unsigned char* __restrict__ image) {
+  TableView T;
+  T.bm = reinterpret_cast<const uint2*>(image + kImageHeaderBytes);
+  T.mean = reinterpret_cast<const double2*>(image + image_mean_offset(wn.n_words));
+  T.ab = reinterpret_cast<const double2*>(image + image_ab_offset(wn.n_words, wn.rec_cap));
+  T.cd = reinterpret_cast<const double2*>(image + image_cd_offset(wn.n_words, wn.rec_cap));
+  T.chol = reinterpret_cast<const float4*>(image + image_chol_offset(wn.n_words, wn.rec_cap));
+  return T;
+}
+// exact mode (fp32-score dense kernels): the fp64 table the arbitration reads, where its image lies in HBM, goes into
+// the LDS parameter block of exact_tasks (thread 0 writes; the barriers of the swarm initialisation publish it)
+__device__ __forceinline__ void enable_arbitration(PsoShared* sh, const GridP& g, const WinP& wn,
+                                                   const unsigned char* __restrict__ image) {
+  if (threadIdx.x == 0) {
+    sh->xa.g = g;
+    sh->xa.xwn = wn;
+    sh->xa.XT = image_table_view(wn, image);
+  }
+}
+
 // the table image where it lies in HBM, for maps whose table does not fit in LDS (PATH 4 / 5)
 __device__ __forceinline__ EvalCtx make_eval_ctx_global(const GridP& g, const WinP& wn, const DenseP& dn,
                                                         const unsigned char* __restrict__ image) {
   EvalCtx E;
   E.g = g;
   E.wn = wn;
-  E.T.bm = reinterpret_cast<const uint2*>(image + kImageHeaderBytes);
-  E.T.mean = reinterpret_cast<const double2*>(image + image_mean_offset(wn.n_words));
-  E.T.ab = reinterpret_cast<const double2*>(image + image_ab_offset(wn.n_words, wn.rec_cap));
-  E.T.cd = reinterpret_cast<const double2*>(image + image_cd_offset(wn.n_words, wn.rec_cap));
-  E.T.chol = reinterpret_cast<const float4*>(image + image_chol_offset(wn.n_words, wn.rec_cap));
+  E.T = image_table_view(wn, image);
   E.dn = dn;
   E.lds0 = g_lds;
   return E;
@@ -390,7 +407,7 @@ k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict_
 
 // ---- K2 --------------------------------------------------------------------------------------
 // CLUSTER: gridDim.x workgroups share this one alignment (see ClusterP in ndtpso_kernels.hpp)
-template <int MODE, int PATH, bool CLUSTER>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false>
 __global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
 k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy, int n,
         const uint32_t* __restrict__ n_ptr, GridP g, WinP wn, Layout L, DenseP dn, PsoP ps,
@@ -407,23 +424,24 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   pad_points_wg(pts, n);
   __syncthreads();
   const EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
+  if constexpr (ARB) enable_arbitration(lds_ctrl(L.ctrl_off), g, wn, image);  // exact mode: the staged image is the fp64 table
   // a swarm too large for LDS lives in an HBM workspace, one per workgroup of a cluster (each keeps the whole swarm)
   // Two copies of the PSO, one per home of the swarm, so that in each the compiler knows the address space of the
   // swarm arrays: selecting the base pointer at run time made every swarm access a FLAT instruction (74 of them), and
   // the proposal / commit phases -- one or two waves working, the rest waiting -- are chains of exactly those accesses.
   if (L.swarm_global) {
     const Swarm sw = swarm_carve(ws + (size_t)cl.rank * swarm_bytes(ps.P), ps.P);
-    pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost,
-                                    stats, cl);
+    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
+                                         out_cost, stats, cl);
   } else {
     const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
-    pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose, out_cost,
-                                    stats, cl);
+    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
+                                         out_cost, stats, cl);
   }
   if (threadIdx.x == 0 && stats && cl.rank == 0) {
     const ImageHeader* h = reinterpret_cast<const ImageHeader*>(g_lds + L.hdr_off);
     stats->n_built = h->n_built;
-    stats->status = (stats->status & (kStatusNeedsF64 | kStatusClusterTimeout)) | h->status;
+    stats->status = (stats->status & (kStatusNeedsF64 | kStatusClusterTimeout | 0xffff0000u)) | h->status;
   }
 }
 
@@ -437,14 +455,14 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
 // CLUSTER (small batches: fewer alignments than compute units): cl.K consecutive workgroups share alignment
 // blockIdx.x / K -- each of them ingests both scans and builds the table for itself (identical arithmetic, so the
 // copies agree), then the PSO runs as a cluster (ClusterP).  Never combined with a gate.
-template <int MODE, int PATH, bool CLUSTER>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false>
 __global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
               const double* __restrict__ dev, const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables,
               size_t table_stride, unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
               double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl,
-              const double2* __restrict__ beam_dirs) {
+              const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride) {
   const size_t b = CLUSTER ? blockIdx.x / (unsigned)cl.K : blockIdx.x;
   if constexpr (CLUSTER) {
     cl.rank = (int)(blockIdx.x % (unsigned)cl.K);
@@ -482,10 +500,22 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     }
   }
   NDTPSO_SETUP_MARK(2);
+  // exact mode (ximg): the bitmap-form fp64 table goes to this workgroup's image in HBM as well
+  unsigned char* my_ximg = nullptr;
+  TableOut xout{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if constexpr (ARB) {
+    {
+      my_ximg = ximg + (CLUSTER ? (size_t)blockIdx.x : b) * ximg_stride;
+      xout.bm = reinterpret_cast<uint2*>(my_ximg + kImageHeaderBytes);
+      xout.mean = reinterpret_cast<double2*>(my_ximg + image_mean_offset(wn.n_words));
+      xout.ab = reinterpret_cast<double2*>(my_ximg + image_ab_offset(wn.n_words, wn.rec_cap));
+      xout.cd = reinterpret_cast<double2*>(my_ximg + image_cd_offset(wn.n_words, wn.rec_cap));
+    }
+  }
   build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
                  reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
                  reinterpret_cast<uint2*>(g_lds + L.bm2_off), reinterpret_cast<unsigned short*>(g_lds + L.plist_off),
-                 nullptr, nullptr, path_is_dense(PATH) ? &dn : nullptr, g_lds, PATH == 3);
+                 nullptr, nullptr, path_is_dense(PATH) ? &dn : nullptr, g_lds, PATH == 3, my_ximg ? &xout : nullptr);
   NDTPSO_SETUP_MARK(3);
   // new frame <- scan B (one-cell frame of the same size: the point list inside the frame, ndtpso_slam_node.cpp:229-230)
   const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
@@ -500,17 +530,18 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
 #endif
 
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
+  if constexpr (ARB) enable_arbitration(lds_ctrl(L.ctrl_off), g, wn, my_ximg);
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
   if (L.swarm_global) {  // (two copies: see k_align)
     const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P);
-    pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                                    tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
-                                    out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                                         tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
+                                         out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
   } else {
     const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
-    pso_run_wg<MODE, PATH, CLUSTER>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                                    tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
-                                    out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                                         tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
+                                         out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
   }
   if (threadIdx.x == 0 && writer) {
     stats[b].n_built = hdr->n_built;
@@ -618,7 +649,7 @@ struct ndtpso_ctx {
   uint32_t n_rows = 0;
   int n_cus = 256;  // compute units of the device (multiProcessorCount)
   size_t cluster_next = 0;  // next unused arrival counter of the ring in `cluster`
-  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster, cluster_xc;
+  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster, cluster_xc, ximg;
   PinnedRing pinned;
   BeamDirs beam_dirs[4];  // cached beam directions of the scan geometries in use (beam_directions)
   unsigned beam_dirs_next = 0;
@@ -885,6 +916,13 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   BIG_PATHS(k_align_pairs, COMMA true)
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, true>);
+  // exact mode (arbitrating variants of the fp32-score dense kernels)
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, true, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, true, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, false, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, true, true>);
 #define GLOBAL_PATHS(K, ...)                                                   \
   if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 4 __VA_ARGS__>);         \
   if (e == hipSuccess) e = allow_big_lds(K<kScoreF32, 5 __VA_ARGS__>);         \
@@ -1295,7 +1333,7 @@ static int cost_launch(ndtpso_ctx* c, const unsigned char* image, const GridP& g
 int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double* poses, uint32_t m, int mode,
                       double* costs, int32_t* cell_idx) {
   if (!c || (!xy && n) || !poses || !costs || m == 0) return fail(c, NDTPSO_E_ARG, "null argument");
-  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
+  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64 && mode != NDTPSO_SCORE_EXACT) return fail(c, NDTPSO_E_ARG, "bad score mode");
   if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
@@ -1375,6 +1413,17 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
                       AfterLaunch after = AfterLaunch{nullptr, nullptr}) {
   Plan plan;
   const uint32_t n = src.n;
+  // exact mode: the fp32-score kernel with arbitration where the table takes the dense form, else the fp64 score itself
+  int exact = 0;
+  if (mode == NDTPSO_SCORE_EXACT) {
+    if (!make_plan(NDTPSO_SCORE_F32, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true) ||
+        plan.path != 2) {
+      mode = NDTPSO_SCORE_F64;
+    } else {
+      mode = NDTPSO_SCORE_F32;
+      exact = 1;
+    }
+  }
   if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true))
     return fail(c, NDTPSO_E_CAPACITY, "points + swarm do not fit in LDS");
   const Layout& L = plan.L;
@@ -1393,15 +1442,18 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     if (int rc = cluster_counters(c, 1, (size_t)2 * cl.stride * 8, &bar, &cl.xc)) return rc;
     cl.bar = bar;
   }
-#define LAUNCH_ALIGN_C(MODE, PATH, CL)                                                                             \
-  hipLaunchKernelGGL((k_align<MODE, PATH, CL>), dim3(K), dim3(waves * 64), L.total, c->stream,                     \
+#define LAUNCH_ALIGN_CA(MODE, PATH, CL, ARB)                                                                       \
+  hipLaunchKernelGGL((k_align<MODE, PATH, CL, ARB>), dim3(K), dim3(waves * 64), L.total, c->stream,                \
                      src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
                      ps, (const double*)c->table.p, (const double*)c->table.p + 3, seed,                           \
                      have_table ? (const int32_t*)((const unsigned char*)c->table.p + kGuessBytes) : nullptr,      \
                      (unsigned char*)c->ws.p, d_out, d_out + 3, d_stats, cl)
+#define LAUNCH_ALIGN_C(MODE, PATH, CL) LAUNCH_ALIGN_CA(MODE, PATH, CL, false)
 #define LAUNCH_ALIGN(MODE, PATH) \
   do { if (K > 1) LAUNCH_ALIGN_C(MODE, PATH, true); else LAUNCH_ALIGN_C(MODE, PATH, false); } while (0)
-  if (mode == NDTPSO_SCORE_F32) {
+  if (mode == NDTPSO_SCORE_F32 && exact) {  // (plan.path == 2, see above)
+    if (K > 1) LAUNCH_ALIGN_CA(kScoreF32, 2, true, true); else LAUNCH_ALIGN_CA(kScoreF32, 2, false, true);
+  } else if (mode == NDTPSO_SCORE_F32) {
     switch (plan.path) {
       case 2: LAUNCH_ALIGN(kScoreF32, 2); break;
       case 1: LAUNCH_ALIGN(kScoreF32, 1); break;
@@ -1419,6 +1471,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   }
 #undef LAUNCH_ALIGN
 #undef LAUNCH_ALIGN_C
+#undef LAUNCH_ALIGN_CA
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpyAsync(host, c->out.p, (4 + sizeof(AlignStats) / 8) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
   if (after.fn)
@@ -1428,7 +1481,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     AlignStats st;
     std::memcpy(&st, host + 4, sizeof(st));
     if (st.status & kStatusClusterTimeout)  // the cluster was not co-resident (device shared with other work): one workgroup
-      return align_once(c, src, cfg, seed, have_table, mode, host, false);
+      return align_once(c, src, cfg, seed, have_table, exact ? NDTPSO_SCORE_EXACT : mode, host, false);
   }
   return NDTPSO_OK;
 }
@@ -1441,7 +1494,7 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
                  const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
                  double* out_cost, ndtpso_align_stats* stats) {
   if (!c || (!xy && n) || !guess || !deviation || !out_pose) return fail(c, NDTPSO_E_ARG, "null argument");
-  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
+  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64 && mode != NDTPSO_SCORE_EXACT) return fail(c, NDTPSO_E_ARG, "bad score mode");
   if (int rc = check_pso(c, cfg)) return rc;
   if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1465,7 +1518,7 @@ static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_con
   if (rc != NDTPSO_OK) return rc;
   AlignStats st;
   std::memcpy(&st, host + 4, sizeof(st));
-  if (mode == NDTPSO_SCORE_F32 && (st.status & kStatusNeedsF64)) {
+  if (mode != NDTPSO_SCORE_F64 && (st.status & kStatusNeedsF64)) {
     static const bool log_redo = std::getenv("NDTPSO_LOG_REDO") != nullptr;  // diagnostics: how often this happens
     if (log_redo) std::fprintf(stderr, "ndtpso: alignment handed to the fp64-score kernel\n");
     rc = align_once(c, src, cfg, seed, have_table, NDTPSO_SCORE_F64, host);
@@ -1508,7 +1561,8 @@ int ndtpso_align_pairs_footprint(const ndtpso_scan_geom* geom, const ndtpso_grid
 
 int ndtpso_align_pairs_describe(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg,
                                 int mode, uint32_t n_pairs, ndtpso_pairs_plan* out) {
-  if (!out || (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64)) return NDTPSO_E_ARG;
+  if (!out || (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64 && mode != NDTPSO_SCORE_EXACT)) return NDTPSO_E_ARG;
+  if (mode == NDTPSO_SCORE_EXACT) mode = NDTPSO_SCORE_F32;  // the same kernels and footprint
   std::memset(out, 0, sizeof(*out));
   GridP g;
   WinP wn;
@@ -1532,7 +1586,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
                         const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess, const double* d_dev,
                         const ndtpso_pso_config* cfg, const uint32_t* d_seeds, const int32_t* d_tables, int mode,
                         double* d_pose, double* d_cost, AlignStats* d_stats, uint32_t gate, bool allow_dense,
-                        int* path_out, bool allow_cluster = false) {
+                        int* path_out, bool allow_cluster = false, bool exact = false) {
   GridP g;
   WinP wn;
   Plan plan;
@@ -1562,13 +1616,24 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   const size_t stride = ndtpso_rand_draws(cfg);
   const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population) : 0;
   if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs * (size_t)K));
-#define LAUNCH_PAIRS_C(MODE, PATH, CL)                                                                            \
-  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL>), dim3(n_pairs * (unsigned)K), dim3(waves * 64), plan.L.total, \
+  // exact mode on the dense form: one fp64 table image per workgroup in HBM (bitmap of the per-alignment window, mean,
+  // ab, cd), written by the table build and read by the arbitration only
+  size_t ximg_stride = 0;
+  if (exact && mode == NDTPSO_SCORE_F32 && plan.path == 2) {
+    ximg_stride = (size_t)round_up(image_bytes(plan.dense_cap / 32 + 2, wn.rec_cap), 256);
+    HIP_TRY(c, c->ximg.reserve(ximg_stride * n_pairs * (size_t)K));
+  }
+  unsigned char* d_ximg = ximg_stride ? (unsigned char*)c->ximg.p : nullptr;
+#define LAUNCH_PAIRS_CA(MODE, PATH, CL, ARB)                                                                      \
+  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB>), dim3(n_pairs * (unsigned)K), dim3(waves * 64), plan.L.total, \
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
                      d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
-                     cl, dirs)
+                     cl, dirs, d_ximg, ximg_stride)
+#define LAUNCH_PAIRS_C(MODE, PATH, CL) LAUNCH_PAIRS_CA(MODE, PATH, CL, false)
 #define LAUNCH_PAIRS(MODE, PATH) \
   do { if (K > 1) LAUNCH_PAIRS_C(MODE, PATH, true); else LAUNCH_PAIRS_C(MODE, PATH, false); } while (0)
+#define LAUNCH_PAIRS_X(PATH) \
+  do { if (K > 1) LAUNCH_PAIRS_CA(kScoreF32, PATH, true, true); else LAUNCH_PAIRS_CA(kScoreF32, PATH, false, true); } while (0)
   // dense form: when every record lies below 64 KB of LDS the table entries can be the records' byte addresses
   // (PATH 3: one shift less per point in the score loop); NDTPSO_BYTE_ENTRIES=0 keeps the general form
   static const bool allow_byte_entries = [] {
@@ -1576,13 +1641,17 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     return !(e && e[0] == '0');
   }();
   const bool byte_entries = plan.path == 2 && allow_byte_entries && plan.dn.rec_off + 32 * (wn.rec_cap + 1) <= 65536;
-  if (mode == NDTPSO_SCORE_F32) {
+  if (d_ximg) {  // exact mode on the dense form
+    if (byte_entries) LAUNCH_PAIRS_X(3); else LAUNCH_PAIRS_X(2);
+  } else if (mode == NDTPSO_SCORE_F32) {
     if (byte_entries) LAUNCH_PAIRS(kScoreF32, 3); else if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
   } else {
     if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
   }
 #undef LAUNCH_PAIRS
+#undef LAUNCH_PAIRS_X
 #undef LAUNCH_PAIRS_C
+#undef LAUNCH_PAIRS_CA
   HIP_TRY(c, hipGetLastError());
   return NDTPSO_OK;
 }
@@ -1594,7 +1663,7 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
                            ndtpso_align_stats* d_stats) {
   if (!c || !d_ref || !d_new || !d_guess || !d_dev || !d_pose || (!d_seeds && !d_tables))
     return fail(c, NDTPSO_E_ARG, "null argument");
-  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64) return fail(c, NDTPSO_E_ARG, "bad score mode");
+  if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64 && mode != NDTPSO_SCORE_EXACT) return fail(c, NDTPSO_E_ARG, "bad score mode");
   if (n_pairs == 0) return NDTPSO_OK;
   HIP_TRY(c, hipSetDevice(c->device));
   AlignStats* st = reinterpret_cast<AlignStats*>(d_stats);
@@ -1605,13 +1674,25 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
   HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(AlignStats) * (size_t)n_pairs, c->stream));
   int path = 0;
   const bool small_batch = n_pairs * 2u <= (uint32_t)c->n_cus;
+  // exact mode: the fp32-score kernel arbitrating in fp64 (dense form) -- or, where the dense form is not available,
+  // the fp64 score itself; flagged alignments are redone by the fp64-score kernel
+  bool exact = mode == NDTPSO_SCORE_EXACT;
+  if (exact) {
+    GridP g0;
+    WinP w0;
+    Plan p0;
+    int waves0 = 0;
+    const int rc0 = pairs_plan(geom, grid, cfg, NDTPSO_SCORE_F32, n_pairs, &g0, &w0, &p0, &waves0, true, (unsigned)c->n_cus);
+    mode = (rc0 == NDTPSO_OK && p0.path == 2) ? NDTPSO_SCORE_F32 : NDTPSO_SCORE_F64;
+    exact = mode == NDTPSO_SCORE_F32;
+  }
   int rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
-                        st, 0u, true, &path, small_batch);
+                        st, 0u, true, &path, small_batch, exact);
   if (rc != NDTPSO_OK) return rc;
   if (std::getenv("NDTPSO_NO_REDO")) return rc;  // diagnostics only
   if (small_batch) {  // a cluster that was not co-resident gave up (bounded wait): those alignments on one workgroup each
     rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
-                      st, kStatusClusterTimeout, true, nullptr);
+                      st, kStatusClusterTimeout, true, nullptr, false, exact);
     if (rc != NDTPSO_OK) return rc;
   }
   if (mode != NDTPSO_SCORE_F32) return rc;
@@ -1619,9 +1700,9 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
   //  - dense form only: alignments whose occupied box exceeded the provisioned cell table -> bitmap form;
   //  - alignments whose fp32 costs fell in the underflow regime (degenerate overlap) -> fp64 score.
   // If a redo form does not fit in LDS its flag simply stays set in the stats block.
-  if (path == 2) {
-    rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F32,
-                      d_pose, d_cost, st, kStatusNeedsBitmap, false, nullptr);
+  if (path == 2) {  // (exact mode: the bitmap form cannot arbitrate, the fp64 score takes those alignments)
+    rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables,
+                      exact ? NDTPSO_SCORE_F64 : NDTPSO_SCORE_F32, d_pose, d_cost, st, kStatusNeedsBitmap, false, nullptr);
     if (rc != NDTPSO_OK && rc != NDTPSO_E_CAPACITY) return rc;
   }
   rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose,

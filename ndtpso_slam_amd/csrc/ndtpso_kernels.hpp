@@ -20,6 +20,8 @@ namespace ndtpso {
 
 constexpr int kScoreF32 = 0;
 constexpr int kScoreF64 = 1;
+// NDTPSO_SCORE_EXACT (2) is not a third kernel family: it is the fp32-score kernel with an exact (fp64) table image at
+// hand (EvalCtx::arb), which arbitrates every comparison its fp32 costs cannot decide -- see "arbitration" below.
 constexpr int kWave = 64;
 constexpr int kImageHeaderBytes = 64;
 __host__ __device__ constexpr int align16_c(int x) { return (x + 15) & ~15; }
@@ -695,7 +697,8 @@ __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsi
 __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const double2* pts, int n,
                                       ImageHeader* hdr, const TableOut& out, int* key, int* cellkey, int* cnt,
                                       uint2* bm2, unsigned short* plist, CellRow* rows, uint32_t* n_rows_out,
-                                      const DenseP* dn, unsigned char* lds0, bool byte_entries = false) {
+                                      const DenseP* dn, unsigned char* lds0, bool byte_entries = false,
+                                      const TableOut* xout = nullptr /* exact mode: bitmap, mean, ab, cd also to HBM */) {
   const int tid = threadIdx.x, nt = blockDim.x;
   uint2* bm = out.bm;
   if (dn) dense_clear_wg(*dn, lds0, byte_entries);
@@ -805,6 +808,8 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   }
   __syncthreads();
   if (tid == 0 && (int)hdr->n_built > wn.rec_cap) atomicOr(&hdr->status, 2u);
+  if (xout)
+    for (int w = tid; w < wn.n_words; w += nt) xout->bm[w] = bm[w];
 
   NDTPSO_BT(4);
   // 5a. Per-cell point lists in beam order (= the reference's insertion order): every point files itself at its rank
@@ -904,6 +909,11 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
       const unsigned slot = bm_slot(bm, mykey);
       if ((int)slot < wn.rec_cap) {
         if (dn) dense_put(g, *dn, lds0, slot, mykey % wn.w, mykey / wn.w, mx, my, ia, ib, ic, id, byte_entries);
+        if (xout) {
+          xout->mean[slot] = make_double2(mx, my);
+          xout->ab[slot] = make_double2(ia, ib);
+          xout->cd[slot] = make_double2(ic, id);
+        }
         if (out.mean) out.mean[slot] = make_double2(mx, my);
         if (out.ab) {
           out.ab[slot] = make_double2(ia, ib);
@@ -1101,6 +1111,24 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P) {
   return sw;
 }
 
+// Parameter block of exact_tasks (exact mode), kept in LDS: filled once by setup_exact_wg, so that the fp32-score kernels
+// carry none of it in registers (the block used to travel in EvalCtx: 17 more SGPRs live through the whole PSO, the
+// spill lanes they needed took VGPRs from the score loop).
+struct ExactArgs {
+  GridP g;
+  WinP xwn;
+  TableView XT;
+  const double2* pts;
+  int n;
+  const double* tpos;  // [3][S]
+  const double* pb;    // [3][S]
+  double* tcost;       // [S]
+  double* pbc;         // [S]
+  const double* gb;    // [3]
+  double* xgbc;
+  int S;
+};
+constexpr int kMaxNear = 16;  // undecidable comparisons one evaluation group may contain before the alignment is handed over
 struct PsoShared {  // small control block in LDS
   double gb[3];
   double gbc;
@@ -1108,6 +1136,12 @@ struct PsoShared {  // small control block in LDS
   int tiny;      // fp32 score mode: some cost of the current group fell in the underflow regime
   int timed_out; // cluster mode: a workgroup of the cluster did not arrive at an exchange
   RngState rng;
+  // arbitration (exact mode): items of a group whose fp32 cost is too close to their pbest's or the gbest's to decide
+  // the comparison; rotating by group number like jstar
+  int near_cnt[3];
+  unsigned short near_list[3][kMaxNear];
+  double xgbc;  // fp64 score of the gbest position (arbitration scratch)
+  ExactArgs xa;
 };
 
 // PATH: 0 = bitmap table, true division by cell_side; 1 = bitmap table, power-of-two cell side; 2 = dense fast path;
@@ -1192,11 +1226,94 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
 }
 
 
+// ---- exact mode: arbitration of the comparisons the fp32 score cannot decide ---------------------------------
+//
+// The PSO consumes a cost only through `cost < best_cost` / `cost < global_best.best_cost` (core.cpp:63,94,97); the
+// value itself survives only as a later comparison's right-hand side and as the returned gbest cost.  The fp32 score
+// is within ~1e-8 relative of the fp64 one (worst case seen 6e-6 absolute on costs of 300..900), so a comparison
+// whose two sides differ by more than kArbRel * |gbest cost| -- three orders of magnitude above that -- comes out the
+// same in either arithmetic.  The few that are closer ("near": 0.1-1 per 70 x 70 alignment) are ARBITRATED: the
+// proposal, the particle's pbest position and the gbest position are scored in fp64 exactly as the fp64-score kernels
+// score them (same operation order, same summation order, the bitmap-form table read from its HBM image), the three
+// stored costs are replaced by those values and the comparison is redone.  Every decision is then the fp64 mode's, so
+// the returned pose is the fp64 mode's bit for bit; the returned cost is the fp64 score of that pose, also its.
+// What this rests on: the fp32 score's error staying below kArbRel / 2 -- measured, not proven; and the dense
+// form's binning (gx within 1e-14 cells of the reference's value, see score_trip_dense).
+constexpr double kArbRel = 2e-5;
+
+__device__ __forceinline__ void near_note(int* near_cnt, unsigned short* near_list, int j) {
+  const int k = atomicAdd(near_cnt, 1);
+  if (k < kMaxNear) near_list[k] = (unsigned short)j;
+}
+__device__ __forceinline__ bool near_tie(double a, double b, double tau) { return fabs(a - b) <= tau; }
+
+// The fp64 scores of an arbitration, one task per wave.  Deliberately NOT inlined and not a template: one copy in the
+// library, called from the cold blocks of the fp32-score kernels with its parameter block in LDS -- the fp64 score
+// loop inlined into them cost the hot loop its registers (private segment 0 -> 208 bytes, -17 % throughput).
+// kind 0: swarm initialisation -- the proposals of the listed items; 1: an evaluation group -- proposal and pbest
+// position of every listed item plus the gbest position (into *xgbc); 2: the gbest position only (returned cost).
+// The scores replace tcost[j] / pbc[j].  Each is what the fp64-score kernels compute for that pose (sincos of the
+// heading as the proposal step takes it, eval_pose_wave<kScoreF64>, table read from its HBM image).
+// Called by every thread of the workgroup; ends with a barrier.
+// The fp64 score of one pose in a rolled loop -- one chunk of 64 points per trip -- that adds its terms into the
+// accumulators the four-chunk trips of eval_pose_wave_t<kScoreF64> would (chunk c of a full trip into acc[c % 4], the
+// chunks behind the last full trip into acc[0]) and folds them the same way: the same sum bit for bit, in a fraction
+// of the registers and of the code.
+__device__ inline double eval_pose_wave_f64_rolled(const GridP& g, const WinP& wn, const TableView& T,
+                                                    const double2* __restrict__ pts, int n, double c, double s, double tx,
+                                                    double ty) {
+  const int chunks = round_up(n, kWave) / kWave, in_trips = chunks & ~3;
+  double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+#pragma unroll 1
+  for (int k = 0; k < chunks; ++k) {
+    double acc[4] = {0., 0., 0., 0.};
+    score_trip<kScoreF64, false, 1, false>(g, wn, T, pts, k * kWave, n, c, s, tx, ty, acc, nullptr);
+    const int u = k < in_trips ? (k & 3) : 0;
+    // (adding +0. to the other three accumulators leaves them as they are: no accumulator is ever -0.)
+    a0 += u == 0 ? acc[0] : 0.;
+    a1 += u == 1 ? acc[0] : 0.;
+    a2 += u == 2 ? acc[0] : 0.;
+    a3 += u == 3 ? acc[0] : 0.;
+  }
+  return -wave_sum((a0 + a1) + (a2 + a3));
+}
+
+__device__ __forceinline__ void exact_tasks(const ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
+  const int n_waves = blockDim.x >> 6;
+  const int n_tasks = kind == 0 ? cnt : (kind == 1 ? 2 * cnt + 1 : 1);
+#pragma unroll 1
+  for (int t = wave_id(); t < n_tasks; t += n_waves) {
+    double x, y, th;
+    double* dst;
+    if (kind == 2 || (kind == 1 && t == 2 * cnt)) {
+      x = ap->gb[0];
+      y = ap->gb[1];
+      th = ap->gb[2];
+      dst = ap->xgbc;
+    } else {
+      const int j = list[kind == 0 ? t : (t >> 1)];
+      const bool pbest = kind == 1 && (t & 1);
+      const double* src = pbest ? ap->pb : ap->tpos;
+      x = src[j];
+      y = src[ap->S + j];
+      th = src[2 * ap->S + j];
+      dst = pbest ? &ap->pbc[j] : &ap->tcost[j];
+    }
+    double sn, cn;
+    sincos(th, &sn, &cn);
+    // (the true division serves power-of-two cell sides too: x / cs == x * (1 / cs) exactly there)
+    const double c = eval_pose_wave_f64_rolled(ap->g, ap->xwn, ap->XT, ap->pts, ap->n, cn, sn, x, y);
+    if (lane_id() == 0) *dst = c;
+  }
+  __syncthreads();
+}
+
 // One wave per item.  `improver` (optional): the evaluating wave itself records the lowest item index whose
 // cost beats `gbc` (core.cpp:97 under single-thread order), so no separate detection pass is needed.
-template <int MODE, int PATH>
+template <int MODE, int PATH, bool ARB = false>
 __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first,
-                                  int last /*exclusive*/, double gbc, int* improver, int* tiny) {
+                                  int last /*exclusive*/, double gbc, int* improver, int* tiny, int* near_cnt,
+                                  unsigned short* near_list) {
   const int n_waves = blockDim.x >> 6;
   for (int j = first + wave_id(); j < last; j += n_waves) {
     const double c = sw.tc[j], s = sw.ts[j];
@@ -1230,6 +1347,13 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       // particle never passes `cost < best_cost`, so it never moves the gbest either.
       if (ordinary && improver && cost < gbc)
         if (cost < pbc_j) atomicMin(improver, j);
+      // exact mode: a comparison too close to call is noted for arbitration (pso_run_wg)
+      if constexpr (ARB) {
+        if (improver) {
+          const double tau = kArbRel * fabs(gbc);
+          if (near_tie(cost, pbc_j, tau) || near_tie(cost, gbc, tau)) near_note(near_cnt, near_list, j);
+        }
+      }
     }
   }
 }
@@ -1275,12 +1399,12 @@ constexpr unsigned long long kClusterWaitTicks = 20000000ull;  // 0.2 s of the 1
 
 // Evaluates items [first, last) of the swarm; on return (after the caller's barrier) sw.tcost holds their costs and
 // *improver / *tiny are set as eval_items sets them.  `epoch` counts the cluster's exchanges.
-template <int MODE, int PATH, bool CLUSTER>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false>
 __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first, int last,
                                   double gbc, int* improver, int* tiny, const ClusterP& cl, unsigned& epoch,
-                                  int* timed_out) {
+                                  int* timed_out, int* near_cnt, unsigned short* near_list) {
   if constexpr (!CLUSTER) {
-    eval_items<MODE, PATH>(E, pts, n, sw, S, first, last, gbc, improver, tiny);
+    eval_items<MODE, PATH, ARB>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
   } else {
     NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
@@ -1319,6 +1443,12 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
         *tiny = 1;
       else if (improver && cost < gbc && cost < sw.pbc[j])  // nested tests of core.cpp:94-104, see eval_items
         atomicMin(improver, j);
+      if constexpr (ARB) {  // exact mode, as in eval_items: every workgroup of the cluster notes the same items
+        if (improver) {
+          const double tau = kArbRel * fabs(gbc);
+          if (near_tie(cost, sw.pbc[j], tau) || near_tie(cost, gbc, tau)) near_note(near_cnt, near_list, j);
+        }
+      }
     }
     ++epoch;
     NDTPSO_PHASE_MARK(3);
@@ -1326,7 +1456,10 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
 }
 
 // returns false when the alignment was abandoned for the fp64-score kernel (fp32 underflow regime)
-template <int MODE, int PATH, bool CLUSTER = false>
+// ARB: the exact mode (NDTPSO_SCORE_EXACT) of the fp32-score dense kernels.  A template parameter, not a run-time
+// switch: the arbitration code in the same kernel cost the plain fp32 mode 11 % (register pressure: spills in the
+// proposal / commit paths), see DESIGN.md.
+template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false>
 __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
@@ -1338,10 +1471,27 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   const int P = ps.P, S = P + 1;
   const bool gen = (table == nullptr);
   int rng_t = 64;
-  uint32_t n_evals = 0, n_rounds = 0, n_gb = 0;
+  uint32_t n_evals = 0, n_rounds = 0, n_gb = 0, n_arb = 0;
+  static_assert(!ARB || (MODE == kScoreF32 && path_is_dense(PATH)), "the exact mode runs on the fp32-score dense kernels");
 
   // ---- swarm initialisation: core.cpp:58-69 ----
   if (tid == 0) sh->tiny = sh->timed_out = 0;
+  if constexpr (ARB) {
+    // exact mode: the rest of exact_tasks' parameter block (the kernel has stored the grid, the window and the table
+    // views of the fp64 image into sh->xa already)
+    if (tid == 0) {
+      ExactArgs& a = sh->xa;
+      a.pts = pts;
+      a.n = n;
+      a.tpos = sw.tpos;
+      a.pb = sw.pb;
+      a.tcost = sw.tcost;
+      a.pbc = sw.pbc;
+      a.gb = sh->gb;
+      a.xgbc = &sh->xgbc;
+      a.S = S;
+    }
+  }
   if (gen && wave_id() == 0) {
     rng_seed_wave0(&sh->rng, seed);
     rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 3 * S);
@@ -1374,7 +1524,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     }
   }
   __syncthreads();
-  eval_round<MODE, PATH, CLUSTER>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out);
+  eval_round<MODE, PATH, CLUSTER, ARB>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
+                                  nullptr);
   n_evals += S;
   n_rounds += 1;
   __syncthreads();
@@ -1385,6 +1536,33 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   if (MODE == kScoreF32 && sh->tiny) {  // underflow regime: give up, the fp64-score kernel redoes this alignment
     if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
     return false;
+  }
+  if constexpr (ARB) {
+    {
+      // exact mode, initial gbest (core.cpp:60-69: the first strict minimum in the order guess particle, 0 .. P-1):
+      // only an item within the margin of the smallest fp32 cost can be the fp64 minimum; if there are several, their
+      // fp64 scores decide (the selection loop below then runs on those)
+      if (tid == 0) {
+        double m = sw.tcost[P];
+        for (int i = 0; i < P; ++i) m = fmin(m, sw.tcost[i]);
+        sh->xgbc = m;
+        sh->near_cnt[0] = 0;
+      }
+      __syncthreads();
+      const double lim = sh->xgbc + kArbRel * fabs(sh->xgbc);
+      for (int i = tid; i < S; i += blockDim.x)
+        if (sw.tcost[i] <= lim) near_note(&sh->near_cnt[0], sh->near_list[0], i);
+      __syncthreads();
+      const int cnt = sh->near_cnt[0];
+      if (__builtin_expect(cnt > kMaxNear, 0)) {  // a swarm of near-identical costs: the fp64-score kernel takes the whole alignment
+        if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+        return false;
+      }
+      if (__builtin_expect(cnt > 1, 0)) {  // (cold: the register allocator must not charge the evaluation loops for it)
+        exact_tasks(&sh->xa, sh->near_list[0], cnt, 0);
+        n_arb += (uint32_t)cnt;
+      }
+    }
   }
   if (tid == 0) {
     double gbc = sw.tcost[P];
@@ -1411,7 +1589,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // ---- iterations: core.cpp:78-109 ----
   double w = ps.w;
   unsigned grp = 0;
-  if (tid == 0) sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
+  if (tid == 0) {
+    sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
+    sh->near_cnt[0] = sh->near_cnt[1] = sh->near_cnt[2] = 0;
+  }
   // rand() table from the host (the live node): the draws of an iteration are fetched from HBM one iteration ahead --
   // the loads are issued at the top of iteration it - 1, sit in two registers per thread while it runs, and land in the
   // LDS buffer the device generator would otherwise fill -- so the proposal step, where most waves wait for one or
@@ -1506,8 +1687,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #endif
       const int slot = (int)(grp % 3u);
       const int hi_g = min(lo + ps.G, P);
-      eval_round<MODE, PATH, CLUSTER>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
-                                      &sh->timed_out);
+      eval_round<MODE, PATH, CLUSTER, ARB>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
+                                      &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot]);
       n_evals += (uint32_t)(hi_g - lo);
       n_rounds += 1;
       __syncthreads();
@@ -1520,8 +1701,39 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
         return false;
       }
+      if constexpr (ARB) {
+        {
+          const int cnt = sh->near_cnt[slot];  // uniform: written before the barrier above
+          if (__builtin_expect(cnt != 0, 0)) {  // cold, see above
+            if (__builtin_expect(cnt > kMaxNear, 0)) {  // (a converged swarm: nearly every comparison is a near-tie)
+              if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+              return false;
+            }
+            // fp64 scores of the undecidable items' proposals and pbest positions and of the gbest position replace
+            // the stored costs; the group's first improver is then looked for again (core.cpp:94-104, nested tests)
+            exact_tasks(&sh->xa, sh->near_list[slot], cnt, 1);
+            if (tid == 0) {
+              sh->gbc = sh->xgbc;
+              int first = P;
+              for (int j = lo; j < hi_g; ++j) {
+                const double cj = sw.tcost[j];
+                if (cj < sh->gbc && cj < sw.pbc[j]) {
+                  first = j;
+                  break;
+                }
+              }
+              sh->jstar[slot] = first;
+            }
+            __syncthreads();
+            n_arb += (uint32_t)cnt;
+          }
+        }
+      }
       const int js = sh->jstar[slot];
-      if (tid == 0) sh->jstar[(grp + 2u) % 3u] = P;
+      if (tid == 0) {
+        sh->jstar[(grp + 2u) % 3u] = P;
+        sh->near_cnt[(grp + 2u) % 3u] = 0;
+      }
       ++grp;
       const int last = (js < P) ? js : (hi_g - 1);
       for (int j = lo + tid; j <= last; j += blockDim.x) {
@@ -1578,10 +1790,18 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     g_phase_ticks[0] = g_phase_ticks[1] = g_phase_ticks[2] = g_phase_ticks[3] = 0;
   }
 #endif
+  bool exact_cost = false;
+  if constexpr (ARB) {
+    {  // exact mode: the returned cost is the fp64 score of the returned pose (what the fp64 mode holds)
+      exact_tasks(&sh->xa, nullptr, 0, 2);
+      exact_cost = true;
+    }
+  }
   if (tid == 0 && writer) {
     for (int k = 0; k < 3; ++k) out_pose[k] = sh->gb[k];  // core.cpp:115
-    if (out_cost) *out_cost = sh->gbc;
+    if (out_cost) *out_cost = exact_cost ? sh->xgbc : sh->gbc;
     if (stats) {
+      stats->status |= (n_arb < 0xffffu ? n_arb : 0xffffu) << 16;  // exact mode: comparisons arbitrated in fp64
       stats->n_points = (uint32_t)n;
       stats->cost_evals = n_evals;
       stats->rounds = n_rounds;
