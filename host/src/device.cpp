@@ -184,9 +184,14 @@ void draw_rand(int32_t* out, size_t n) {
   for (size_t i = 0; i < n; ++i) out[i] = std::rand();
 }
 
+// Default: NDTPSO_SCORE_EXACT -- the fp64 score's poses (the reference's arithmetic, ndtcell.cpp:70-78) at close to the
+// fp32 score's speed.  NDTPSO_SCORE=f32 selects the plain fp32 score (a tolerance mode: a comparison of two costs closer
+// than its rounding error can fall the other way, measured on 1 of 4096 scan pairs), =f64 the fp64 score throughout.
 int score_mode() {
   const char* e = std::getenv("NDTPSO_SCORE");
-  return (e && std::strcmp(e, "f64") == 0) ? NDTPSO_SCORE_F64 : NDTPSO_SCORE_F32;
+  if (e && std::strcmp(e, "f64") == 0) return NDTPSO_SCORE_F64;
+  if (e && std::strcmp(e, "f32") == 0) return NDTPSO_SCORE_F32;
+  return NDTPSO_SCORE_EXACT;
 }
 
 bool check(int rc, const char* what) {

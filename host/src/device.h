@@ -13,7 +13,7 @@
 
 namespace ndtpso_host {
 ndtpso_ctx* device();                 // lazily created on HIP device $NDTPSO_DEVICE (default 0); nullptr if there is none
-int score_mode();                     // $NDTPSO_SCORE = f32 (default) | f64
+int score_mode();                     // $NDTPSO_SCORE = exact (default: fp64 results, fp32 speed) | f32 | f64
 bool check(int rc, const char* what); // true if rc == NDTPSO_OK; otherwise records + logs the C-ABI error text, returns false
 const void*& table_owner();           // which frame's cell table currently sits in the device context
 bool resident_default();              // $NDTPSO_RESIDENT != 0

@@ -159,12 +159,22 @@ __device__ __forceinline__ TableView image_table_view(const WinP& wn, const unsi
 }
 // exact mode (fp32-score dense kernels): the fp64 table the arbitration reads, where its image lies in HBM, goes into
 // the LDS parameter block of exact_tasks (thread 0 writes; the barriers of the swarm initialisation publish it)
-__device__ __forceinline__ void enable_arbitration(PsoShared* sh, const GridP& g, const WinP& wn,
+template <bool BYTE>
+__device__ __forceinline__ void enable_arbitration(PsoShared* sh, const GridP& g, const WinP& wn, const DenseP& dn,
                                                    const unsigned char* __restrict__ image) {
   if (threadIdx.x == 0) {
-    sh->xa.g = g;
-    sh->xa.xwn = wn;
-    sh->xa.XT = image_table_view(wn, image);
+    ExactArgs& a = sh->xa;
+    a.g = g;
+    a.dw = dn.dw;
+    a.dh = dn.dh;
+    a.ox = dn.ox;
+    a.oy = dn.oy;
+    a.null_entry = BYTE ? (unsigned)dn.rec_off : (unsigned)dn.rec_off >> 4;
+    a.rec0 = BYTE ? (unsigned)dn.rec_off + 32u : ((unsigned)dn.rec_off >> 4) + 2u;  // dense_put: record slot + 1
+    const TableView T = image_table_view(wn, image);
+    a.xmean = T.mean;
+    a.xab = T.ab;
+    a.xcd = T.cd;
   }
 }
 
@@ -424,7 +434,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   pad_points_wg(pts, n);
   __syncthreads();
   const EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
-  if constexpr (ARB) enable_arbitration(lds_ctrl(L.ctrl_off), g, wn, image);  // exact mode: the staged image is the fp64 table
+  if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, image);  // exact mode: the staged image holds the fp64 records
   // a swarm too large for LDS lives in an HBM workspace, one per workgroup of a cluster (each keeps the whole swarm)
   // Two copies of the PSO, one per home of the swarm, so that in each the compiler knows the address space of the
   // swarm arrays: selecting the base pointer at run time made every swarm access a FLAT instruction (74 of them), and
@@ -506,7 +516,6 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if constexpr (ARB) {
     {
       my_ximg = ximg + (CLUSTER ? (size_t)blockIdx.x : b) * ximg_stride;
-      xout.bm = reinterpret_cast<uint2*>(my_ximg + kImageHeaderBytes);
       xout.mean = reinterpret_cast<double2*>(my_ximg + image_mean_offset(wn.n_words));
       xout.ab = reinterpret_cast<double2*>(my_ximg + image_ab_offset(wn.n_words, wn.rec_cap));
       xout.cd = reinterpret_cast<double2*>(my_ximg + image_cd_offset(wn.n_words, wn.rec_cap));
@@ -530,7 +539,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
 #endif
 
   const EvalCtx E = make_eval_ctx(g, wn, L, dn);
-  if constexpr (ARB) enable_arbitration(lds_ctrl(L.ctrl_off), g, wn, my_ximg);
+  if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg);
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
   if (L.swarm_global) {  // (two copies: see k_align)
     const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P);

@@ -808,8 +808,6 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
   }
   __syncthreads();
   if (tid == 0 && (int)hdr->n_built > wn.rec_cap) atomicOr(&hdr->status, 2u);
-  if (xout)
-    for (int w = tid; w < wn.n_words; w += nt) xout->bm[w] = bm[w];
 
   NDTPSO_BT(4);
   // 5a. Per-cell point lists in beam order (= the reference's insertion order): every point files itself at its rank
@@ -1086,9 +1084,11 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
   double* ttx;    // [S] that evaluates it (dense form only)
   double* tty;    // [S]
   double* tcost;  // [S]
-  int32_t* raw;   // [max(3(P+1), 6P)] rand() outputs of the current phase
+  double* pcs;    // [2][S] plain cos, sin of the proposal's heading  } exact mode only: what the fp64 score of a
+  double* bcs;    // [2][S] the same for the pbest position            } position takes (exact_tasks), so that the
+  int32_t* raw;   // [max(3(P+1), 6P)] rand() outputs of the current phase   arbitration needs no sincos of its own
 };
-__host__ __device__ inline int swarm_doubles(int P) { return 21 * (P + 1); }
+__host__ __device__ inline int swarm_doubles(int P) { return 25 * (P + 1); }
 __host__ __device__ inline int swarm_raw_ints(int P) { return (6 * P > 3 * (P + 1)) ? 6 * P : 3 * (P + 1); }
 __host__ __device__ inline int swarm_bytes(int P) { return align16(swarm_doubles(P) * 8) + align16(swarm_raw_ints(P) * 4); }
 
@@ -1107,6 +1107,8 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P) {
   sw.tcost = d + 18 * S;
   sw.ttx = d + 19 * S;
   sw.tty = d + 20 * S;
+  sw.pcs = d + 21 * S;
+  sw.bcs = d + 23 * S;
   sw.raw = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P) * 8));
   return sw;
 }
@@ -1116,15 +1118,21 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P) {
 // spill lanes they needed took VGPRs from the score loop).
 struct ExactArgs {
   GridP g;
-  WinP xwn;
-  TableView XT;
-  const double2* pts;
+  int dw, dh, ox, oy;          // the dense cell table (DenseP): the cell lookup of the fp64 score goes through it too
+  unsigned null_entry, rec0;   // its null entry; entry of record slot 0 (entries step by 32 / 2 per slot: byte / 16-byte units)
+  const double2* xmean;        // fp64 records by slot, in the table image in HBM: NDTCell::mean,
+  const double2* xab;          //   s_inv_covar row 0,
+  const double2* xcd;          //   s_inv_covar row 1
+  unsigned pts_lds;    // LDS byte address of the (padded) point list
   int n;
   const double* tpos;  // [3][S]
   const double* pb;    // [3][S]
   double* tcost;       // [S]
   double* pbc;         // [S]
   const double* gb;    // [3]
+  const double* pcs;   // [2][S] cos, sin of the proposals' headings (as the proposal step took them)
+  const double* bcs;   // [2][S] of the pbest positions'
+  const double* gcs;   // [2]    of the gbest position's
   double* xgbc;
   int S;
 };
@@ -1141,6 +1149,7 @@ struct PsoShared {  // small control block in LDS
   int near_cnt[3];
   unsigned short near_list[3][kMaxNear];
   double xgbc;  // fp64 score of the gbest position (arbitration scratch)
+  double gcs[2];  // cos, sin of the gbest position's heading
   ExactArgs xa;
 };
 
@@ -1239,9 +1248,15 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
 // the returned pose is the fp64 mode's bit for bit; the returned cost is the fp64 score of that pose, also its.
 // What this rests on: the fp32 score's error staying below kArbRel / 2 -- measured, not proven; and the dense
 // form's binning (gx within 1e-14 cells of the reference's value, see score_trip_dense).
-constexpr double kArbRel = 2e-5;
+#ifndef NDTPSO_ARB_REL
+#define NDTPSO_ARB_REL 2e-5
+#endif
+constexpr double kArbRel = NDTPSO_ARB_REL;
 
 __device__ __forceinline__ void near_note(int* near_cnt, unsigned short* near_list, int j) {
+#ifdef NDTPSO_X_NODETECT
+  return;
+#endif
   const int k = atomicAdd(near_cnt, 1);
   if (k < kMaxNear) near_list[k] = (unsigned short)j;
 }
@@ -1255,54 +1270,105 @@ __device__ __forceinline__ bool near_tie(double a, double b, double tau) { retur
 // The scores replace tcost[j] / pbc[j].  Each is what the fp64-score kernels compute for that pose (sincos of the
 // heading as the proposal step takes it, eval_pose_wave<kScoreF64>, table read from its HBM image).
 // Called by every thread of the workgroup; ends with a barrier.
-// The fp64 score of one pose in a rolled loop -- one chunk of 64 points per trip -- that adds its terms into the
-// accumulators the four-chunk trips of eval_pose_wave_t<kScoreF64> would (chunk c of a full trip into acc[c % 4], the
-// chunks behind the last full trip into acc[0]) and folds them the same way: the same sum bit for bit, in a fraction
-// of the registers and of the code.
-__device__ inline double eval_pose_wave_f64_rolled(const GridP& g, const WinP& wn, const TableView& T,
-                                                    const double2* __restrict__ pts, int n, double c, double s, double tx,
-                                                    double ty) {
-  const int chunks = round_up(n, kWave) / kWave, in_trips = chunks & ~3;
+// The fp64 score of one pose as the arbitration computes it.  Per point exactly the operations of
+// score_trip<kScoreF64> (reference order: transform_point core.h:28-31 without FMA, strict frame bounds and
+// floor((x + w/2) / cs) of getCellIndex ndtframe.cpp:240-249 incl. the index wrap, the quadratic form and exp of
+// normalDistribution ndtcell.cpp:70-78), the same four lane accumulators over trips of four chunks, the chunks behind
+// the last full trip into the first, the same fold: the fp64 kernels' sum bit for bit.
+// The cell lookup goes through the dense u16 table in LDS (same cell coordinates, hence the same membership as the
+// bitmap of the fp64 kernels; one dependent HBM round trip less), the records come from the table image in HBM.
+template <bool BYTE, bool POW2>
+__device__ __forceinline__ double eval_pose_wave_exact(const ExactArgs* ap, double c, double s, double tx, double ty) {
+  const GridP g = ap->g;
+  const int dw = ap->dw, dh = ap->dh, ox = ap->ox, oy = ap->oy;
+  const unsigned null_entry = ap->null_entry, rec0 = ap->rec0;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+  typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
+  const unsigned pts_lds = ap->pts_lds;
+  const double2* __restrict__ xmean = ap->xmean;
+  const double2* __restrict__ xab = ap->xab;
+  const double2* __restrict__ xcd = ap->xcd;
+  const int chunks = round_up(ap->n, kWave) / kWave;
+  const int lane = lane_id();
+  auto term_of = [&](int k) -> double {
+    const v2d_t p = *(lds_d2_t)(uintptr_t)(pts_lds + (unsigned)(k * kWave + lane) * 16u);
+    const double qx = (p.x * c - p.y * s) + tx;  // reference rounding, no fma
+    const double qy = (p.x * s + p.y * c) + ty;
+    const bool inframe = (int)(fabs(qx) < g.hw) & (int)(fabs(qy) < g.hh);
+    int ix, iy;
+    cell_coords<POW2>(g, qx, qy, ix, iy);
+    const bool wrap = (ix == g.W);
+    ix = wrap ? 0 : ix;
+    iy = wrap ? iy + 1 : iy;
+    const unsigned rx = (unsigned)(ix - ox), ry = (unsigned)(iy - oy);
+    const bool inwin = (int)inframe & (int)(rx <= (unsigned)dw) & (int)(ry <= (unsigned)dh);
+    const unsigned lin = inwin ? ry * (unsigned)dense_stride(dw) + rx : 0u;  // entry 0: the empty low border, null
+    const unsigned e = *(lds_u16_t)(uintptr_t)(lin << 1);
+    const bool hit = e != null_entry;
+    const unsigned slot = hit ? (BYTE ? (e - rec0) >> 5 : (e - rec0) >> 1) : 0u;
+    // a miss adds exp(-inf) = +0. in the fp64 kernels, which leaves the accumulator as it was; slot 0 exists whenever
+    // any cell is built, and a table without built cells has no hits
+    const double2 m = xmean[slot], ab = xab[slot], cd = xcd[slot];
+    const double d0 = qx - m.x, d1 = qy - m.y;
+    const double r0 = d0 * ab.x + d1 * cd.x;  // (diff^T * inv_covar), ndtcell.cpp:73-75
+    const double r1 = d0 * ab.y + d1 * cd.y;
+    const double x = -(r0 * d0 + r1 * d1) / 2.;
+    return exp(hit ? x : -(double)__builtin_inff());
+  };
   double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+  int k = 0;
 #pragma unroll 1
-  for (int k = 0; k < chunks; ++k) {
-    double acc[4] = {0., 0., 0., 0.};
-    score_trip<kScoreF64, false, 1, false>(g, wn, T, pts, k * kWave, n, c, s, tx, ty, acc, nullptr);
-    const int u = k < in_trips ? (k & 3) : 0;
-    // (adding +0. to the other three accumulators leaves them as they are: no accumulator is ever -0.)
-    a0 += u == 0 ? acc[0] : 0.;
-    a1 += u == 1 ? acc[0] : 0.;
-    a2 += u == 2 ? acc[0] : 0.;
-    a3 += u == 3 ? acc[0] : 0.;
+  for (; k + 4 <= chunks; k += 4) {  // four independent gathers in flight
+    const double t0 = term_of(k), t1 = term_of(k + 1), t2 = term_of(k + 2), t3 = term_of(k + 3);
+    a0 += t0;
+    a1 += t1;
+    a2 += t2;
+    a3 += t3;
   }
+#pragma unroll 1
+  for (; k < chunks; ++k) a0 += term_of(k);
   return -wave_sum((a0 + a1) + (a2 + a3));
 }
 
+#ifndef NDTPSO_EXACT_CALL
+#define NDTPSO_EXACT_CALL 1
+#endif
+template <bool BYTE>
+#if NDTPSO_EXACT_CALL
+__device__ __attribute__((noinline, cold)) void exact_tasks(const ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
+#else
 __device__ __forceinline__ void exact_tasks(const ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
+#endif
+#ifdef NDTPSO_X_NOTASKS
+  __syncthreads();
+  return;
+#endif
   const int n_waves = blockDim.x >> 6;
   const int n_tasks = kind == 0 ? cnt : (kind == 1 ? 2 * cnt + 1 : 1);
 #pragma unroll 1
   for (int t = wave_id(); t < n_tasks; t += n_waves) {
-    double x, y, th;
+    double x, y, cn, sn;
     double* dst;
     if (kind == 2 || (kind == 1 && t == 2 * cnt)) {
       x = ap->gb[0];
       y = ap->gb[1];
-      th = ap->gb[2];
+      cn = ap->gcs[0];
+      sn = ap->gcs[1];
       dst = ap->xgbc;
     } else {
       const int j = list[kind == 0 ? t : (t >> 1)];
       const bool pbest = kind == 1 && (t & 1);
       const double* src = pbest ? ap->pb : ap->tpos;
+      const double* cs = pbest ? ap->bcs : ap->pcs;
       x = src[j];
       y = src[ap->S + j];
-      th = src[2 * ap->S + j];
+      cn = cs[j];
+      sn = cs[ap->S + j];
       dst = pbest ? &ap->pbc[j] : &ap->tcost[j];
     }
-    double sn, cn;
-    sincos(th, &sn, &cn);
-    // (the true division serves power-of-two cell sides too: x / cs == x * (1 / cs) exactly there)
-    const double c = eval_pose_wave_f64_rolled(ap->g, ap->xwn, ap->XT, ap->pts, ap->n, cn, sn, x, y);
+    const double c = ap->g.cs_pow2 ? eval_pose_wave_exact<BYTE, true>(ap, cn, sn, x, y)
+                                   : eval_pose_wave_exact<BYTE, false>(ap, cn, sn, x, y);
     if (lane_id() == 0) *dst = c;
   }
   __syncthreads();
@@ -1472,6 +1538,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   const bool gen = (table == nullptr);
   int rng_t = 64;
   uint32_t n_evals = 0, n_rounds = 0, n_gb = 0, n_arb = 0;
+#ifdef NDTPSO_PROFILE_ARB
+  uint32_t arb_ticks = 0;  // diagnostic builds: 100 MHz ticks spent arbitrating, reported in place of `rounds`
+#endif
   static_assert(!ARB || (MODE == kScoreF32 && path_is_dense(PATH)), "the exact mode runs on the fp32-score dense kernels");
 
   // ---- swarm initialisation: core.cpp:58-69 ----
@@ -1481,13 +1550,16 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     // views of the fp64 image into sh->xa already)
     if (tid == 0) {
       ExactArgs& a = sh->xa;
-      a.pts = pts;
+      a.pts_lds = (unsigned)(uintptr_t)(const double2 __attribute__((address_space(3)))*)pts;  // generic -> LDS address
       a.n = n;
       a.tpos = sw.tpos;
       a.pb = sw.pb;
       a.tcost = sw.tcost;
       a.pbc = sw.pbc;
       a.gb = sh->gb;
+      a.pcs = sw.pcs;
+      a.bcs = sw.bcs;
+      a.gcs = sh->gcs;
       a.xgbc = &sh->xgbc;
       a.S = S;
     }
@@ -1512,6 +1584,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       }
       double sn, cn;
       sincos(th, &sn, &cn);
+      if constexpr (ARB) {
+        sw.pcs[slot] = cn;
+        sw.pcs[S + slot] = sn;
+      }
       if constexpr (path_is_dense(PATH) && !CLUSTER) {  // DenseItem of this pose (dense_item), kept with it
         sw.tc[slot] = cn * E.g.inv_cs;
         sw.ts[slot] = sn * E.g.inv_cs;
@@ -1559,7 +1635,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         return false;
       }
       if (__builtin_expect(cnt > 1, 0)) {  // (cold: the register allocator must not charge the evaluation loops for it)
-        exact_tasks(&sh->xa, sh->near_list[0], cnt, 0);
+        exact_tasks<PATH == 3>(&sh->xa, sh->near_list[0], cnt, 0);
         n_arb += (uint32_t)cnt;
       }
     }
@@ -1574,6 +1650,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       }
     sh->gbc = gbc;
     for (int k = 0; k < 3; ++k) sh->gb[k] = sw.tpos[k * S + best];
+    if constexpr (ARB) {
+      sh->gcs[0] = sw.pcs[best];
+      sh->gcs[1] = sw.pcs[S + best];
+    }
   }
   for (int j = tid; j < P; j += blockDim.x) {
     for (int k = 0; k < 3; ++k) {
@@ -1583,6 +1663,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       sw.vel[k * S + j] = 0.;
     }
     sw.pbc[j] = sw.tcost[j];
+    if constexpr (ARB) {
+      sw.bcs[j] = sw.pcs[j];
+      sw.bcs[S + j] = sw.pcs[S + j];
+    }
   }
   __syncthreads();
 
@@ -1664,6 +1748,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             sincos(np, &sn, &cn);
             sw.tc[j] = fold ? cn * E.g.inv_cs : cn;
             sw.ts[j] = fold ? sn * E.g.inv_cs : sn;
+            if constexpr (ARB) {
+              sw.pcs[j] = cn;
+              sw.pcs[S + j] = sn;
+            }
           }
         }
         need_propose = false;
@@ -1705,13 +1793,16 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         {
           const int cnt = sh->near_cnt[slot];  // uniform: written before the barrier above
           if (__builtin_expect(cnt != 0, 0)) {  // cold, see above
+#ifdef NDTPSO_PROFILE_ARB
+            const unsigned long long arb_t0 = wall_clock64();
+#endif
             if (__builtin_expect(cnt > kMaxNear, 0)) {  // (a converged swarm: nearly every comparison is a near-tie)
               if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
               return false;
             }
             // fp64 scores of the undecidable items' proposals and pbest positions and of the gbest position replace
             // the stored costs; the group's first improver is then looked for again (core.cpp:94-104, nested tests)
-            exact_tasks(&sh->xa, sh->near_list[slot], cnt, 1);
+            exact_tasks<PATH == 3>(&sh->xa, sh->near_list[slot], cnt, 1);
             if (tid == 0) {
               sh->gbc = sh->xgbc;
               int first = P;
@@ -1726,6 +1817,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             }
             __syncthreads();
             n_arb += (uint32_t)cnt;
+#ifdef NDTPSO_PROFILE_ARB
+            n_rounds += 1000000u * 0u;
+            arb_ticks += (uint32_t)(wall_clock64() - arb_t0);
+#endif
           }
         }
       }
@@ -1752,6 +1847,12 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           if (better) sw.pb[k * S + j] = np;
         }
         if (better) sw.pbc[j] = cst;
+        if constexpr (ARB) {
+          if (better) {
+            sw.bcs[j] = sw.pcs[j];
+            sw.bcs[S + j] = sw.pcs[S + j];
+          }
+        }
       }
       if (js < P) {
         // gbest moves (core.cpp:97-104): every thread has read the old gbc above (eval_items), so one more
@@ -1760,6 +1861,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         if (tid == 0) {
           sh->gbc = sw.tcost[js];
           for (int k = 0; k < 3; ++k) sh->gb[k] = sw.tpos[k * S + js];
+          if constexpr (ARB) {
+            sh->gcs[0] = sw.pcs[js];
+            sh->gcs[1] = sw.pcs[S + js];
+          }
         }
         __syncthreads();
         n_gb += 1;
@@ -1791,12 +1896,14 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   }
 #endif
   bool exact_cost = false;
+#ifndef NDTPSO_NO_FINAL_EXACT
   if constexpr (ARB) {
     {  // exact mode: the returned cost is the fp64 score of the returned pose (what the fp64 mode holds)
-      exact_tasks(&sh->xa, nullptr, 0, 2);
+      exact_tasks<PATH == 3>(&sh->xa, nullptr, 0, 2);
       exact_cost = true;
     }
   }
+#endif
   if (tid == 0 && writer) {
     for (int k = 0; k < 3; ++k) out_pose[k] = sh->gb[k];  // core.cpp:115
     if (out_cost) *out_cost = exact_cost ? sh->xgbc : sh->gbc;
@@ -1805,6 +1912,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       stats->n_points = (uint32_t)n;
       stats->cost_evals = n_evals;
       stats->rounds = n_rounds;
+#ifdef NDTPSO_PROFILE_ARB
+      stats->rounds = arb_ticks;
+#endif
       stats->gbest_updates = n_gb;
 #ifdef NDTPSO_COUNT_AMBIG
       if (!CLUSTER) stats->gbest_updates = (uint32_t)sh->timed_out;

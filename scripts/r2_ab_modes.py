@@ -35,5 +35,13 @@ for r in range(R):
     for n in names:
         res[n].append(run(MODES[n], 30))
 for n in names:
+    run(MODES[n], 30)
+    st = d_stats.cpu().numpy().view(capi.STATS_DTYPE).reshape(B)
+    dur = (st["t_end"] - st["t_start"]).astype(np.uint32) / 100.0
+    start = (st["t_start"] - st["t_start"].min()).astype(np.uint32) / 100.0
+    end = (st["t_end"] - st["t_start"].min()).astype(np.uint32) / 100.0
+    print("%-6s steady state, last launch: wg duration us p50 %.0f p99 %.0f max %.0f; start spread %.0f; last finish %.0f; arbitrated mean %.2f max %d"
+          % (n, np.percentile(dur, 50), np.percentile(dur, 99), dur.max(), start.max(), end.max(), st["arbitrated"].mean(), st["arbitrated"].max()))
+for n in names:
     v = np.array(res[n])
     print("%-6s ms/launch: median %.4f  min %.4f  max %.4f   -> %.0f align/s" % (n, np.median(v), v.min(), v.max(), B / np.median(v) * 1e3))

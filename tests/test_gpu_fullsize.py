@@ -40,7 +40,9 @@ def _check_modes(tag, pose32, cost32, pose64, cost64, posex, costx, stx, want, w
     assert d64.max() < 1e-9 and np.abs(cost64 - want_cost).max() < 1e-9
     assert np.array_equal(posex, pose64) and np.array_equal(costx, cost64)
     assert (stx["status"] == 0).all()
-    assert same32 >= 0.995 * n and d32.max() < F32_POSE_TOL and np.abs(cost32 - want_cost).max() < 0.5
+    assert same32 >= 0.995 * n and d32.max() < F32_POSE_TOL
+    ok32 = d32.max(axis=1) <= 1e-6   # (a flipped pair ends in another optimum: its cost is that optimum's)
+    assert np.abs(cost32 - want_cost)[ok32].max() < 1e-4 * 1081
 
 
 def _oracle_all(oracle, p):

@@ -149,6 +149,12 @@ def test_node_replay_matches_oracle(tmp_path, oracle, resident, monkeypatch):
     d32 = np.abs(got32 - want)
     print("node replay (fp32 score) max |dpose|", d32.max(axis=0))
     assert d32[:, :2].max() < 1e-3 and d32[:, 2].max() < 1e-3
+    # the library's default score mode (exact: fp32 score, undecidable comparisons arbitrated in fp64) prints what the
+    # fp64 score mode prints, digit for digit
+    env_default = {k: v for k, v in os.environ.items() if k != "NDTPSO_SCORE"}
+    out_x = subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs),
+                                     str(I), str(P), str(seed)], text=True, env=env_default)
+    assert out_x == out
     # like the reference (ndtframe.cpp:257) align() runs 30 x 50 whatever PSO configuration the frame was given
     out_cfg = subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs),
                                        "7", "11", str(seed)], text=True, env=dict(os.environ, NDTPSO_SCORE="f64"))
@@ -424,7 +430,7 @@ def run_host_operation_sequence(oracle, workdir, seed, frame_w, frame_h, cs, ogc
 
     n_aligns = n_exact32 = 0
     for resident in ("1", "0"):
-        for score in ("f64", "f32"):
+        for score in ("f64", "f32", "exact"):
             out = subprocess.check_output([os.path.join(HOST, "replay", "frame_fuzz"), path], text=True,
                                           env=dict(os.environ, NDTPSO_RESIDENT=resident, NDTPSO_SCORE=score))
             lines = [l.split() for l in out.splitlines()]
@@ -448,11 +454,11 @@ def run_host_operation_sequence(oracle, workdir, seed, frame_w, frame_h, cs, ogc
                     assert (float.fromhex(got[2]), float.fromhex(got[3])) == (want[2], want[3]), tag
                 elif want[0] == "cost":
                     g, w = float.fromhex(got[1]), want[1]
-                    tol = 1e-9 * max(1.0, abs(w)) if score == "f64" else max(1e-4 * max(1, want[2]), 1e-6 * abs(w))
+                    tol = 1e-9 * max(1.0, abs(w)) if score != "f32" else max(1e-4 * max(1, want[2]), 1e-6 * abs(w))
                     assert (np.isnan(g) and np.isnan(w)) or g == w or abs(g - w) <= tol, tag + (g, w)
                 elif want[0] in ("pso", "align"):
                     g = np.array([float.fromhex(v) for v in got[1:4]])
-                    assert np.abs(g - want[1]).max() < (1e-9 if score == "f64" else 1e-3), tag + (g, want[1])
+                    assert np.abs(g - want[1]).max() < (1e-9 if score != "f32" else 1e-3), tag + (g, want[1])
                     if score == "f32":
                         n_aligns += 1
                         n_exact32 += int(np.array_equal(g, want[1]))
