@@ -8,7 +8,20 @@ the fused kernel over the rank's 512 pairs, scans already resident in HBM.  N > 
 pairs sharded by contiguous index range (weak scaling, 512 pairs/GPU), one RCCL all_gather of the poses
 per step.
 
-Prints ONE JSON line on rank 0 (contract in the task statement), with `roofline` and `cpu_baseline`.
+Score mode: `exact` by default -- fp32 Gaussian, every pbest / gbest comparison it cannot decide arbitrated in
+fp64: the poses (and costs) of the all-fp64 mode, which are the oracle's, bit for bit (tests/test_gpu_fullsize.py
+checks all 512 pairs of this very workload).  `--score f32` is the plain fp32 score (BASELINE config 2's "fp32":
+a tolerance mode, 1 of 4096 pairs leaves the reference's trajectory), `--score f64` the fp64 score throughout;
+both are timed as `extra.modes` of the default run.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      bound "valu": the kernel keeps table, points and swarm in LDS, HBM sees 8.7 KB per alignment; what
+                bounds it is vector-ALU issue.  peak = the issue-time floor of the score loop's instruction mix
+                (profiles/r02_isa_mix.json: llvm-objdump of the shipped kernel x the per-instruction issue times of
+                scripts/ubench_valu.hip measured on this chip), achieved = algorithmic point evaluations / kernel time
+                measured here with events; the 40-byte-per-point-eval "effective bandwidth" of SURVEY 8(d) is kept
+                under roofline.hbm_effective.
+  cpu_baseline  the oracle (a port of the reference's algorithm) on this box's host cores, SURVEY 8(d)'s four numbers.
 """
 from __future__ import annotations
 
@@ -24,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_SIMD = 256 * 4               # 256 CUs x 4 SIMDs
 BYTES_PER_POINT_EVAL = 40.0    # 16 B fp64 point + 24 B compact cell record
 FRAME_M, CELL_SIDE = 60, 0.5
 DEVIATION = (0.1, 0.1, 3.1415e-3)
@@ -32,14 +46,14 @@ DEVIATION = (0.1, 0.1, 3.1415e-3)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)   # (a step is 2.6 ms: the first few run before the clocks settle)
+    ap.add_argument("--steps", type=int, default=200)   # 200 x 2.7 ms: a timed region of more than half a second
+    ap.add_argument("--warmup", type=int, default=20)   # (the first steps run before the clocks settle)
     ap.add_argument("--pairs", type=int, default=512, help="scan pairs per GPU per step")
     ap.add_argument("--particles", type=int, default=70)
     ap.add_argument("--iterations", type=int, default=70)
-    ap.add_argument("--score", choices=["f32", "f64", "exact"], default="f32")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="pairs timed on the host oracle (0 = skip)")
-    ap.add_argument("--no-latency", action="store_true", help="skip the single-pair latency measurement")
+    ap.add_argument("--score", choices=["exact", "f32", "f64"], default="exact")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="pairs of this step timed on the host oracle (0 = skip the CPU baseline)")
+    ap.add_argument("--no-latency", action="store_true", help="skip the extras (other score modes, config 5, latency, live sequence)")
     ap.add_argument("--identical", action="store_true", help="diagnostic: replicate pair 0 (no load imbalance)")
     args = ap.parse_args()
 
@@ -152,7 +166,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64 transform/index + f32 score" if mode == capi.SCORE_F32 else "f64",
+            "dtype": {"exact": "f64 transform/index + f32 score, undecidable comparisons arbitrated in f64 (= the f64 mode's poses)",
+                      "f32": "f64 transform/index + f32 score", "f64": "f64"}[args.score],
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE config 3: %d scan pairs per GPU per step, %d beams, %.2f m cells, %d m frame, "
@@ -162,18 +177,7 @@ def main():
                 "parallelism": "pairs sharded by contiguous index range, 1 RCCL all_gather of poses per step"
                                if world > 1 else "single GPU",
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic_bytes(),
-                "kernel": "k_align_pairs", "kernel_ms": kern_ms,
-                "algorithmic_bytes_per_launch": algo_bytes,
-                "valu": _valu_roof(stats, kern_ms),
-                "note": "achieved = streaming-equivalent bytes (40 B per point-eval x (1+P+P*I) x N_valid, summed "
-                        "over the launch's pairs) / kernel time; the kernel keeps table+points+swarm in LDS, so this "
-                        "is an effective bandwidth that can exceed the HBM peak; traffic = HBM bytes per launch from "
-                        "profiles/r01_pmc_summary.json (compulsory ~8.7 KB/alignment).  The kernel is VALU-bound: "
-                        "`valu` is the roof that bounds it (DESIGN.md section 5)",
-            },
+            "roofline": _roofline(stats, evals_nominal, kern_ms, algo_bytes, achieved),
             "extra": {
                 "mean_cost_evals_per_alignment": float(stats["cost_evals"].mean()),
                 "mean_replay_overhead": float(stats["cost_evals"].mean()) / evals_nominal - 1.0,
@@ -183,6 +187,8 @@ def main():
                 "rounds_min_max": [int(stats["rounds"].min()), int(stats["rounds"].max())],
                 "n_built_min_max": [int(stats["n_built"].min()), int(stats["n_built"].max())],
                 "n_points_min_max": [int(stats["n_points"].min()), int(stats["n_points"].max())],
+                "comparisons_arbitrated_in_f64_per_alignment": float(stats["arbitrated"].mean()),
+                "timed_region_s": elapsed,
             },
         }
 
@@ -200,6 +206,40 @@ def main():
             torch.cuda.synchronize()
             lat.append(a.elapsed_time(b))
         out["extra"]["single_pair_latency_ms"] = float(np.median(lat))
+        out["extra"]["single_pair_latency_note"] = "one pair of this workload, %s score, spread over a cluster of workgroups" % args.score
+
+    # the other score modes on the same workload and BASELINE config 5, timed here so that they are driver-visible
+    if rank == 0 and not args.no_latency:
+        def timed(n_pairs, m, steps, geom_, grid_, cfg_, ref_, new_, seeds_):
+            for _ in range(2):
+                ctx.align_pairs_dev(n_pairs, ref_.data_ptr(), new_.data_ptr(), geom_, grid_, d_guess.data_ptr(), d_dev.data_ptr(),
+                                    cfg_, seeds_.data_ptr(), 0, m, d_pose.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                ctx.align_pairs_dev(n_pairs, ref_.data_ptr(), new_.data_ptr(), geom_, grid_, d_guess.data_ptr(), d_dev.data_ptr(),
+                                    cfg_, seeds_.data_ptr(), 0, m, d_pose.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr())
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            return {"alignments_per_s": n_pairs * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "pairs": n_pairs}
+        modes = {}
+        for name, m, steps in (("f32", capi.SCORE_F32, 150), ("f64", capi.SCORE_F64, 60), ("exact", capi.SCORE_EXACT, 150)):
+            if m != mode:
+                modes[name] = timed(B, m, steps, geom, grid, cfg, d_ref, d_new, d_seeds)
+        out["extra"]["modes"] = modes
+        try:
+            B5 = min(256, B)
+            p5 = synth.make_pairs(B5, n_beams=2048, seed=21)
+            g5 = capi.ScanGeom(p5.n_beams, float(p5.angle_min), float(p5.angle_inc), float(p5.range_max), 0.1)
+            r5, n5 = torch.from_numpy(p5.ref_ranges).to(dev), torch.from_numpy(p5.new_ranges).to(dev)
+            s5 = torch.from_numpy(p5.seeds.astype(np.int64)).to(dev).to(torch.int32)
+            c5 = {}
+            for name, m in (("exact", capi.SCORE_EXACT), ("f32", capi.SCORE_F32)):
+                c5[name] = timed(B5, m, 2, g5, capi.Grid(FRAME_M, FRAME_M, 0.25), capi.PSOConfig.make(200, 2048), r5, n5, s5)
+            c5["workload"] = "BASELINE config 5: %d pairs per launch, 2048 particles x 200 iterations, 2048 beams, 0.25 m cells" % B5
+            out["extra"]["config5"] = c5
+        except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench run fails
+            out["extra"]["config5"] = {"error": str(e)}
 
     # the node's live sequence: loadLaser -> align -> update against an accumulating resident map,
     # default 30 x 50 PSO, rand() table from the host as the drop-in library passes it; rank 0 only, 60 scans
@@ -209,23 +249,12 @@ def main():
         except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench run fails
             out["extra"]["live_sequence"] = {"error": str(e)}
 
-    # CPU baseline: the oracle (a port of the reference's algorithm) on a bounded sample, host cores of this box
+    # CPU baseline: the oracle -- a port of the reference's algorithm -- on this box's host cores
     if rank == 0 and world == 1 and args.cpu_sample > 0:
-        from oracle import pyoracle
-        S = min(args.cpu_sample, B)
-        ocfg = pyoracle.PSOConfig.make(I, P)
-        t1 = time.perf_counter()
-        opose, _, used = pyoracle.align_pairs(pairs.ref_ranges[:S], pairs.new_ranges[:S], pairs.angle_min,
-                                              pairs.angle_inc, pairs.range_max, 0.1, FRAME_M, FRAME_M, CELL_SIDE,
-                                              (0, 0, 0), DEVIATION, ocfg, pairs.seeds[:S], n_threads=0)
-        dt = time.perf_counter() - t1
-        out["cpu_baseline"] = {
-            "value": S / dt, "unit": "alignments/s", "cores": int(used), "kind": "port",
-            "sample": "first %d of the %d pairs of this step, oracle/ndtpso_oracle.c (sequential reference "
-                      "algorithm per pair, OpenMP across pairs, %d threads, %s)" % (S, B, used, _cpu_model()),
-            "seconds": dt,
-        }
-        out["extra"]["parity_sample_max_abs_dpose"] = np.abs(pose[:S] - opose).max(axis=0).tolist()
+        out["cpu_baseline"] = _cpu_baseline(pairs, min(args.cpu_sample, B), P, I)
+        opose = out["cpu_baseline"].pop("_poses")
+        out["extra"]["parity_max_abs_dpose_vs_oracle"] = np.abs(pose[:len(opose)] - opose).max(axis=0).tolist()
+        out["extra"]["parity_pairs_compared"] = int(len(opose))
     elif rank == 0:
         out["cpu_baseline"] = None
 
@@ -281,36 +310,98 @@ def _live_sequence(ctx, capi, synth, mode, n_scans=60):
             "map_cells_built": int(info["n_built"]), "through": "ctypes binding (host/replay/node_replay.cpp is the C++ equivalent)"}
 
 
-def _valu_roof(stats, kern_ms):
-    """The roof that actually bounds the kernel ("quote the ALU roof"): vector-ALU issue.  Work = the
-    64-point chunks this launch scored (cost evaluations x ceil(points / 64), from the kernel's own counters) x the
-    VALU instructions one chunk takes; peak = 1024 SIMDs issuing one such instruction every `cycles_per_instr`
-    cycles.  Instructions per chunk and cycles per instruction are the measured PMC figures of this kernel
-    (profiles/r01_pmc_summary.json: SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU); the duration is this run's."""
+def _load_json(name):
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            d = json.load(f)["derived"]
-        ipc, cpi = float(d["valu_instr_per_64_point_evals"]), float(d["valu_cycles_per_instr"])
-    except (OSError, KeyError, ValueError):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
         return None
-    clock_hz, simds = 2.4e9, 256 * 4
-    chunks = float((stats["cost_evals"].astype(np.float64) * np.ceil(stats["n_points"] / 64.0)).sum())
-    achieved = chunks * ipc / (kern_ms * 1e-3)
-    peak = simds * clock_hz / cpi
-    return {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "wave-instructions/s", "frac": achieved / peak,
-            "valu_instr_per_64_point_evals": ipc, "valu_cycles_per_instr": cpi, "clock_hz": clock_hz}
+
+
+def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs):
+    """bound = "valu".  Work of a launch: the reference's 1 + P + P*I cost evaluations per alignment x the points each
+    scores (algorithmic point evaluations, replays of the exact-order scheme not counted).  achieved = that / the
+    kernel time measured here.  peak = the same work at the issue-time floor of the score loop: every 64 points cost
+    profiles/r02_isa_mix.json's `valu_issue_ns_per_chunk` of one SIMD's time (instruction mix from llvm-objdump of the
+    shipped kernel, issue time per instruction from scripts/ubench_valu.hip on this chip), 1024 SIMDs working.  What is
+    outside the loop -- pose constants, wave reductions, the PSO's proposals and commits, barriers -- is not in the
+    floor, so frac < 1 by construction and 1 - frac is what those and the stalls cost together."""
+    mix = _load_json("r02_isa_mix.json")
+    point_evals = float(stats["n_points"].astype(np.float64).sum()) * evals_nominal
+    achieved = point_evals / (kern_ms * 1e-3)
+    r = {"bound": "valu", "achieved": achieved, "peak": None, "unit": "point-evals/s", "frac": None,
+         "traffic": _pmc_traffic_bytes(), "kernel": "k_align_pairs (fused scan ingest + cell statistics + PSO)",
+         "kernel_ms": kern_ms, "algorithmic_point_evals_per_launch": point_evals}
+    if mix:
+        ns_chunk = float(mix["valu_issue_ns_per_chunk"])
+        r["peak"] = N_SIMD * 64.0 / (ns_chunk * 1e-9)
+        r["frac"] = achieved / r["peak"]
+        r["floor"] = {"valu_instructions_per_64_points": mix["valu_per_chunk"], "valu_issue_ns_per_64_points": ns_chunk,
+                      "floor_ms_per_launch": point_evals / r["peak"] * 1e3, "source": "profiles/r02_isa_mix.json (scripts/isa_mix.py), "
+                      "profiles/r02_score_loop_isa.txt, profiles/r02_ubench_valu.txt"}
+    r["hbm_effective"] = {"achieved": hbm_equiv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_equiv_gbs / HBM_PEAK_GBS,
+                          "algorithmic_bytes_per_launch": algo_bytes,
+                          "note": "SURVEY 8(d)'s streaming-equivalent accounting: 40 B per point evaluation (16 B point + 24 B cell "
+                                  "record); the kernel serves them from LDS, so this exceeds the HBM peak by construction -- HBM is "
+                                  "not the roof (traffic = measured HBM bytes per launch, 1.3 x the compulsory 8.7 KB per alignment)"}
+    return r
 
 
 def _pmc_traffic_bytes():
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 per the
     gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE; separate --pmc runs, scripts/pmc.sh).  A profile of
     THIS workload measured on MI355X, not collected live (rocprofv3 cannot wrap the timed run); null if absent."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-            d = json.load(f)["derived"]
-        return float(d["hbm_read_bytes_per_launch_FETCH_SIZE_x2_KiB_units"]) + float(d["hbm_write_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        d = _load_json(name)
+        try:
+            d = d["derived"]
+            return float(d["hbm_read_bytes_per_launch_FETCH_SIZE_x2_KiB_units"]) + float(d["hbm_write_bytes_per_launch"])
+        except (TypeError, KeyError, ValueError):
+            continue
+    return None
+
+
+def _cpu_baseline(pairs, S, P, I):
+    """the repo's fp64 CPU restatement of the reference (oracle/ndtpso_oracle.c, `kind: "port"` -- the
+    reference itself cannot be built in this image) on the GPU box's host cores:
+      c1  one scan pair (BASELINE config 1) in the reference's own parallel shape -- OpenMP over the particles of an
+          iteration, live rand(), racy gbest (core.cpp:72-109) -- median of 21 alignments, at 1 thread and at all;
+      c3  all S pairs of this step, sequential alignments parallelised over pairs on all threads (the fairest CPU
+          figure: no synchronisation at all), best of two passes; this is `value`."""
+    from oracle import pyoracle
+    ocfg = pyoracle.PSOConfig.make(I, P)
+    nproc = os.cpu_count() or 1
+    ref = pyoracle.Frame((0, 0, 0), FRAME_M, FRAME_M, CELL_SIDE)
+    ref.load_laser(pairs.ref_ranges[0], pairs.angle_min, pairs.angle_inc, pairs.range_max)
+    new = pyoracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
+    new.load_laser(pairs.new_ranges[0], pairs.angle_min, pairs.angle_inc, pairs.range_max)
+    ref.build()
+    c1 = {}
+    for label, nt in (("1_thread", 1), ("all_threads", 0)):
+        ts = []
+        for _ in range(21):
+            t1 = time.perf_counter()
+            ref.pso_omp((0, 0, 0), new, DEVIATION, ocfg, n_threads=nt)
+            ts.append(time.perf_counter() - t1)
+        c1[label] = {"alignments_per_s": 1.0 / float(np.median(ts)), "median_ms": 1e3 * float(np.median(ts)),
+                     "threads": 1 if nt == 1 else nproc, "runs": len(ts)}
+    best, used, opose = None, 1, None
+    for _ in range(2):
+        t1 = time.perf_counter()
+        opose, _, used = pyoracle.align_pairs(pairs.ref_ranges[:S], pairs.new_ranges[:S], pairs.angle_min, pairs.angle_inc,
+                                              pairs.range_max, 0.1, FRAME_M, FRAME_M, CELL_SIDE, (0, 0, 0), DEVIATION, ocfg,
+                                              pairs.seeds[:S], n_threads=0)
+        dt = time.perf_counter() - t1
+        best = dt if best is None else min(best, dt)
+    return {
+        "value": S / best, "unit": "alignments/s", "cores": int(used), "kind": "port",
+        "sample": "all %d scan pairs of this step (BASELINE config 3), sequential alignments of oracle/ndtpso_oracle.c parallelised "
+                  "over pairs, %d OpenMP threads, best of 2 passes; %s, %d logical CPUs" % (S, used, _cpu_model(), nproc),
+        "seconds": best,
+        "c1_single_pair_omp_over_particles": c1,
+        "c3_pairs": S, "nproc": nproc, "cpu_model": _cpu_model(),
+        "_poses": opose,
+    }
 
 
 def _cpu_model() -> str:

@@ -1318,6 +1318,7 @@ __device__ __forceinline__ double eval_pose_wave_exact(const ExactArgs* ap, doub
   };
   double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
   int k = 0;
+#ifndef NDTPSO_EXACT_ROLLED
 #pragma unroll 1
   for (; k + 4 <= chunks; k += 4) {  // four independent gathers in flight
     const double t0 = term_of(k), t1 = term_of(k + 1), t2 = term_of(k + 2), t3 = term_of(k + 3);
@@ -1328,6 +1329,18 @@ __device__ __forceinline__ double eval_pose_wave_exact(const ExactArgs* ap, doub
   }
 #pragma unroll 1
   for (; k < chunks; ++k) a0 += term_of(k);
+#else  // one chunk per trip: fewer registers for the callee to save, more latency per chunk
+  const int in_trips = chunks & ~3;
+#pragma unroll 1
+  for (; k < chunks; ++k) {
+    const double t = term_of(k);
+    const int u = k < in_trips ? (k & 3) : 0;
+    a0 += u == 0 ? t : 0.;  // (adding +0. leaves an accumulator as it is: none is ever -0.)
+    a1 += u == 1 ? t : 0.;
+    a2 += u == 2 ? t : 0.;
+    a3 += u == 3 ? t : 0.;
+  }
+#endif
   return -wave_sum((a0 + a1) + (a2 + a3));
 }
 
@@ -1341,7 +1354,6 @@ __device__ __attribute__((noinline, cold)) void exact_tasks(const ExactArgs* ap,
 __device__ __forceinline__ void exact_tasks(const ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
 #endif
 #ifdef NDTPSO_X_NOTASKS
-  __syncthreads();
   return;
 #endif
   const int n_waves = blockDim.x >> 6;
@@ -1371,6 +1383,14 @@ __device__ __forceinline__ void exact_tasks(const ExactArgs* ap, const unsigned 
                                    : eval_pose_wave_exact<BYTE, false>(ap, cn, sn, x, y);
     if (lane_id() == 0) *dst = c;
   }
+}
+// Only the waves that have a task make the call (an out-of-line call saves and restores the callee-saved registers it
+// uses in scratch memory: 100 MB of HBM traffic per launch when all eight waves went through it for three tasks);
+// every thread of the workgroup calls this wrapper, which ends with a barrier.
+template <bool BYTE>
+__device__ __forceinline__ void exact_tasks_wg(const ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
+  const int n_tasks = kind == 0 ? cnt : (kind == 1 ? 2 * cnt + 1 : 1);
+  if (wave_id() < n_tasks) exact_tasks<BYTE>(ap, list, cnt, kind);
   __syncthreads();
 }
 
@@ -1635,7 +1655,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         return false;
       }
       if (__builtin_expect(cnt > 1, 0)) {  // (cold: the register allocator must not charge the evaluation loops for it)
-        exact_tasks<PATH == 3>(&sh->xa, sh->near_list[0], cnt, 0);
+        exact_tasks_wg<PATH == 3>(&sh->xa, sh->near_list[0], cnt, 0);
         n_arb += (uint32_t)cnt;
       }
     }
@@ -1802,7 +1822,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             }
             // fp64 scores of the undecidable items' proposals and pbest positions and of the gbest position replace
             // the stored costs; the group's first improver is then looked for again (core.cpp:94-104, nested tests)
-            exact_tasks<PATH == 3>(&sh->xa, sh->near_list[slot], cnt, 1);
+            exact_tasks_wg<PATH == 3>(&sh->xa, sh->near_list[slot], cnt, 1);
             if (tid == 0) {
               sh->gbc = sh->xgbc;
               int first = P;
@@ -1899,7 +1919,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #ifndef NDTPSO_NO_FINAL_EXACT
   if constexpr (ARB) {
     {  // exact mode: the returned cost is the fp64 score of the returned pose (what the fp64 mode holds)
-      exact_tasks<PATH == 3>(&sh->xa, nullptr, 0, 2);
+      exact_tasks_wg<PATH == 3>(&sh->xa, nullptr, 0, 2);
       exact_cost = true;
     }
   }

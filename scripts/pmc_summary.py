@@ -7,9 +7,11 @@ import csv, json, sys, collections, math
 src, dst = sys.argv[1], sys.argv[2]
 pairs, P, I, beams = (int(v) for v in (sys.argv[3:7] if len(sys.argv) >= 7 else (512, 70, 70, 1081)))
 import os
-KERNEL = "k_align_pairs<0, 3, false>"   # dense form with byte-address entries (what config 3 runs); else the general dense form
-if not any(KERNEL in r["Kernel_Name"] for r in csv.DictReader(open(f"{src}/p1/p_counter_collection.csv"))):
-    KERNEL = "k_align_pairs<0, 2, false>"
+# dense form with byte-address entries (what config 3 runs): the arbitrating kernel of the exact mode, the plain fp32-score
+# kernel, or the general dense form -- whichever the profiled run launched
+names = {r["Kernel_Name"] for r in csv.DictReader(open(f"{src}/p1/p_counter_collection.csv"))}
+KERNEL = next((k for k in ("k_align_pairs<0, 3, false, true>", "k_align_pairs<0, 3, false, false>", "k_align_pairs<0, 3, false>",
+                           "k_align_pairs<0, 2, false") if any(k in n for n in names)), "k_align_pairs")
 vals = collections.defaultdict(list)
 disp = {}
 for p in ("p1", "p2", "p3", "p4", "p5"):
@@ -21,12 +23,14 @@ for p in ("p1", "p2", "p3", "p4", "p5"):
 mean = {k: sum(v) / len(v) for k, v in vals.items()}
 stats = [r for r in csv.DictReader(open(f"{src}/trace/t_kernel_stats.csv")) if KERNEL in r["Name"]]
 kern_ns = float(stats[0]["AverageNs"]) if stats else float("nan")
+kern_calls = int(float(stats[0]["Calls"])) if stats else 0
 evals = 1 + P + P * I
 # cost evaluations include the replays of the exact-order scheme (measured mean of the bench workload: +2.3 %)
 chunks = pairs * evals * 1.0228 * math.ceil(beams / 64)
 cyc_xcd = mean["GRBM_GUI_ACTIVE"] / 8
 derived = {
     "kernel_avg_ns_from_kernel_trace": kern_ns,
+    "kernel_trace_calls": kern_calls,
     "kernel_cycles_per_xcd": cyc_xcd,
     "valu_instr_per_64_point_evals": mean["SQ_INSTS_VALU"] / chunks,
     "valu_cycles_per_instr": mean["SQ_ACTIVE_INST_VALU"] * 4 / mean["SQ_INSTS_VALU"],

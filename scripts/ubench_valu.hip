@@ -72,6 +72,13 @@ KERNEL_F32(k_add3, "v_add3_u32 %0, %0, %1, %2")
 KERNEL_F32(k_lshladd, "v_lshl_add_u32 %0, %0, 4, %1")
 KERNEL_F32(k_cvt_i32_f32, "v_cvt_i32_f32 %0, %0")
 KERNEL_F32(k_cvt_f32_i32, "v_cvt_f32_i32 %0, %0")
+// the remaining mnemonics of the score loop (scripts/isa_mix.py prices the loop with this table)
+KERNEL_F32(k_fmac32, "v_fmac_f32 %0, %1, %2")
+KERNEL_F32(k_minu32, "v_min_u32 %0, %0, %1")
+KERNEL_F32(k_mulu24, "v_mul_u32_u24 %0, %0, %1")
+KERNEL_F32(k_addlshl, "v_add_lshl_u32 %0, %0, %1, 1")
+KERNEL_F64(k_pkadd32, "v_pk_add_f32 %0, %0, %0")
+KERNEL_F64(k_fmac64, "v_fmac_f64 %0, %1, %2")
 KERNEL_CVT(k_cvt_f32_f64, "v_cvt_f32_f64 %0, %1", "v_cvt_f64_f32 %0, %1")
 KERNEL_CVT(k_cvt_i32_f64, "v_cvt_i32_f64 %0, %1", "v_cvt_f64_i32 %0, %1")
 
@@ -107,6 +114,7 @@ int main() {
   R32(k_mul32, 8) R32(k_add32, 8) R32(k_min32, 8) R32(k_exp32, 8) R32(k_addu, 8) R32(k_subrev, 8) R32(k_and, 8)
   R32(k_lshr, 8) R32(k_bfe, 8) R32(k_bcnt, 8) R32(k_mad24, 8) R32(k_cndm, 8) R32(k_cmp32, 8) R32(k_cmpu, 8)
   R32(k_cmpu_s, 8) R32(k_mov, 8) R32(k_add3, 8) R32(k_lshladd, 8) R32(k_cvt_i32_f32, 8) R32(k_cvt_f32_i32, 8)
+  R32(k_fmac32, 8) R32(k_minu32, 8) R32(k_mulu24, 8) R32(k_addlshl, 8) R64(k_pkadd32, 8) R64(k_fmac64, 8)
   printf("pair costs (sum of the two instructions):\n");
   printf("%-34s %.2f cyc\n", "cvt_f32_f64 + cvt_f64_f32", 2.0 * 2 * run(k_cvt_f32_f64, d64, 1.0001, 0.5, 16) / base);
   printf("%-34s %.2f cyc\n", "cvt_i32_f64 + cvt_f64_i32", 2.0 * 2 * run(k_cvt_i32_f64, d64, 1.0001, 0.5, 16) / base);
