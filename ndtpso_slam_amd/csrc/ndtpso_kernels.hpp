@@ -1087,10 +1087,13 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
   double* pcs;    // [2][S] plain cos, sin of the proposal's heading  } exact mode only: what the fp64 score of a
   double* bcs;    // [2][S] the same for the pbest position            } position takes (exact_tasks), so that the
   int32_t* raw;   // [max(3(P+1), 6P)] rand() outputs of the current phase   arbitration needs no sincos of its own
+  int32_t* raw2;  // [6P] the next iteration's outputs, generated by an idle wave behind the current one's last round
 };
 __host__ __device__ inline int swarm_doubles(int P) { return 25 * (P + 1); }
 __host__ __device__ inline int swarm_raw_ints(int P) { return (6 * P > 3 * (P + 1)) ? 6 * P : 3 * (P + 1); }
-__host__ __device__ inline int swarm_bytes(int P) { return align16(swarm_doubles(P) * 8) + align16(swarm_raw_ints(P) * 4); }
+__host__ __device__ inline int swarm_bytes(int P) {
+  return align16(swarm_doubles(P) * 8) + align16(swarm_raw_ints(P) * 4) + align16(6 * P * 4);
+}
 
 __device__ inline Swarm swarm_carve(unsigned char* base, int P) {
   const int S = P + 1;
@@ -1110,6 +1113,7 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P) {
   sw.pcs = d + 21 * S;
   sw.bcs = d + 23 * S;
   sw.raw = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P) * 8));
+  sw.raw2 = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P) * 8) + align16(swarm_raw_ints(P) * 4));
   return sw;
 }
 
@@ -1584,7 +1588,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       a.S = S;
     }
   }
-  if (gen && wave_id() == 0) {
+  // The device replay of glibc's generator is the work of ONE wave -- the last one, which is the wave left without an
+  // item when an evaluation round has fewer items than the workgroup has waves (see the iterations below).
+  const int rng_w = (int)(blockDim.x >> 6) - 1;
+  if (gen && wave_id() == rng_w) {
     rng_seed_wave0(&sh->rng, seed);
     rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 3 * S);
   }
@@ -1719,14 +1726,29 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #else
 #define NDTPSO_PSO_MARK(k) do { } while (0)
 #endif
+  // Device generator: the 6P draws of an iteration took one wave 3.4 us while the other seven waited at the barrier
+  // behind it -- 235 us of a 2.2 ms alignment (-DNDTPSO_PROFILE_PSO).  The last evaluation round of an iteration
+  // (70 particles in rounds of 16: 6 items for 8 waves) leaves the last wave without an item: it generates the NEXT
+  // iteration's draws then, into the other of two buffers, and the iteration starts from them without waiting.
+  // (Replays re-read the current iteration's draws, hence two buffers.  A cluster keeps the old scheme.)
+  int32_t* dcur = sw.raw;
+  int32_t* dnext = sw.raw2;
+  bool have_next = false;
   for (int it = 0; it < ps.I; ++it) {
     NDTPSO_PSO_MARK(4);
     if (gen) {
-      if (wave_id() == 0) rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 6 * P);
-      __syncthreads();
+      if (have_next) {  // generated behind the previous iteration's last round, published by the barriers since
+        int32_t* t = dcur;
+        dcur = dnext;
+        dnext = t;
+        have_next = false;
+      } else {
+        if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dcur, 6 * P);
+        __syncthreads();
+      }
     }
     NDTPSO_PSO_MARK(0);
-    const int32_t* draws = (gen || prefetch) ? sw.raw : (table + 3 * S + (size_t)it * 6 * P);
+    const int32_t* draws = gen ? dcur : (prefetch ? sw.raw : (table + 3 * S + (size_t)it * 6 * P));
     if (prefetch && it + 1 < ps.I) {
       const int32_t* next = table + 3 * S + (size_t)(it + 1) * 6 * P;
       if (tid < 6 * P) pre0 = next[tid];
@@ -1797,6 +1819,13 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       const int hi_g = min(lo + ps.G, P);
       eval_round<MODE, PATH, CLUSTER, ARB>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
                                       &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot]);
+      if constexpr (!CLUSTER) {
+        // the iteration's last round with a wave to spare: that wave (it had no item above) draws the next iteration's numbers
+        if (gen && !have_next && it + 1 < ps.I && hi_g == P && hi_g - lo <= rng_w) {
+          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext, 6 * P);
+          have_next = true;
+        }
+      }
       n_evals += (uint32_t)(hi_g - lo);
       n_rounds += 1;
       __syncthreads();
