@@ -1244,8 +1244,8 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
 // The PSO consumes a cost only through `cost < best_cost` / `cost < global_best.best_cost` (core.cpp:63,94,97); the
 // value itself survives only as a later comparison's right-hand side and as the returned gbest cost.  The fp32 score
 // is within ~1e-8 relative of the fp64 one (worst case seen 6e-6 absolute on costs of 300..900), so a comparison
-// whose two sides differ by more than kArbRel * |gbest cost| -- three orders of magnitude above that -- comes out the
-// same in either arithmetic.  The few that are closer ("near": 0.1-1 per 70 x 70 alignment) are ARBITRATED: the
+// whose two sides differ by more than kArbRel * |gbest cost| (2e-3 absolute there, 300 times that) comes out the
+// same in either arithmetic.  The few that are closer ("near": ~0.5 per 70 x 70 alignment) are ARBITRATED: the
 // proposal, the particle's pbest position and the gbest position are scored in fp64 exactly as the fp64-score kernels
 // score them (same operation order, same summation order, the bitmap-form table read from its HBM image), the three
 // stored costs are replaced by those values and the comparison is redone.  Every decision is then the fp64 mode's, so
@@ -1253,7 +1253,7 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
 // What this rests on: the fp32 score's error staying below kArbRel / 2 -- measured, not proven; and the dense
 // form's binning (gx within 1e-14 cells of the reference's value, see score_trip_dense).
 #ifndef NDTPSO_ARB_REL
-#define NDTPSO_ARB_REL 2e-5
+#define NDTPSO_ARB_REL 5e-6
 #endif
 constexpr double kArbRel = NDTPSO_ARB_REL;
 
@@ -1440,7 +1440,7 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       // exact mode: a comparison too close to call is noted for arbitration (pso_run_wg)
       if constexpr (ARB) {
         if (improver) {
-          const double tau = kArbRel * fabs(gbc);
+          const double tau = kArbRel * fabs(gbc);  // (uniform: scalar-unit work)
           if (near_tie(cost, pbc_j, tau) || near_tie(cost, gbc, tau)) near_note(near_cnt, near_list, j);
         }
       }
