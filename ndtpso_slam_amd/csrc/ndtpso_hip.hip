@@ -144,6 +144,7 @@ __device__ __forceinline__ EvalCtx make_eval_ctx(const GridP& g, const WinP& wn,
   E.T = lds_table_view(L);
   E.dn = dn;
   E.lds0 = g_lds;
+  E.light = 0;
   return E;
 }
 
@@ -187,6 +188,7 @@ __device__ __forceinline__ EvalCtx make_eval_ctx_global(const GridP& g, const Wi
   E.T = image_table_view(wn, image);
   E.dn = dn;
   E.lds0 = g_lds;
+  E.light = 0;
   return E;
 }
 
@@ -433,7 +435,8 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   copy16(pts, xy, n * 16);
   pad_points_wg(pts, n);
   __syncthreads();
-  const EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
+  EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
+  E.light = CLUSTER ? 0 : ps.light;
   if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, image);  // exact mode: the staged image holds the fp64 records
   // a swarm too large for LDS lives in an HBM workspace, one per workgroup of a cluster (each keeps the whole swarm)
   // Two copies of the PSO, one per home of the swarm, so that in each the compiler knows the address space of the
@@ -538,7 +541,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
            (tk[3] - tk[2]) * 0.01, (tk[4] - tk[3]) * 0.01);
 #endif
 
-  const EvalCtx E = make_eval_ctx(g, wn, L, dn);
+  EvalCtx E = make_eval_ctx(g, wn, L, dn);
+  E.light = CLUSTER ? 0 : ps.light;
   if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg);
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
   if (L.swarm_global) {  // (two copies: see k_align)
@@ -760,6 +764,14 @@ PsoP make_pso(const ndtpso_pso_config* c, int waves) {
   int k = 2;  // particles per evaluation round = k x waves
   if (const char* e = std::getenv("NDTPSO_GROUP")) k = std::max(1, std::atoi(e));  // tuning knob
   p.G = std::min(std::max(waves * k, 1), std::max(c->population, 1));
+  // light wave (PsoP::light): rounds of 2 x waves - 1, wave 0 takes one item and does the commits and the generator
+  static const bool light = [] {
+    const char* e = std::getenv("NDTPSO_LIGHT_WAVE");  // tuning knob: =0 deals every wave two items
+    return !(e && e[0] == '0');
+  }();
+  // (a swarm of a few rounds per iteration is better off with full shares and the generator in its last, short round)
+  p.light = (light && k == 2 && waves >= 2 && c->population > 8 * 2 * waves) ? 1 : 0;
+  if (p.light) p.G = std::min(2 * waves - 1, std::max(c->population, 1));
   p.w = c->w;
   p.c1 = c->c1;
   p.c2 = c->c2;
@@ -958,7 +970,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
-                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate, &c->cluster, &c->cluster_xc})
+                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate, &c->cluster, &c->cluster_xc, &c->ximg})
     b->release();
   for (BeamDirs& b : c->beam_dirs) b.buf.release();
   c->pinned.release();
@@ -1709,13 +1721,14 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
   //  - dense form only: alignments whose occupied box exceeded the provisioned cell table -> bitmap form;
   //  - alignments whose fp32 costs fell in the underflow regime (degenerate overlap) -> fp64 score.
   // If a redo form does not fit in LDS its flag simply stays set in the stats block.
-  if (path == 2) {  // (exact mode: the bitmap form cannot arbitrate, the fp64 score takes those alignments)
-    rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables,
-                      exact ? NDTPSO_SCORE_F64 : NDTPSO_SCORE_F32, d_pose, d_cost, st, kStatusNeedsBitmap, false, nullptr);
+  // (exact mode: the bitmap form cannot arbitrate, so both kinds of flagged alignment go to the fp64-score kernel, in one launch)
+  if (path == 2 && !exact) {
+    rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F32, d_pose,
+                      d_cost, st, kStatusNeedsBitmap, false, nullptr);
     if (rc != NDTPSO_OK && rc != NDTPSO_E_CAPACITY) return rc;
   }
   rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose,
-                    d_cost, st, kStatusNeedsF64, false, nullptr);
+                    d_cost, st, exact ? (kStatusNeedsF64 | kStatusNeedsBitmap) : kStatusNeedsF64, false, nullptr);
   return rc == NDTPSO_E_CAPACITY ? NDTPSO_OK : rc;
 }
 

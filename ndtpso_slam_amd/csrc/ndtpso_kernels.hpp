@@ -52,7 +52,10 @@ struct ScanP {
 
 struct PsoP {
   int P, I;
-  int G;  // particles evaluated per round (a multiple of the workgroup's wave count)
+  int G;  // particles evaluated per round: 2 x waves - 1 with a light wave (below), else a multiple of the wave count
+  int light;  // 1: wave 0 takes ONE item of a round, every other wave two -- wave 0 is the wave that commits the round
+              // before and replays glibc's generator, and with a full share it kept the other waves waiting at the
+              // round's barrier for exactly that long (one-workgroup kernels; a cluster deals its items differently)
   double w, c1, c2, wdamp;
 };
 
@@ -1165,6 +1168,7 @@ struct EvalCtx {
   TableView T;
   DenseP dn;
   const unsigned char* lds0;
+  int light;  // PsoP::light (the item -> wave deal of eval_items)
 };
 
 // ---- fp32 score mode, underflow regime ----------------------------------------------------------------
@@ -1405,7 +1409,12 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
                                   int last /*exclusive*/, double gbc, int* improver, int* tiny, int* near_cnt,
                                   unsigned short* near_list) {
   const int n_waves = blockDim.x >> 6;
-  for (int j = first + wave_id(); j < last; j += n_waves) {
+  // item k of the round goes to wave k + 1 for k < n - 1, to wave k - (n - 1) after that: wave 0 gets one item (k = n - 1)
+  // of a round of 2n - 1, the others two.  `light` off, or a longer round (the swarm's initialisation): plain striding.
+  const bool light = E.light && last - first <= 2 * n_waves - 1;
+  const int j0 = light ? (wave_id() == 0 ? first + n_waves - 1 : first + wave_id() - 1) : first + wave_id();
+  const int dj = light ? (wave_id() == 0 ? 2 * n_waves : n_waves) : n_waves;
+  for (int j = j0; j < last; j += dj) {
     const double c = sw.tc[j], s = sw.ts[j];
     const double pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
                                      // initialisation, where it is not looked at)
@@ -1588,9 +1597,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       a.S = S;
     }
   }
-  // The device replay of glibc's generator is the work of ONE wave -- the last one, which is the wave left without an
-  // item when an evaluation round has fewer items than the workgroup has waves (see the iterations below).
-  const int rng_w = (int)(blockDim.x >> 6) - 1;
+  // The device replay of glibc's generator is the work of ONE wave: wave 0 when it is the light wave of the evaluation
+  // rounds (PsoP::light), else the last wave -- the one a round with fewer items than waves leaves idle.
+  const int rng_w = ps.light ? 0 : (int)(blockDim.x >> 6) - 1;
   if (gen && wave_id() == rng_w) {
     rng_seed_wave0(&sh->rng, seed);
     rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 3 * S);
@@ -1726,24 +1735,36 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #else
 #define NDTPSO_PSO_MARK(k) do { } while (0)
 #endif
-  // Device generator: the 6P draws of an iteration took one wave 3.4 us while the other seven waited at the barrier
-  // behind it -- 235 us of a 2.2 ms alignment (-DNDTPSO_PROFILE_PSO).  The last evaluation round of an iteration
-  // (70 particles in rounds of 16: 6 items for 8 waves) leaves the last wave without an item: it generates the NEXT
-  // iteration's draws then, into the other of two buffers, and the iteration starts from them without waiting.
-  // (Replays re-read the current iteration's draws, hence two buffers.  A cluster keeps the old scheme.)
+  // Device generator: the 6P draws of an iteration took one wave 3.4 us (70 particles; 74 us for 2048) while all the
+  // others waited at the barrier behind it -- 235 us of a 2.2 ms alignment, 15 ms of a 179 ms one
+  // (-DNDTPSO_PROFILE_PSO).  Now the NEXT iteration's draws are generated while the current one is evaluated, into the
+  // other of two buffers (replays re-read the current iteration's draws):
+  //   - large swarms (PsoP::light): by the light wave, a slice per evaluation round, in the time its second item
+  //     would have taken (config 5: 1418 -> 1503 align/s together with the commits that wave no longer delays);
+  //   - small swarms: all of them by the last wave during the iteration's last round, when that round has fewer items
+  //     than the workgroup has waves (70 particles in rounds of 16: 6 items for 8 waves) -- 212 -> 219 k align/s; the
+  //     light-wave deal costs such a swarm 2 % instead.
+  // What is still missing when the iteration ends is drawn then.  (A cluster draws at the start of the iteration.)
   int32_t* dcur = sw.raw;
   int32_t* dnext = sw.raw2;
-  bool have_next = false;
+  int next_filled = 0;  // draws of the next iteration already in dnext (the same in every thread)
+  const bool overlapped = gen && !CLUSTER, sliced = overlapped && ps.light;
+  const int n_draw = 6 * P;
+  const int slice = 30 * max(1, (n_draw + 30 * ((P + ps.G - 1) / ps.G) - 1) / (30 * ((P + ps.G - 1) / ps.G)));
   for (int it = 0; it < ps.I; ++it) {
     NDTPSO_PSO_MARK(4);
     if (gen) {
-      if (have_next) {  // generated behind the previous iteration's last round, published by the barriers since
+      if (overlapped && it > 0) {  // what the previous iteration's rounds left time for, and the rest now
+        if (next_filled < n_draw) {
+          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext + next_filled, n_draw - next_filled);
+          __syncthreads();
+        }
         int32_t* t = dcur;
         dcur = dnext;
         dnext = t;
-        have_next = false;
+        next_filled = 0;
       } else {
-        if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dcur, 6 * P);
+        if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dcur, n_draw);
         __syncthreads();
       }
     }
@@ -1820,10 +1841,14 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       eval_round<MODE, PATH, CLUSTER, ARB>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
                                       &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot]);
       if constexpr (!CLUSTER) {
-        // the iteration's last round with a wave to spare: that wave (it had no item above) draws the next iteration's numbers
-        if (gen && !have_next && it + 1 < ps.I && hi_g == P && hi_g - lo <= rng_w) {
-          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext, 6 * P);
-          have_next = true;
+        // the light wave's other job: a slice of the next iteration's draws (published by the barriers that follow)
+        if (sliced && it + 1 < ps.I && next_filled < n_draw) {
+          const int cnt = min(slice, n_draw - next_filled);
+          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext + next_filled, cnt);
+          next_filled += cnt;
+        } else if (overlapped && !ps.light && it + 1 < ps.I && next_filled == 0 && hi_g == P && hi_g - lo <= rng_w) {
+          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext, n_draw);  // (rng_w had no item in this round)
+          next_filled = n_draw;
         }
       }
       n_evals += (uint32_t)(hi_g - lo);
