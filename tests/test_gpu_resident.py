@@ -163,12 +163,34 @@ def test_resident_scan_append_and_errors(ctx, oracle):
     with pytest.raises(capi.NdtpsoError) as e:
         scan.load_scan(ranges[0], geom, append=True)        # third scan does not fit
     assert e.value.code == capi.E_CAPACITY
-    # a pool that is too small is reported, not silently truncated
+    # a point pool that is too small grows (the reference's cells grow their vectors): every point is kept ...
+    n_scan = scan.get().shape[0]
     tiny = capi.ResidentMap(ctx, grid, pool_bytes=64 * 512)
-    tiny.insert(scan, (0, 0, 0))
-    with pytest.raises(capi.NdtpsoError) as e:
-        tiny.info()
-    assert e.value.code == capi.E_CAPACITY
+    for _ in range(3):
+        tiny.insert(scan, (0, 0, 0))
+    assert tiny.info()["n_points"] == 3 * n_scan and tiny.points().shape[0] == 3 * n_scan
+    big = capi.ResidentMap(ctx, grid, pool_bytes=64 << 20)
+    for _ in range(3):
+        big.insert(scan, (0, 0, 0))
+    assert np.array_equal(tiny.points(), big.points())
+    tiny.build()
+    big.build()
+    ct, cb = tiny.cells(), big.cells()
+    assert len(ct) == len(cb) and all(a["index"] == b["index"] and a["count"] == b["count"] and a["built"] == b["built"] and
+                                      np.array_equal(a["mean"], b["mean"], equal_nan=True) and
+                                      np.array_equal(a["icov"], b["icov"], equal_nan=True) for a, b in zip(ct, cb))
+    # ... and where it cannot (NDTPSO_MAP_POOL_FIXED: what a failed allocation leaves), running out is reported, not
+    # silently truncated
+    import os
+    os.environ["NDTPSO_MAP_POOL_FIXED"] = "1"
+    try:
+        fixed = capi.ResidentMap(ctx, grid, pool_bytes=64 * 512)
+        fixed.insert(scan, (0, 0, 0))
+        with pytest.raises(capi.NdtpsoError) as e:
+            fixed.info()
+        assert e.value.code == capi.E_CAPACITY
+    finally:
+        del os.environ["NDTPSO_MAP_POOL_FIXED"]
 
 
 def test_resident_sequence_matches_golden_fixture(ctx):
