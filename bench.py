@@ -365,7 +365,8 @@ def _cpu_baseline(pairs, S, P, I):
     """the repo's fp64 CPU restatement of the reference (oracle/ndtpso_oracle.c, `kind: "port"` -- the
     reference itself cannot be built in this image) on the GPU box's host cores:
       c1  one scan pair (BASELINE config 1) in the reference's own parallel shape -- OpenMP over the particles of an
-          iteration, live rand(), racy gbest (core.cpp:72-109) -- median of 21 alignments, at 1 thread and at all;
+          iteration, live rand(), racy gbest (core.cpp:72-109) -- median of 21 alignments, at 1, 8 and all threads
+          (the reference's default is all: num_threads = -1, config.h:30);
       c3  all S pairs of this step, sequential alignments parallelised over pairs on all threads (the fairest CPU
           figure: no synchronisation at all), best of two passes; this is `value`."""
     from oracle import pyoracle
@@ -377,14 +378,14 @@ def _cpu_baseline(pairs, S, P, I):
     new.load_laser(pairs.new_ranges[0], pairs.angle_min, pairs.angle_inc, pairs.range_max)
     ref.build()
     c1 = {}
-    for label, nt in (("1_thread", 1), ("all_threads", 0)):
+    for label, nt in (("1_thread", 1), ("8_threads", 8), ("all_threads", 0)):
         ts = []
         for _ in range(21):
             t1 = time.perf_counter()
             ref.pso_omp((0, 0, 0), new, DEVIATION, ocfg, n_threads=nt)
             ts.append(time.perf_counter() - t1)
         c1[label] = {"alignments_per_s": 1.0 / float(np.median(ts)), "median_ms": 1e3 * float(np.median(ts)),
-                     "threads": 1 if nt == 1 else nproc, "runs": len(ts)}
+                     "threads": nt if nt else nproc, "runs": len(ts)}
     best, used, opose = None, 1, None
     for _ in range(2):
         t1 = time.perf_counter()

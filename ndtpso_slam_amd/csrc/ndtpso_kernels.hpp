@@ -206,6 +206,9 @@ __device__ __forceinline__ void cell_coords_rt(const GridP& g, double qx, double
 #ifndef NDTPSO_UNROLL
 #define NDTPSO_UNROLL 4
 #endif
+#ifndef NDTPSO_MAD24_INDEX
+#define NDTPSO_MAD24_INDEX 1
+#endif
 #ifndef NDTPSO_ALTERNATE_PRIO
 #define NDTPSO_ALTERNATE_PRIO 1
 #endif
@@ -358,7 +361,13 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
     // Out-of-window coordinates clamp into the always-null high column / row (negative ones convert to huge
     // unsigned values first; column / row 0 is the empty low border): no range test, no select.
     const unsigned rx = min((unsigned)(int)gx[u], (unsigned)dn.dw), ry = min((unsigned)(int)gy[u], (unsigned)dn.dh);
+#if NDTPSO_MAD24_INDEX
+    // one v_mad_u32_u24 (+ the shift of the table read below) instead of v_mul_u32_u24 + v_add_lshl_u32: on this chip
+    // the 24-bit multiply alone costs as much as the multiply-add (scripts/ubench_valu.hip), the shift half of it
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lin[u]) : "v"(ry), "s"((unsigned)dense_stride(dn.dw)), "v"(rx));
+#else
     lin[u] = __umul24(ry, (unsigned)dense_stride(dn.dw)) + rx;
+#endif
     // A grid whose last cells overhang the frame (width/cs not an integer): points past the frame's upper
     // bound are rejected by NDTFrame::getCellIndex (ndtframe.cpp:242) although a cell exists there.
     if constexpr (CLIP) lin[u] = ((int)(gx[u] < it.XMAX) & (int)(gy[u] < it.YMAX)) ? lin[u] : 0u;  // cell 0: null

@@ -61,7 +61,7 @@ def main():
     print("| beams | cell m | P x I | pairs | score | table form | window | LDS B/WG | threads/WG | WG/CU | swarm | ms/launch | align/s | evals/align |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for (n, cs, P, I, B) in rows:
-        for mode, mname in ((capi.SCORE_F32, "f32"), (capi.SCORE_F64, "f64")):
+        for mode, mname in ((capi.SCORE_EXACT, "exact"), (capi.SCORE_F32, "f32"), (capi.SCORE_F64, "f64")):
             if mode == capi.SCORE_F64 and (P > 512 and I > 20):
                 continue
             geom = capi.ScanGeom(n, -2.356194, 4.712389 / (n - 1), 30.0, 0.1)
