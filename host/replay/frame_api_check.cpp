@@ -88,5 +88,23 @@ int main(int argc, char** argv) {
   a.loadLaser(scans[1], amin, ainc, rmax);
   a.build();
   print_cells("A reset + scan 1", a);
+
+  // addScan(pose, scan) == loadLaser into a one-cell per-scan frame + update with it (the two lines must be identical)
+  const Vector3d at(0.4, -0.3, 0.07);
+  NDTFrame c1(Vector3d::Zero(), 60, 60, 0.5, true), c2(Vector3d::Zero(), 60, 60, 0.5, true);
+  c1.addScan(Vector3d::Zero(), scans[0], amin, ainc, rmax);
+  c1.addScan(at, scans[2], amin, ainc, rmax);
+  c1.build();
+  {
+    NDTFrame s0(Vector3d::Zero(), 60, 60, 60, false), s2(Vector3d::Zero(), 60, 60, 60, false);
+    s0.loadLaser(scans[0], amin, ainc, rmax);
+    c2.update(Vector3d::Zero(), &s0);
+    s2.loadLaser(scans[2], amin, ainc, rmax);
+    c2.update(at, &s2);
+  }
+  c2.build();
+  print_cells("addScan", c1);
+  print_cells("addScan", c2);
+  std::printf("errors %lu\n", ndtpso_slam_error_count());
   return 0;
 }

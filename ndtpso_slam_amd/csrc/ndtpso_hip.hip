@@ -37,7 +37,7 @@ struct Layout {
 // fmt: kScoreF32 -> mean+chol, kScoreF64 -> mean+ab+cd, 2 -> everything (table build kernel);
 // ddw > 0: dense form with a ddw x ddh cell table (fp32 score only)
 Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw = 0, int ddh = 0,
-                   bool swarm_global = false) {
+                   bool swarm_global = false, bool exact = false) {
   Layout L;
   L.swarm_global = swarm_global ? 1 : 0;
   const bool dense = ddw > 0;
@@ -81,7 +81,7 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
     L.bm_off = L.region_off + scratch;
     scratch += align16(n_words * 8);
   }
-  const int swarm = (P > 0 && !swarm_global) ? swarm_bytes(P) : 0;
+  const int swarm = (P > 0 && !swarm_global) ? swarm_bytes(P, exact, swarm_has_raw2(P, false)) : 0;
   L.total = L.region_off + std::max(scratch, swarm);
   return L;
 }
@@ -443,11 +443,11 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   // swarm arrays: selecting the base pointer at run time made every swarm access a FLAT instruction (74 of them), and
   // the proposal / commit phases -- one or two waves working, the rest waiting -- are chains of exactly those accesses.
   if (L.swarm_global) {
-    const Swarm sw = swarm_carve(ws + (size_t)cl.rank * swarm_bytes(ps.P), ps.P);
+    const Swarm sw = swarm_carve(ws + (size_t)cl.rank * swarm_bytes(ps.P, true, true), ps.P, ARB, true);
     pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
                                          out_cost, stats, cl);
   } else {
-    const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
+    const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
     pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
                                          out_cost, stats, cl);
   }
@@ -546,12 +546,12 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg);
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
   if (L.swarm_global) {  // (two copies: see k_align)
-    const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P);
+    const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P, ARB, true);
     pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                                          tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
                                          out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
   } else {
-    const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P);
+    const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
     pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                                          tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
                                          out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
@@ -809,7 +809,7 @@ struct Plan {
 // allow_global: when neither form fits, read the table from its HBM image (path 4 / 5; kernels that stage a prebuilt
 // table only -- a long-lived map can hold more built cells than LDS has room for).
 bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan* plan, bool dynamic_window = false,
-               bool allow_dense = true, bool allow_global = false) {
+               bool allow_dense = true, bool allow_global = false, bool exact = false) {
   const int bitmap_path = g.cs_pow2 ? 1 : 0;
   int force = -1;
   if (const char* e = std::getenv("NDTPSO_PATH")) force = std::atoi(e);  // tuning knob
@@ -819,7 +819,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
     if (swarm_global && P <= 0) break;
     if (dense_ok) {
       const int full_w = wn.w + 1, full_h = wn.h + 1;
-      Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, full_w, full_h, swarm_global != 0);
+      Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, full_w, full_h, swarm_global != 0, exact);
       int cap = dense_entries(full_w, full_h);
       if (dynamic_window && Ld.total > kMaxLds / 2) {
         // shrink the provisioned (square) table until two workgroups fit per CU, else until one does;
@@ -827,7 +827,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         for (int limit : {kMaxLds / 2, kMaxLds}) {
           bool found = false;
           for (int side = (int)std::sqrt((double)(full_w * full_h)); side >= 64; side -= 4) {
-            const Layout Lt = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0);
+            const Layout Lt = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0, exact);
             if (Lt.total <= limit) {
               Ld = Lt;
               cap = dense_entries(side, side);
@@ -846,7 +846,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         return true;
       }
     }
-    const Layout Lb = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, 0, 0, swarm_global != 0);
+    const Layout Lb = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, 0, 0, swarm_global != 0, exact);
     if (Lb.total <= kMaxLds) {
       plan->path = bitmap_path;
       plan->L = Lb;
@@ -862,7 +862,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
   if (allow_global) {
     for (int swarm_global = 0; swarm_global < 2; ++swarm_global) {
       if (swarm_global && P <= 0) break;
-      const Layout Lg = make_layout(0, 0, n_max, P, mode, 0, 0, swarm_global != 0);
+      const Layout Lg = make_layout(0, 0, n_max, P, mode, 0, 0, swarm_global != 0, exact);
       if (Lg.total <= kMaxLds) {
         plan->path = bitmap_path | 4;
         plan->L = Lg;
@@ -1437,7 +1437,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   // exact mode: the fp32-score kernel with arbitration where the table takes the dense form, else the fp64 score itself
   int exact = 0;
   if (mode == NDTPSO_SCORE_EXACT) {
-    if (!make_plan(NDTPSO_SCORE_F32, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true) ||
+    if (!make_plan(NDTPSO_SCORE_F32, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true, true) ||
         plan.path != 2) {
       mode = NDTPSO_SCORE_F64;
     } else {
@@ -1445,14 +1445,14 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
       exact = 1;
     }
   }
-  if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true))
+  if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true, exact != 0))
     return fail(c, NDTPSO_E_CAPACITY, "points + swarm do not fit in LDS");
   const Layout& L = plan.L;
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
   int K, cw;
   cluster_shape(cfg->population, true, allow_cluster, &K, &cw);
-  if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population) * (size_t)K));
+  if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves);
   ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr};
@@ -1557,12 +1557,12 @@ static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_con
 
 static int pairs_plan(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg, int mode,
                       unsigned n_pairs, GridP* g, WinP* wn, Plan* plan, int* waves, bool allow_dense = true,
-                      unsigned n_cus = 0) {
+                      unsigned n_cus = 0, bool exact = false) {
   if (!geom || geom->n_beams == 0 || !cfg || cfg->population < 1 || cfg->iterations < 0) return NDTPSO_E_ARG;
   if (make_grid(grid, g) != NDTPSO_OK) return NDTPSO_E_ARG;
   const double r = (double)geom->max_range;
   *wn = make_window(*g, -r, r, -r, r, (int)(geom->n_beams / 3) + 1);
-  const bool ok = make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan, true, allow_dense);
+  const bool ok = make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan, true, allow_dense, false, exact);
   *waves = pick_waves(cfg->population, plan->L.total, n_pairs, n_cus);
   return ok ? NDTPSO_OK : NDTPSO_E_CAPACITY;
 }
@@ -1583,13 +1583,14 @@ int ndtpso_align_pairs_footprint(const ndtpso_scan_geom* geom, const ndtpso_grid
 int ndtpso_align_pairs_describe(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg,
                                 int mode, uint32_t n_pairs, ndtpso_pairs_plan* out) {
   if (!out || (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64 && mode != NDTPSO_SCORE_EXACT)) return NDTPSO_E_ARG;
-  if (mode == NDTPSO_SCORE_EXACT) mode = NDTPSO_SCORE_F32;  // the same kernels and footprint
+  const bool exact = mode == NDTPSO_SCORE_EXACT;
+  if (exact) mode = NDTPSO_SCORE_F32;  // the same table forms; the swarm keeps four more arrays
   std::memset(out, 0, sizeof(*out));
   GridP g;
   WinP wn;
   Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves);
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves, true, 0, exact);
   if (rc == NDTPSO_E_ARG) return rc;
   out->block_threads = (uint32_t)waves * 64u;
   out->window_w = (uint32_t)wn.w;
@@ -1612,7 +1613,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   WinP wn;
   Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves, allow_dense, (unsigned)c->n_cus);
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves, allow_dense, (unsigned)c->n_cus, exact);
   if (path_out) *path_out = plan.path;
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
@@ -1635,7 +1636,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     cl.bar = bar;
   }
   const size_t stride = ndtpso_rand_draws(cfg);
-  const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population) : 0;
+  const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population, true, true) : 0;
   if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs * (size_t)K));
   // exact mode on the dense form: one fp64 table image per workgroup in HBM (bitmap of the per-alignment window, mean,
   // ab, cd), written by the table build and read by the arbitration only
@@ -1703,7 +1704,7 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
     WinP w0;
     Plan p0;
     int waves0 = 0;
-    const int rc0 = pairs_plan(geom, grid, cfg, NDTPSO_SCORE_F32, n_pairs, &g0, &w0, &p0, &waves0, true, (unsigned)c->n_cus);
+    const int rc0 = pairs_plan(geom, grid, cfg, NDTPSO_SCORE_F32, n_pairs, &g0, &w0, &p0, &waves0, true, (unsigned)c->n_cus, true);
     mode = (rc0 == NDTPSO_OK && p0.path == 2) ? NDTPSO_SCORE_F32 : NDTPSO_SCORE_F64;
     exact = mode == NDTPSO_SCORE_F32;
   }

@@ -1101,13 +1101,17 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
   int32_t* raw;   // [max(3(P+1), 6P)] rand() outputs of the current phase   arbitration needs no sincos of its own
   int32_t* raw2;  // [6P] the next iteration's outputs, generated by an idle wave behind the current one's last round
 };
-__host__ __device__ inline int swarm_doubles(int P) { return 25 * (P + 1); }
+// exact: the arbitrating kernels keep the headings' cosines and sines (pcs, bcs); raw2: the second draw buffer of the
+// overlapped generator -- always with the swarm in its HBM workspace, in LDS only for swarms of up to 256 particles (a
+// 512-particle swarm with it no longer fits beside the dense table: 16 266 instead of 26 202 align/s, measured)
+__host__ __device__ inline bool swarm_has_raw2(int P, bool swarm_global) { return swarm_global || P <= 256; }
+__host__ __device__ inline int swarm_doubles(int P, bool exact) { return (exact ? 25 : 21) * (P + 1); }
 __host__ __device__ inline int swarm_raw_ints(int P) { return (6 * P > 3 * (P + 1)) ? 6 * P : 3 * (P + 1); }
-__host__ __device__ inline int swarm_bytes(int P) {
-  return align16(swarm_doubles(P) * 8) + align16(swarm_raw_ints(P) * 4) + align16(6 * P * 4);
+__host__ __device__ inline int swarm_bytes(int P, bool exact, bool raw2) {
+  return align16(swarm_doubles(P, exact) * 8) + align16(swarm_raw_ints(P) * 4) + (raw2 ? align16(6 * P * 4) : 0);
 }
 
-__device__ inline Swarm swarm_carve(unsigned char* base, int P) {
+__device__ inline Swarm swarm_carve(unsigned char* base, int P, bool exact, bool raw2) {
   const int S = P + 1;
   double* d = reinterpret_cast<double*>(base);
   Swarm sw;
@@ -1122,10 +1126,10 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P) {
   sw.tcost = d + 18 * S;
   sw.ttx = d + 19 * S;
   sw.tty = d + 20 * S;
-  sw.pcs = d + 21 * S;
-  sw.bcs = d + 23 * S;
-  sw.raw = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P) * 8));
-  sw.raw2 = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P) * 8) + align16(swarm_raw_ints(P) * 4));
+  sw.pcs = exact ? d + 21 * S : nullptr;
+  sw.bcs = exact ? d + 23 * S : nullptr;
+  sw.raw = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P, exact) * 8));
+  sw.raw2 = raw2 ? reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P, exact) * 8) + align16(swarm_raw_ints(P) * 4)) : nullptr;
   return sw;
 }
 
@@ -1757,7 +1761,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   int32_t* dcur = sw.raw;
   int32_t* dnext = sw.raw2;
   int next_filled = 0;  // draws of the next iteration already in dnext (the same in every thread)
-  const bool overlapped = gen && !CLUSTER, sliced = overlapped && ps.light;
+  const bool overlapped = gen && !CLUSTER && sw.raw2 != nullptr, sliced = overlapped && ps.light;
   const int n_draw = 6 * P;
   const int slice = 30 * max(1, (n_draw + 30 * ((P + ps.G - 1) / ps.G) - 1) / (30 * ((P + ps.G - 1) / ps.G)));
   for (int it = 0; it < ps.I; ++it) {

@@ -276,6 +276,10 @@ def test_frame_api_resident_and_host_frames_agree(tmp_path, oracle):
                                                                      NDTPSO_SCORE="f64"))
     print(outs["1"])
     assert outs["1"] == outs["0"]
+    # NDTFrame::addScan (north star's name for loadLaser + update): the frame it fills equals the two-call one
+    add = [l for l in outs["1"].splitlines() if l.startswith("addScan")]
+    assert len(add) == 2 and add[0] == add[1] and " built 0 " not in add[0]
+    assert outs["1"].strip().splitlines()[-1] == "errors 0"
     for ext in (".pose.csv", ".map.csv"):
         assert open(str(tmp_path / "dump1") + ext).read() == open(str(tmp_path / "dump0") + ext).read()
     lines = {l.split()[0]: l.split()[1:] for l in outs["1"].splitlines() if l.split()[0] in ("cost", "pso")}
