@@ -206,6 +206,9 @@ __device__ __forceinline__ void cell_coords_rt(const GridP& g, double qx, double
 #ifndef NDTPSO_UNROLL
 #define NDTPSO_UNROLL 4
 #endif
+#ifndef NDTPSO_PRIO_SHARE
+#define NDTPSO_PRIO_SHARE 9  // sixteenths of the time the later-dispatched partner on a CU holds the higher priority (8, 10, 11 re-measured in round 2: 9 stays)
+#endif
 #ifndef NDTPSO_MAD24_INDEX
 #define NDTPSO_MAD24_INDEX 1
 #endif
@@ -1843,7 +1846,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       // complementary at all times, and the later-dispatched one gets 9 of 16 slices, which is what equalises
       // their finishing times.
       if constexpr (!CLUSTER) {
-        if ((((unsigned)(wall_clock64() >> 9) & 15u) < 9u) == (blockIdx.x >= (gridDim.x >> 1)))
+        if ((((unsigned)(wall_clock64() >> 9) & 15u) < (unsigned)NDTPSO_PRIO_SHARE) == (blockIdx.x >= (gridDim.x >> 1)))
           __builtin_amdgcn_s_setprio(1);
         else
           __builtin_amdgcn_s_setprio(0);
