@@ -1754,13 +1754,13 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // Device generator: the 6P draws of an iteration took one wave 3.4 us (70 particles; 74 us for 2048) while all the
   // others waited at the barrier behind it -- 235 us of a 2.2 ms alignment, 15 ms of a 179 ms one
   // (-DNDTPSO_PROFILE_PSO).  Now the NEXT iteration's draws are generated while the current one is evaluated, into the
-  // other of two buffers (replays re-read the current iteration's draws):
-  //   - large swarms (PsoP::light): by the light wave, a slice per evaluation round, in the time its second item
-  //     would have taken (config 5: 1418 -> 1503 align/s together with the commits that wave no longer delays);
-  //   - small swarms: all of them by the last wave during the iteration's last round, when that round has fewer items
-  //     than the workgroup has waves (70 particles in rounds of 16: 6 items for 8 waves) -- 212 -> 219 k align/s; the
-  //     light-wave deal costs such a swarm 2 % instead.
-  // What is still missing when the iteration ends is drawn then.  (A cluster draws at the start of the iteration.)
+  // other of two buffers (replays re-read the current iteration's draws): by the light wave (PsoP::light), a slice per
+  // evaluation round, in the time its second item would have taken.  Together with the commits that wave no longer
+  // delays: config 5 1418 -> 1503 align/s, 512 pairs of 30 x 50 554 -> 594 k align/s, 256 pairs of 256 x 70 49.5 ->
+  // 55.2 k, config 3 +0.5-1 %.  Without a light wave (NDTPSO_LIGHT_WAVE=0) the last wave draws all of them during the
+  // iteration's last round when that round has fewer items than the workgroup has waves (70 particles in rounds of 16:
+  // 6 items for 8 waves; that alone took config 3 from 212 to 219 k align/s).  What is still missing when the
+  // iteration ends is drawn then.  (A cluster draws at the start of the iteration.)
   int32_t* dcur = sw.raw;
   int32_t* dnext = sw.raw2;
   int next_filled = 0;  // draws of the next iteration already in dnext (the same in every thread)
