@@ -1517,7 +1517,9 @@ constexpr unsigned long long kClusterWaitTicks = 20000000ull;  // 0.2 s of the 1
 template <int MODE, int PATH, bool CLUSTER, bool ARB = false>
 __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first, int last,
                                   double gbc, int* improver, int* tiny, const ClusterP& cl, unsigned& epoch,
-                                  int* timed_out, int* near_cnt, unsigned short* near_list) {
+                                  int* timed_out, int* near_cnt, unsigned short* near_list,
+                                  RngState* gen_st = nullptr, int* gen_t = nullptr, int32_t* gen_dst = nullptr,
+                                  int gen_cnt = 0, int gen_wave = -1) {
   if constexpr (!CLUSTER) {
     eval_items<MODE, PATH, ARB>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
   } else {
@@ -1536,6 +1538,9 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     }
     __syncthreads();
     NDTPSO_PHASE_MARK(1);
+    // behind the exchange (thread 0 spins on the arrival counter, everybody else would idle): one wave of every
+    // workgroup draws the next iteration's rand() numbers -- 3.4 us that used to stand alone at the iteration's start
+    if (gen_cnt > 0 && wave_id() == gen_wave) rng_fill_wave0(gen_st, gen_t, gen_dst, gen_cnt);
     if (threadIdx.x == 0) {
       __threadfence();
       atomicAdd(cl.bar, 1u);
@@ -1615,7 +1620,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   }
   // The device replay of glibc's generator is the work of ONE wave: wave 0 when it is the light wave of the evaluation
   // rounds (PsoP::light), else the last wave -- the one a round with fewer items than waves leaves idle.
-  const int rng_w = ps.light ? 0 : (int)(blockDim.x >> 6) - 1;
+  const int rng_w = (ps.light && !CLUSTER) ? 0 : (int)(blockDim.x >> 6) - 1;  // (a cluster's wave 0 holds the exchange's spinning thread)
   if (gen && wave_id() == rng_w) {
     rng_seed_wave0(&sh->rng, seed);
     rng_fill_wave0(&sh->rng, &rng_t, sw.raw, 3 * S);
@@ -1764,7 +1769,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   int32_t* dcur = sw.raw;
   int32_t* dnext = sw.raw2;
   int next_filled = 0;  // draws of the next iteration already in dnext (the same in every thread)
-  const bool overlapped = gen && !CLUSTER && sw.raw2 != nullptr, sliced = overlapped && ps.light;
+  const bool overlapped = gen && sw.raw2 != nullptr, sliced = overlapped && !CLUSTER && ps.light;
   const int n_draw = 6 * P;
   const int slice = 30 * max(1, (n_draw + 30 * ((P + ps.G - 1) / ps.G) - 1) / (30 * ((P + ps.G - 1) / ps.G)));
   for (int it = 0; it < ps.I; ++it) {
@@ -1854,8 +1859,12 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #endif
       const int slot = (int)(grp % 3u);
       const int hi_g = min(lo + ps.G, P);
+      // a cluster draws the next iteration's numbers behind the first exchange of this one (eval_round)
+      const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
       eval_round<MODE, PATH, CLUSTER, ARB>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
-                                      &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot]);
+                                      &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
+                                      dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
+      if (gen_here) next_filled = n_draw;
       if constexpr (!CLUSTER) {
         // the light wave's other job: a slice of the next iteration's draws (published by the barriers that follow)
         if (sliced && it + 1 < ps.I && next_filled < n_draw) {
