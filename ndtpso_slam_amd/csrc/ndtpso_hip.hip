@@ -662,6 +662,9 @@ struct ndtpso_ctx {
   uint32_t n_rows = 0;
   int n_cus = 256;  // compute units of the device (multiProcessorCount)
   size_t cluster_next = 0;  // next unused arrival counter of the ring in `cluster`
+  // A cluster whose workgroups were not scheduled together gave up (bounded wait) and its alignment was redone on one
+  // workgroup: the device is shared with other work.  The next `cluster_penalty` single alignments do not try again.
+  int cluster_penalty = 0;
   DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster, cluster_xc, ximg;
   PinnedRing pinned;
   BeamDirs beam_dirs[4];  // cached beam directions of the scan geometries in use (beam_directions)
@@ -1452,6 +1455,10 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
   int K, cw;
+  if (allow_cluster && c->cluster_penalty > 0) {
+    --c->cluster_penalty;
+    allow_cluster = false;
+  }
   cluster_shape(cfg->population, true, allow_cluster, &K, &cw);
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
@@ -1502,7 +1509,10 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (K > 1) {
     AlignStats st;
     std::memcpy(&st, host + 4, sizeof(st));
-    if (st.status & kStatusClusterTimeout)  // the cluster was not co-resident (device shared with other work): one workgroup
+    if (st.status & kStatusClusterTimeout) {  // the cluster was not co-resident (device shared with other work): one workgroup,
+      c->cluster_penalty = 200;               // and no new attempt for the next 200 alignments (a robot's 5-20 s)
+    }
+    if (st.status & kStatusClusterTimeout)
       return align_once(c, src, cfg, seed, have_table, exact ? NDTPSO_SCORE_EXACT : mode, host, false);
   }
   return NDTPSO_OK;

@@ -1510,7 +1510,7 @@ struct ClusterP {
   double* xc;           // [2][stride] exchanged costs
 };
 constexpr uint32_t kStatusClusterTimeout = 16u;
-constexpr unsigned long long kClusterWaitTicks = 20000000ull;  // 0.2 s of the 100 MHz counter
+constexpr unsigned long long kClusterWaitTicks = 2000000ull;  // 20 ms of the 100 MHz counter (an exchange takes 1.5 us; round 1 waited 0.2 s)
 
 // Evaluates items [first, last) of the swarm; on return (after the caller's barrier) sw.tcost holds their costs and
 // *improver / *tiny are set as eval_items sets them.  `epoch` counts the cluster's exchanges.

@@ -13,14 +13,14 @@ with open('/tmp/scans.bin', 'wb') as f:
     ranges.tofile(f)
 cmd = ['host/replay/node_replay', '/tmp/scans.bin', '60', '0.5', '50', '30', '7']
 for resident in ('1', '0'):
-    for score in ('f32', 'f64'):
+    for score in ('exact', 'f32', 'f64'):
         for og in ([], ['0.1', '/tmp/replay_dump', '10']):
             env = dict(os.environ, NDTPSO_RESIDENT=resident, NDTPSO_SCORE=score)
             r = subprocess.run(cmd + og, capture_output=True, text=True, env=env)
             print('resident', resident, score, 'og+dump' if og else 'plain', r.stderr.strip().splitlines()[-1])
 if '--prof' in sys.argv:
     os.makedirs('gpurun_out/replay_prof', exist_ok=True)
-    env = dict(os.environ, NDTPSO_RESIDENT='1', NDTPSO_SCORE='f32', TMPDIR='/tmp')
+    env = dict(os.environ, NDTPSO_RESIDENT='1', NDTPSO_SCORE=os.environ.get('REPLAY_PROF_SCORE', 'exact'), TMPDIR='/tmp')
     subprocess.run(['rocprofv3', '--kernel-trace', '--stats', '-d', 'gpurun_out/replay_prof', '-o', 'replay', '--output-format', 'csv', '--'] + cmd + ['0.1', '/tmp/replay_dump2', '10'],
                    env=env, capture_output=True, text=True)
     for root, _, files in os.walk('gpurun_out/replay_prof'):

@@ -504,7 +504,14 @@ def test_small_batches_cluster_and_timeout_fallback(ctx, oracle, pairs8, monkeyp
     monkeypatch.delenv("NDTPSO_CLUSTER_TEST_ABSENT")
     assert np.array_equal(got[0], want[0][:2]) and (got[2]["status"] == 0).all()
     assert np.array_equal(got_one[0], want_one[0]) and got_one[1] == want_one[1]
-    assert 0.3 < waited < 5.0          # two bounded waits of 0.2 s, then the reruns
+    assert 0.03 < waited < 5.0         # two bounded waits of 20 ms, then the reruns
+    # after a timeout the context leaves clusters alone for a while: the next single alignment does not wait again
+    monkeypatch.setenv("NDTPSO_CLUSTER_TEST_ABSENT", "1")
+    t0 = time.perf_counter()
+    again = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, seed=int(p.seeds[0]))
+    waited = time.perf_counter() - t0
+    monkeypatch.delenv("NDTPSO_CLUSTER_TEST_ABSENT")
+    assert np.array_equal(again[0], want_one[0]) and waited < 0.02
 
 
 def test_coincident_points_cell_scores_nan_like_the_reference(ctx, oracle, pairs8):
