@@ -1510,7 +1510,8 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     AlignStats st;
     std::memcpy(&st, host + 4, sizeof(st));
     if (st.status & kStatusClusterTimeout) {  // the cluster was not co-resident (device shared with other work): one workgroup,
-      c->cluster_penalty = 200;               // and no new attempt for the next 200 alignments (a robot's 5-20 s)
+      c->cluster_penalty = cluster_test_absent() >= 0 ? 1 : 200;  // and no new attempt for the next 200 alignments (a
+                                                                   // robot's 5-20 s; one under the test hook)
     }
     if (st.status & kStatusClusterTimeout)
       return align_once(c, src, cfg, seed, have_table, exact ? NDTPSO_SCORE_EXACT : mode, host, false);
