@@ -3,7 +3,16 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ndtpso_slam_amd import capi, synth
-from oracle import pyoracle
+import ctypes
+_libc = ctypes.CDLL(None)
+
+
+def libc_rand(seed, n):
+    """srand(seed); n x rand() -- the table the drop-in library hands over"""
+    _libc.srand(ctypes.c_uint(int(seed)))
+    return np.array([_libc.rand() for _ in range(n)], dtype=np.int32)
+
+
 p = synth.make_pairs(8, seed=2024)
 dev = torch.device("cuda", 0)
 geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
@@ -17,7 +26,7 @@ for (P, I) in ((70, 70), (30, 50)):
         d_guess = torch.zeros(B, 3, dtype=torch.float64, device=dev)
         d_dev = torch.tensor((0.1, 0.1, 3.1415e-3), dtype=torch.float64, device=dev).repeat(B, 1).contiguous()
         d_seeds = torch.from_numpy(p.seeds[:B].astype(np.int64)).to(dev).to(torch.int32)
-        tabs = np.stack([pyoracle.glibc_rand(int(sd), n_draw) for sd in p.seeds[:B]])
+        tabs = np.stack([libc_rand(int(sd), n_draw) for sd in p.seeds[:B]])
         d_tabs = torch.from_numpy(tabs).to(dev)
         d_pose = torch.zeros(B, 3, dtype=torch.float64, device=dev); d_cost = torch.zeros(B, dtype=torch.float64, device=dev)
         d_stats = torch.zeros(B, 8, dtype=torch.int32, device=dev)
