@@ -42,6 +42,13 @@ for n in names:
     end = (st["t_end"] - st["t_start"].min()).astype(np.uint32) / 100.0
     print("%-6s steady state, last launch: wg duration us p50 %.0f p99 %.0f max %.0f; start spread %.0f; last finish %.0f; arbitrated mean %.2f max %d"
           % (n, np.percentile(dur, 50), np.percentile(dur, 99), dur.max(), start.max(), end.max(), st["arbitrated"].mean(), st["arbitrated"].max()))
+    if B % 2 == 0:
+        h = B // 2
+        ea, eb = end[:h], end[h:]
+        gap = eb - ea   # later-dispatched partner minus earlier one (assumed partners: b and b + B/2)
+        print("       partners (b, b + B/2): finish gap us mean %.0f, |gap| mean %.0f p90 %.0f max %.0f; CU finish (max of the two) p50 %.0f max %.0f; evals corr with duration %.2f"
+              % (gap.mean(), np.abs(gap).mean(), np.percentile(np.abs(gap), 90), np.abs(gap).max(), np.percentile(np.maximum(ea, eb), 50), np.maximum(ea, eb).max(),
+                 np.corrcoef(dur, st["cost_evals"])[0, 1]))
 for n in names:
     v = np.array(res[n])
     print("%-6s ms/launch: median %.4f  min %.4f  max %.4f   -> %.0f align/s" % (n, np.median(v), v.min(), v.max(), B / np.median(v) * 1e3))

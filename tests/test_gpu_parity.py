@@ -112,14 +112,14 @@ def test_align_matches_oracle_pose(ctx, oracle, pairs8, P, I):
     p = pairs8
     ocfg = oracle.PSOConfig.make(I, P)
     cfg = capi.PSOConfig.make(I, P)
-    worst = {capi.SCORE_F64: 0.0, capi.SCORE_F32: 0.0}
+    worst = {capi.SCORE_F64: 0.0, capi.SCORE_EXACT: 0.0, capi.SCORE_F32: 0.0}
     for b in range(4):
         ref, new = oracle_frames(oracle, p, b)
         want, want_cost, st = ref.pso((0, 0, 0), new, DEVIATION, ocfg, seed=int(p.seeds[b]))
         ctx.ref_from_scan(_grid(capi), p.ref_ranges[b], _geom(p, capi))
         xy = new.points()
         table = oracle.glibc_rand(int(p.seeds[b]), 3 + 3 * P + 6 * P * I)
-        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
             got, cost, gst = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, rand_table=table, mode=mode)
             d = np.abs(got - want)
             worst[mode] = max(worst[mode], d.max())
@@ -143,14 +143,14 @@ def test_align_pairs_fused_matches_oracle(ctx, oracle, pairs8):
     want, want_cost, _ = oracle.align_pairs(p.ref_ranges, p.new_ranges, p.angle_min, p.angle_inc, p.range_max, 0.1,
                                             FRAME_M, FRAME_M, CELL_SIDE, (0, 0, 0), DEVIATION,
                                             oracle.PSOConfig.make(I, P), p.seeds)
-    for mode in (capi.SCORE_F64, capi.SCORE_F32):
+    for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
         got, cost, stats = ctx.align_pairs(p.ref_ranges, p.new_ranges, _geom(p, capi), _grid(capi), (0, 0, 0),
                                            DEVIATION, capi.PSOConfig.make(I, P), seeds=p.seeds, mode=mode)
         assert (stats["status"] == 0).all()
         d = np.abs(got - want)
         print("mode", mode, "max |dpose|", d.max(axis=0), "evals", stats["cost_evals"])
         assert (d < 1e-3).all()
-        if mode == capi.SCORE_F64:
+        if mode != capi.SCORE_F32:
             assert d.max() < 1e-9
             assert np.abs(cost - want_cost).max() < 1e-9
     # accuracy vs ground truth is the reference's own (a few mm)
@@ -167,14 +167,14 @@ def test_large_swarm_config5_shape(ctx, oracle):
     want, want_cost, _ = oracle.align_pairs(p.ref_ranges, p.new_ranges, p.angle_min, p.angle_inc, p.range_max, 0.1,
                                             FRAME_M, FRAME_M, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P),
                                             p.seeds)
-    for mode in (capi.SCORE_F64, capi.SCORE_F32):
+    for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
         got, cost, stats = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, capi.Grid(FRAME_M, FRAME_M, cs), (0, 0, 0),
                                            DEVIATION, capi.PSOConfig.make(I, P), seeds=p.seeds, mode=mode)
         assert (stats["status"] == 0).all()
         d = np.abs(got - want)
         print("config-5 shape, mode", mode, "max |dpose|", d.max(axis=0), "evals", stats["cost_evals"], "built", stats["n_built"])
         assert (d < 1e-3).all()
-        if mode == capi.SCORE_F64:
+        if mode != capi.SCORE_F32:
             assert d.max() < 1e-9 and np.abs(cost - want_cost).max() < 1e-8
 
 
@@ -194,13 +194,13 @@ def test_edge_cases_empty_and_degenerate(ctx, oracle, pairs8):
     for (P, I) in ((1, 0), (1, 3), (5, 2), (70, 1)):
         want, wcost, _ = oracle.align_pairs(ref, new, p.angle_min, p.angle_inc, p.range_max, 0.1, FRAME_M, FRAME_M,
                                             CELL_SIDE, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P), p.seeds[:4])
-        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
             got, cost, stats = ctx.align_pairs(ref, new, geom, grid, (0, 0, 0), DEVIATION, capi.PSOConfig.make(I, P),
                                                seeds=p.seeds[:4], mode=mode)
             assert (stats["status"] == 0).all()
             assert stats["n_points"][0] == 0 and stats["n_built"][1] == 0
-            assert np.abs(got - want).max() < (1e-12 if mode == capi.SCORE_F64 else 1e-3), (P, I, mode, got, want)
-            assert np.abs(cost - wcost).max() < (1e-9 if mode == capi.SCORE_F64 else 1e-3)
+            assert np.abs(got - want).max() < (1e-12 if mode != capi.SCORE_F32 else 1e-3), (P, I, mode, got, want)
+            assert np.abs(cost - wcost).max() < (1e-9 if mode != capi.SCORE_F32 else 1e-3)
             assert cost[0] == 0.0 and cost[1] == 0.0
     # a guess that throws every point out of the frame: cost 0 everywhere, the first candidate wins
     far = np.tile(np.array([500.0, -500.0, 0.3]), (4, 1))
@@ -218,13 +218,13 @@ def test_non_pow2_cells_and_small_frame(ctx, oracle, pairs8):
     for frame, cs in ((FRAME_M, 0.3), (20, 0.5), (20, 0.7)):
         want, wcost, _ = oracle.align_pairs(p.ref_ranges[:3], p.new_ranges[:3], p.angle_min, p.angle_inc, p.range_max, 0.1,
                                             frame, frame, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(20, 24), p.seeds[:3])
-        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
             got, cost, stats = ctx.align_pairs(p.ref_ranges[:3], p.new_ranges[:3], _geom(p, capi), capi.Grid(frame, frame, cs),
                                                (0, 0, 0), DEVIATION, capi.PSOConfig.make(20, 24), seeds=p.seeds[:3], mode=mode)
             assert (stats["status"] == 0).all()
             d = np.abs(got - want)
             print("frame", frame, "cs", cs, "mode", mode, "max |dpose|", d.max())
-            assert d.max() < (1e-9 if mode == capi.SCORE_F64 else 1e-3)
+            assert d.max() < (1e-9 if mode != capi.SCORE_F32 else 1e-3)
 
 
 def test_bad_arguments_fail_loudly(ctx):
@@ -289,12 +289,12 @@ def test_randomised_configurations(ctx, oracle):
         geom = capi.ScanGeom(n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
         want, wcost, _ = oracle.align_pairs(ref, new, p.angle_min, p.angle_inc, p.range_max, 0.1, frame, frame, cs,
                                             guess, dev, oracle.PSOConfig.make(I, P), p.seeds)
-        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
             got, cost, stats = ctx.align_pairs(ref, new, geom, capi.Grid(frame, frame, cs), guess, dev,
                                                capi.PSOConfig.make(I, P), seeds=p.seeds, mode=mode)
             assert (stats["status"] == 0).all(), (case, mode, stats["status"])
             d = np.abs(got - want).max()
-            if mode == capi.SCORE_F64:
+            if mode != capi.SCORE_F32:
                 assert d < 1e-9 and np.abs(cost - wcost).max() < 1e-8, (case, n_beams, frame, cs, P, I, d)
             else:
                 worst32 = max(worst32, d)
@@ -338,11 +338,11 @@ def test_randomised_staged_tables(ctx, oracle):
         wc = np.array([ref.cost(q, new) for q in poses])
         assert np.abs(ctx.cost_batch(xy, poses, capi.SCORE_F64) - wc).max() < 1e-9
         assert np.abs(ctx.cost_batch(xy, poses, capi.SCORE_F32) - wc).max() < 1e-4 * max(len(xy), 1)
-        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
             got, cost, st = ctx.align(xy, guess, dev, capi.PSOConfig.make(I, P), seed=seed, mode=mode)
             d = np.abs(got - want).max()
             assert st["status"] == 0
-            if mode == capi.SCORE_F64:
+            if mode != capi.SCORE_F32:
                 assert d < 1e-9 and abs(cost - wcost) < 1e-8, (case, n_beams, frame, cs, P, I, d)
             else:
                 exact32 += int(d == 0.0)
@@ -365,12 +365,12 @@ def test_table_in_hbm_paths_match_lds_paths(ctx, oracle, pairs8, monkeypatch):
         out = {}
         for path in (lds_path, hbm_path):
             monkeypatch.setenv("NDTPSO_PATH", path)
-            for mode in (capi.SCORE_F64, capi.SCORE_F32):
+            for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
                 costs, idx = ctx.cost_batch(xy, poses, mode=mode, want_cells=True)
                 pose, cost, st = ctx.align(xy, (0, 0, 0), DEVIATION, capi.PSOConfig.make(50, 30), rand_table=table, mode=mode)
                 out[(path, mode)] = (costs, idx, pose, cost, st["cost_evals"])
         monkeypatch.delenv("NDTPSO_PATH")
-        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
             a, b = out[(lds_path, mode)], out[(hbm_path, mode)]
             assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
             assert np.array_equal(a[2], b[2]) and a[3] == b[3] and a[4] == b[4]
@@ -418,7 +418,7 @@ def test_map_larger_than_lds_is_served_from_hbm(ctx, oracle):
     ctx.ref_set_cells(grid, [c["index"] for c in cells], [c["mean"] for c in cells], [c["icov"] for c in cells])
     costs, _ = ctx.cost_batch(new_xy, poses, mode=capi.SCORE_F64, want_cells=True)
     assert np.abs(costs - want_costs).max() < 1e-9
-    for mode, tol in ((capi.SCORE_F64, 1e-9), (capi.SCORE_F32, 1e-3)):
+    for mode, tol in ((capi.SCORE_F64, 1e-9), (capi.SCORE_EXACT, 1e-9), (capi.SCORE_F32, 1e-3)):
         got, cost, st = ctx.align(new_xy, (0, 0, 0), DEVIATION, capi.PSOConfig.make(I, P), rand_table=table, mode=mode)
         assert st["n_built"] == n_cells and np.abs(got - want).max() < tol, (mode, got, want)
     # the same map, resident: inserted, built and aligned against on the device
@@ -443,7 +443,7 @@ def test_cluster_of_workgroups_matches_one_workgroup(ctx, oracle, pairs8, monkey
         ctx.ref_from_scan(grid, p.ref_ranges[b], _geom(p, capi))
         cfg = capi.PSOConfig.make(I, P)
         table = oracle.glibc_rand(int(p.seeds[b]), 3 + 3 * P + 6 * P * I)
-        for mode in (capi.SCORE_F32, capi.SCORE_F64):
+        for mode in (capi.SCORE_F32, capi.SCORE_F64, capi.SCORE_EXACT):
             for kw in (dict(rand_table=table), dict(seed=int(p.seeds[b]))):     # host table / device replay of rand()
                 monkeypatch.setenv("NDTPSO_CLUSTER", "0")
                 want = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, mode=mode, **kw)
@@ -479,7 +479,7 @@ def test_small_batches_cluster_and_timeout_fallback(ctx, oracle, pairs8, monkeyp
     def run(sel, mode):
         return ctx.align_pairs(p.ref_ranges[sel], p.new_ranges[sel], _geom(p, capi), _grid(capi), (0, 0, 0), DEVIATION,
                                cfg, seeds=p.seeds[sel], mode=mode)
-    for mode in (capi.SCORE_F32, capi.SCORE_F64):
+    for mode in (capi.SCORE_F32, capi.SCORE_F64, capi.SCORE_EXACT):
         monkeypatch.setenv("NDTPSO_CLUSTER", "0")
         want = run(np.arange(8), mode)
         monkeypatch.delenv("NDTPSO_CLUSTER")
@@ -561,14 +561,14 @@ def test_coincident_points_cell_scores_nan_like_the_reference(ctx, oracle, pairs
     icov = np.array([c["icov"] for c in cells if c["built"]])
 
     def check(cost_fn, align_fn, label):
-        for mode in (capi.SCORE_F64, capi.SCORE_F32):
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
             got_c = cost_fn(poses, mode)
             assert np.array_equal(np.isnan(got_c), np.isnan(want_c)), (label, mode)
             fin = np.isfinite(want_c)
             assert np.allclose(got_c[fin], want_c[fin], rtol=1e-9, atol=1e-9), (label, mode)   # (a batch with a NaN is
             # evaluated by the fp64 form in either mode; a batch without one keeps its form)
             got_f = cost_fn(poses[fin], mode)
-            assert np.allclose(got_f, want_c[fin], rtol=0, atol=1e-9 if mode == capi.SCORE_F64 else 1e-4 * len(new_xy))
+            assert np.allclose(got_f, want_c[fin], rtol=0, atol=1e-9 if mode != capi.SCORE_F32 else 1e-4 * len(new_xy))
             for (g, d), (wpose, wcost, _) in zip(cases, wants):
                 pose, cost, _ = align_fn(g, d, mode)
                 assert np.array_equal(pose, wpose), (label, mode, pose, wpose)
