@@ -343,6 +343,9 @@ def run_operation_sequence(ctx, oracle, seed, frame_w, frame_h, cs, ogcs):
             # (after a resetCells the window's stale partial terms can make a covariance indefinite and a cost infinite --
             # in the reference too; equal infinities count as equal)
             assert np.abs(got - want).max() < 1e-9, (it, got, want)
+            # the exact mode (the drop-in library's default) returns what the fp64 mode returns, NaN costs included
+            gotx, costx, _ = rmap.align(scan, (0, 0, 0), (.2, .2, .05), cfg, rand_table=table, mode=capi.SCORE_EXACT)
+            assert np.array_equal(gotx, got) and (costx == cost or (np.isnan(costx) and np.isnan(cost))), (it, gotx, got, costx, cost)
             got32, _, _ = rmap.align(scan, (0, 0, 0), (.2, .2, .05), cfg, rand_table=table, mode=capi.SCORE_F32)
             assert np.abs(got32 - want).max() < 1e-3, (it, got32, want)     # BASELINE tolerance of the fp32 score
             n_exact32 += int(np.array_equal(got32, want))
