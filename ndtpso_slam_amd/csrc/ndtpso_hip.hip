@@ -21,7 +21,7 @@ static_assert(sizeof(AlignStats) == sizeof(ndtpso_align_stats), "stats ABI");
 namespace {
 
 constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
-constexpr int kCtrlBytes = 832;      // control block (PsoShared + compaction counters)
+constexpr int kCtrlBytes = 864;      // control block (PsoShared + compaction counters)
 
 // LDS layout shared by every kernel.
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
@@ -145,6 +145,7 @@ __device__ __forceinline__ EvalCtx make_eval_ctx(const GridP& g, const WinP& wn,
   E.dn = dn;
   E.lds0 = g_lds;
   E.light = 0;
+  E.guard_lds = 0;
   return E;
 }
 
@@ -189,6 +190,7 @@ __device__ __forceinline__ EvalCtx make_eval_ctx_global(const GridP& g, const Wi
   E.dn = dn;
   E.lds0 = g_lds;
   E.light = 0;
+  E.guard_lds = 0;
   return E;
 }
 
@@ -500,8 +502,37 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
   __syncthreads();
   NDTPSO_SETUP_MARK(1);
+  DenseGuard guard{1., 0., 1., 0.};  // (empty: every pose takes the clamped loop)
   if constexpr (path_is_dense(PATH)) {
     wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
+    if constexpr (PATH == 3 && !CLUSTER) {
+      // Room in the table for scan B under any heading: all its points lie within rho of the sensor, so around the
+      // guess -- plus a margin for the translations the particles try -- a box of rho / cell_side cells either way
+      // holds every table coordinate the score loop can produce, and the loop may drop its clamps (DenseGuard).  The
+      // box is clipped to the grid and joined with scan A's occupied box; if the provisioned table cannot hold the
+      // union, the window stays A's box and the guard stays empty.
+      const float rho = scan_max_range_wg(new_ranges + b * sp.n_beams, sp, lds_cnt(L.ctrl_off) + 30);
+      const double rc = (double)rho * g.inv_cs * (1. + 1e-9) + 1e-6;  // cells, rounding of the transform included
+      const double cx = (guess[3 * b] + g.hw) * g.inv_cs, cy = (guess[3 * b + 1] + g.hh) * g.inv_cs;
+      constexpr double kMarginCells = 4.;
+      if (rho > 0.f && fabs(cx) < 1e6 && fabs(cy) < 1e6) {
+        const int bx0 = max((int)floor(cx - rc - kMarginCells), 0), bx1 = min((int)floor(cx + rc + kMarginCells), g.W - 1);
+        const int by0 = max((int)floor(cy - rc - kMarginCells), 0), by1 = min((int)floor(cy + rc + kMarginCells), g.H - 1);
+        if (bx1 >= bx0 && by1 >= by0) {
+          const int ux0 = min(wn.x0, bx0), uy0 = min(wn.y0, by0);
+          const int uw = max(wn.x0 + wn.w - 1, bx1) - ux0 + 1, uh = max(wn.y0 + wn.h - 1, by1) - uy0 + 1;
+          if (dense_entries(uw + 1, uh + 1) <= dense_cap) {
+            wn.x0 = ux0;
+            wn.y0 = uy0;
+            wn.w = uw;
+            wn.h = uh;
+            wn.n_words = (uw * uh + 31) / 32;
+            // table coordinates run over [0, dw + 1), dw = w + 1 (low border column, window, null high column)
+            guard = DenseGuard{rc, (double)(uw + 2) - rc, rc, (double)(uh + 2) - rc};
+          }
+        }
+      }
+    }
     dn.dw = wn.w + 1;
     dn.dh = wn.h + 1;
     dn.ox = wn.x0 - 1;
@@ -533,6 +564,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
                                       g.hw, g.hh);
   pad_points_wg(pts, n_new);
+  if (threadIdx.x == 0) lds_ctrl(L.ctrl_off)->guard = guard;
   __syncthreads();
   NDTPSO_SETUP_MARK(4);
 #ifdef NDTPSO_PROFILE_SETUP
@@ -543,6 +575,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
 
   EvalCtx E = make_eval_ctx(g, wn, L, dn);
   E.light = CLUSTER ? 0 : ps.light;
+  E.guard_lds = (unsigned)(uintptr_t)(const DenseGuard __attribute__((address_space(3)))*)&lds_ctrl(L.ctrl_off)->guard;
   if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg);
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
   if (L.swarm_global) {  // (two copies: see k_align)

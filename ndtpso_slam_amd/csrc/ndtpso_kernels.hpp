@@ -203,6 +203,9 @@ __device__ __forceinline__ void cell_coords_rt(const GridP& g, double qx, double
   if (g.cs_pow2) cell_coords<true>(g, qx, qy, ix, iy); else cell_coords<false>(g, qx, qy, ix, iy);
 }
 
+#ifndef NDTPSO_DIAG  // timing diagnostics of the dense score loop (score_trip_dense): extra work per 64-point chunk
+#define NDTPSO_DIAG 0
+#endif
 #ifndef NDTPSO_UNROLL
 #define NDTPSO_UNROLL 4
 #endif
@@ -347,7 +350,12 @@ __device__ __forceinline__ DenseItem dense_item(const GridP& g, const DenseP& dn
 
 // BYTE: the table entries are the records' LDS byte addresses themselves (possible when every record lies below
 // 64 KB: PATH 3, the fused pairs kernel) instead of addresses in 16-byte units -- one shift less per point.
-template <int U, bool DUMP, bool CLIP, bool BYTE = false>
+// NOCLAMP: the caller has established that no point of the list leaves the table under this pose (DenseGuard): the
+// two clamps go -- v_min_u32 costs 1.5 x a v_fma_f32 on this chip (scripts/ubench_valu.hip), the pair a tenth of the
+// loop's issue time -- and nothing else changes, so the result is the clamped form's bit for bit.
+// MASKLAST (with NOCLAMP, on the trip that holds the list's last chunk): the padding behind point n - 1 is sent to the
+// null entry by index -- the clamps are what used to catch the sentinel coordinates.
+template <int U, bool DUMP, bool CLIP, bool BYTE = false, bool NOCLAMP = false, bool MASKLAST = false>
 __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                  const double2* __restrict__ pts, int base, int n,
                                                  const DenseItem& it, double (&acc)[4], int32_t* __restrict__ dump) {
@@ -363,7 +371,8 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
     gy[u] = fma(p[u].x, it.S, fma(p[u].y, it.C, it.TY));
     // Out-of-window coordinates clamp into the always-null high column / row (negative ones convert to huge
     // unsigned values first; column / row 0 is the empty low border): no range test, no select.
-    const unsigned rx = min((unsigned)(int)gx[u], (unsigned)dn.dw), ry = min((unsigned)(int)gy[u], (unsigned)dn.dh);
+    const unsigned rx = NOCLAMP ? (unsigned)(int)gx[u] : min((unsigned)(int)gx[u], (unsigned)dn.dw),
+                   ry = NOCLAMP ? (unsigned)(int)gy[u] : min((unsigned)(int)gy[u], (unsigned)dn.dh);
 #if NDTPSO_MAD24_INDEX
     // one v_mad_u32_u24 (+ the shift of the table read below) instead of v_mul_u32_u24 + v_add_lshl_u32: on this chip
     // the 24-bit multiply alone costs as much as the multiply-add (scripts/ubench_valu.hip), the shift half of it
@@ -374,6 +383,8 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
     // A grid whose last cells overhang the frame (width/cs not an integer): points past the frame's upper
     // bound are rejected by NDTFrame::getCellIndex (ndtframe.cpp:242) although a cell exists there.
     if constexpr (CLIP) lin[u] = ((int)(gx[u] < it.XMAX) & (int)(gy[u] < it.YMAX)) ? lin[u] : 0u;  // cell 0: null
+    if constexpr (MASKLAST)
+      if (u == U - 1) lin[u] = (base + u * kWave + lane < n) ? lin[u] : 0u;
   }
   // the dense table starts at LDS address 0 and records are addressed absolutely: plain shifts, no base add
   typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
@@ -401,6 +412,24 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
     const float d0 = (float)(gx[u] - m[u].x), d1 = (float)(gy[u] - m[u].y);
     const float a = fmaf(f[u].x, d0, f[u].y * d1), b = f[u].z * d1;
     t[u] = __builtin_amdgcn_exp2f(-fmaf(a, a, fmaf(b, b, f[u].w)));  // null record: w = +inf -> 0
+#if NDTPSO_DIAG >= 1 && NDTPSO_DIAG <= 16  // timing diagnostics: that many extra independent v_fma_f32 per chunk
+    {
+      float dz = d0;
+#pragma unroll
+      for (int q = 0; q < NDTPSO_DIAG; ++q) asm volatile("v_fma_f32 %0, %1, %1, %1" : "=v"(dz) : "v"(d1));
+    }
+#elif NDTPSO_DIAG == 17  // one extra (independent) 16-byte LDS read per chunk
+    {
+      v4f_t dz;
+      asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(dz) : "v"((unsigned)(lane * 16)));
+    }
+#elif NDTPSO_DIAG == 18  // four extra fp64 FMAs per chunk
+    {
+      double dz;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("v_fma_f64 %0, %1, %1, %1" : "=v"(dz) : "v"(gx[u]));
+    }
+#endif
   }
   // the U terms (each in [0,1]) are summed in fp32 first, then folded into the fp64 lane accumulator
   if constexpr (U == 8) {  // two groups of four in flight together, folded in the order two U = 4 trips would be
@@ -448,13 +477,48 @@ __device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const D
   return -wave_sum(acc[0]);
 }
 // the same with the folded constants already at hand (the PSO keeps them with each proposal)
-template <bool WIDE, bool BYTE>
+template <bool WIDE, bool BYTE, bool NOCLAMP = false>
 __device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                        const double2* __restrict__ pts, int n, const DenseItem& it) {
   constexpr int U = NDTPSO_UNROLL;
   double acc[4] = {0., 0., 0., 0.};
   const int n_pad = round_up(n, kWave);
   int base = 0;
+  if constexpr (NOCLAMP) {
+    // the same trips in the same order as below (so the sum is the same, bit for bit), the one that holds the last
+    // chunk masking the list's padding
+    static_assert(U == 4 && !WIDE, "the no-clamp form follows the four-chunk sequence");
+    const int chunks = n_pad >> 6, rem = chunks & 3;
+    if (chunks == 0) return -wave_sum(acc[0]);  // (an empty list)
+    const bool five = rem == 1 && chunks >= 5;
+    const int fours = five ? (chunks - 5) >> 2 : (rem == 0 ? (chunks >> 2) - 1 : chunks >> 2);
+    if (dn.clip) {
+      for (int i = 0; i < fours; ++i, base += 4 * kWave)
+        score_trip_dense<4, false, true, BYTE, true, false>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+      if (five)
+        score_trip_dense<5, false, true, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+      else if (rem == 0)
+        score_trip_dense<4, false, true, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+      else {
+        for (; base + kWave < n_pad; base += kWave)
+          score_trip_dense<1, false, true, BYTE, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+        score_trip_dense<1, false, true, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+      }
+    } else {
+      for (int i = 0; i < fours; ++i, base += 4 * kWave)
+        score_trip_dense<4, false, false, BYTE, true, false>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+      if (five)
+        score_trip_dense<5, false, false, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+      else if (rem == 0)
+        score_trip_dense<4, false, false, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+      else {
+        for (; base + kWave < n_pad; base += kWave)
+          score_trip_dense<1, false, false, BYTE, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+        score_trip_dense<1, false, false, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+      }
+    }
+    return -wave_sum(acc[0]);
+  }
   // a remainder of exactly five chunks (1081 beams are 17) goes as one trip instead of a trip of four and a lonely one
   if (dn.clip) {
     if constexpr (WIDE && U == 4)
@@ -579,6 +643,23 @@ __device__ inline int scan_to_points_wg(const float* __restrict__ ranges, const 
     __syncthreads();
   }
   return base;
+}
+
+// Largest range among the beams loadLaser keeps (ndtframe.cpp:165), 0 if none: every point of the scan lies within it
+// of the sensor.  `slot`: an int of LDS scratch.  Uniform result; ends with a barrier.
+__device__ inline float scan_max_range_wg(const float* __restrict__ ranges, const ScanP& sp, int* slot) {
+  if (threadIdx.x == 0) *slot = 0;
+  __syncthreads();
+  float m = 0.f;
+  for (int i = threadIdx.x; i < sp.n_beams; i += blockDim.x) {
+    const float r = ranges[i];
+    if (((double)r > 0.) && (r < sp.rmax) && (r > sp.eps)) m = fmaxf(m, r);
+  }
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, kWave));
+  if (lane_id() == 0) atomicMax(slot, __float_as_int(m));  // (non-negative floats order as their bit patterns)
+  __syncthreads();
+  return __int_as_float(*slot);
 }
 
 // ---- K3b: points -> reference cell table (fresh frame) ------------------------------------------
@@ -1159,6 +1240,14 @@ struct ExactArgs {
   double* xgbc;
   int S;
 };
+// Dense form, fused pairs kernel: the folded translation (DenseItem::TX, TY) of a pose whose transform keeps EVERY point
+// of the list inside the cell table lies in [x_lo, x_hi) x [y_lo, y_hi) -- the points lie within `rho` of the sensor,
+// so whatever the heading their table coordinates lie within rho / cell_side of (TX, TY).  The kernel sizes the table
+// for that (k_align_pairs); a pose outside the box (or a table that could not be made that large: empty box) takes the
+// clamped loop.  In LDS: the evaluating waves read it next to the item's constants.
+struct __attribute__((aligned(16))) DenseGuard {
+  double x_lo, x_hi, y_lo, y_hi;
+};
 constexpr int kMaxNear = 16;  // undecidable comparisons one evaluation group may contain before the alignment is handed over
 struct PsoShared {  // small control block in LDS
   double gb[3];
@@ -1173,6 +1262,7 @@ struct PsoShared {  // small control block in LDS
   unsigned short near_list[3][kMaxNear];
   double xgbc;  // fp64 score of the gbest position (arbitration scratch)
   double gcs[2];  // cos, sin of the gbest position's heading
+  DenseGuard guard;  // (fused pairs kernel, dense form)
   ExactArgs xa;
 };
 
@@ -1185,6 +1275,7 @@ struct EvalCtx {
   DenseP dn;
   const unsigned char* lds0;
   int light;  // PsoP::light (the item -> wave deal of eval_items)
+  unsigned guard_lds;  // LDS byte address of the DenseGuard, 0: none
 };
 
 // ---- fp32 score mode, underflow regime ----------------------------------------------------------------
@@ -1437,7 +1528,22 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
     double cost;
     if constexpr (path_is_dense(PATH)) {
       const DenseItem it{c, s, sw.ttx[j], sw.tty[j], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
-      cost = eval_item_wave_dense<false, PATH == 3>(E.g, E.dn, E.lds0, pts, n, it);
+      if constexpr (PATH == 3) {
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+        const v2d_t gx = *(lds_d2_t)(uintptr_t)E.guard_lds, gy = *(lds_d2_t)(uintptr_t)(E.guard_lds + 16u);  // DenseGuard
+        // (NaN translations fail the tests and take the clamped loop)
+#ifdef NDTPSO_FORCE_NOCLAMP  // diagnostic builds: the guard's upper bound (wrong results when a point does leave the table)
+        if (gx.x == gx.x)
+#else
+        if (it.TX >= gx.x && it.TX < gx.y && it.TY >= gy.x && it.TY < gy.y)
+#endif
+          cost = eval_item_wave_dense<false, true, true>(E.g, E.dn, E.lds0, pts, n, it);
+        else
+          cost = eval_item_wave_dense<false, true>(E.g, E.dn, E.lds0, pts, n, it);
+      } else {
+        cost = eval_item_wave_dense<false, PATH == 3>(E.g, E.dn, E.lds0, pts, n, it);
+      }
     } else {
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
