@@ -262,6 +262,39 @@ def test_dense_window_overflow_falls_back_to_bitmap_form(ctx, oracle, pairs8):
     assert np.abs(cost - wcost).max() < 1e-3
 
 
+def test_no_clamp_loop_edges(ctx, oracle, pairs8):
+    """The fused pairs kernel sizes its cell table for scan B under any heading and lets poses inside the guard box run
+    the score loop without clamps (DenseGuard).  Edges: a point list that is a whole number of 64-point chunks (no
+    padding to catch) and one point short of it; a guess next to the frame's border (the box is clipped: the guard is
+    empty, every pose takes the clamped loop); a guess whose heading turns the scan around; particles thrown far outside
+    the box by a huge deviation (clamped loop for those, the other loop for the rest -- the same sums either way)."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    geom = _geom(p, capi)
+    P, I = 24, 12
+    cfg, ocfg = capi.PSOConfig.make(I, P), oracle.PSOConfig.make(I, P)
+    ref, new = p.ref_ranges[:4].copy(), p.new_ranges[:4].copy()
+    # exactly 640 and 639 surviving beams in scans 0 and 1 (drop from the far end of the sweep)
+    for b, keep in ((0, 640), (1, 639)):
+        ok = np.flatnonzero((new[b] > 0.1) & (new[b] < p.range_max))
+        new[b, ok[keep:]] = 0.0
+        assert ((new[b] > 0.1) & (new[b] < p.range_max)).sum() == keep
+    cases = [((0, 0, 0), DEVIATION), ((27.5, -27.0, 0.3), DEVIATION), ((0.2, -0.1, 3.0), DEVIATION),
+             ((0, 0, 0), (6.0, 6.0, 0.5))]
+    for guess, dev in cases:
+        want, wcost, _ = oracle.align_pairs(ref, new, p.angle_min, p.angle_inc, p.range_max, 0.1, FRAME_M, FRAME_M, CELL_SIDE,
+                                            guess, dev, ocfg, p.seeds[:4])
+        res = {}
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
+            got, cost, stats = ctx.align_pairs(ref, new, geom, _grid(capi), guess, dev, cfg, seeds=p.seeds[:4], mode=mode)
+            assert (stats["status"] == 0).all(), (guess, dev, mode, stats["status"])
+            res[mode] = (got, cost)
+            assert np.abs(got - want).max() < (1e-9 if mode != capi.SCORE_F32 else 1e-3), (guess, dev, mode, np.abs(got - want).max())
+        assert np.array_equal(res[capi.SCORE_EXACT][0], res[capi.SCORE_F64][0])
+        assert np.array_equal(res[capi.SCORE_EXACT][1], res[capi.SCORE_F64][1])
+        assert np.abs(res[capi.SCORE_F64][1] - wcost).max() < 1e-8
+
+
 def test_randomised_configurations(ctx, oracle):
     """40 random configurations (frame 20..120 m, cell side 0.2..1.5 m incl. non power-of-two, 3..90 particles,
     0..25 iterations, 90..1500 beams, off-centre guesses, random deviations, dropped beams) against the oracle:
