@@ -26,7 +26,7 @@ constexpr int kCtrlBytes = 864;      // control block (PsoShared + compaction co
 // LDS layout shared by every kernel.
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
 //                header..chol are contiguous exactly as in the HBM image
-//   dense form : [u16 cell table @0 | ctrl | DenseRec[cap+1] | header | points | region]
+//   dense form : [u16 cell table @0 | ctrl | dense records (cap+1, blocks of 16 means + 16 factors) | header | points | region]
 //   region = max(table-build scratch {key, cellkey, cnt, bm2, plist, (bm)}, swarm)
 struct Layout {
   int ctrl_off, hdr_off, bm_off, mean_off, ab_off, cd_off, chol_off, drec_off, pts_off, region_off, total;
@@ -47,7 +47,7 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
   L.drec_off = -1;
   if (dense) {
     L.drec_off = off;
-    off += 32 * (rec_cap + 1);
+    off += dense_rec_bytes(rec_cap + 1);
   }
   L.hdr_off = off;
   off += kImageHeaderBytes;
@@ -172,7 +172,6 @@ __device__ __forceinline__ void enable_arbitration(PsoShared* sh, const GridP& g
     a.ox = dn.ox;
     a.oy = dn.oy;
     a.null_entry = BYTE ? (unsigned)dn.rec_off : (unsigned)dn.rec_off >> 4;
-    a.rec0 = BYTE ? (unsigned)dn.rec_off + 32u : ((unsigned)dn.rec_off >> 4) + 2u;  // dense_put: record slot + 1
     const TableView T = image_table_view(wn, image);
     a.xmean = T.mean;
     a.xab = T.ab;
@@ -1707,7 +1706,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     const char* e = std::getenv("NDTPSO_BYTE_ENTRIES");
     return !(e && e[0] == '0');
   }();
-  const bool byte_entries = plan.path == 2 && allow_byte_entries && plan.dn.rec_off + 32 * (wn.rec_cap + 1) <= 65536;
+  const bool byte_entries = plan.path == 2 && allow_byte_entries && plan.dn.rec_off + dense_rec_bytes(wn.rec_cap + 1) <= 65536;
   if (d_ximg) {  // exact mode on the dense form
     if (byte_entries) LAUNCH_PAIRS_X(3); else LAUNCH_PAIRS_X(2);
   } else if (mode == NDTPSO_SCORE_F32) {

@@ -85,15 +85,25 @@ struct TableOut {  // same arrays, writable (table build); null = not wanted
 // staging window (plus one empty border row/column on the low sides) holding the LDS address / 16 of the
 // cell's 32-byte record; cells that are not built point at a null record whose exponent is -inf, so a miss
 // needs no mask, select or compare.  The table sits at LDS offset 0: entry address = cell index * 2.
-struct __attribute__((aligned(16))) DenseRec {
+struct __attribute__((aligned(16))) DenseMean {
   double mgx, mgy;        // NDTCell::mean in cell units, relative to the dense window origin
+};
+struct __attribute__((aligned(16))) DenseChol {
   float l11, l21, l22, w; // Cholesky factor of 0.5*log2(e)*s_inv_covar scaled to cell units; w: 0, or +inf for the null record
 };
-static_assert(sizeof(DenseRec) == 32, "dense record must be 32 bytes");
+static_assert(sizeof(DenseMean) == 16 && sizeof(DenseChol) == 16, "dense record halves must be 16 bytes");
+// Record k (0 = the null record, built cell slot s = record s + 1) lives in blocks of sixteen: sixteen means, then the
+// sixteen factors -- the factor kDenseCholOff bytes behind its mean (an immediate offset of the second ds_read_b128).
+// A 16-lane group of a ds_read_b128 conflicts when two different records sit at the same 16-byte position of a
+// 256-byte LDS row: with mean and factor side by side (32-byte records) there were 8 positions, this way there are 16.
+constexpr unsigned kDenseCholOff = 256;
+__host__ __device__ inline unsigned dense_rec_pos(unsigned k) { return ((k >> 4) << 9) + ((k & 15u) << 4); }
+__host__ __device__ inline unsigned dense_rec_index(unsigned pos) { return ((pos >> 9) << 4) + ((pos >> 4) & 15u); }
+__host__ __device__ inline int dense_rec_bytes(int n_records) { return 512 * ((n_records + 15) / 16); }
 struct DenseP {
   int dw, dh;    // dense window size in cells, = wn.w + 1, wn.h + 1
   int ox, oy;    // grid coordinates of dense cell (0,0), = wn.x0 - 1, wn.y0 - 1
-  int rec_off;   // LDS byte offset of DenseRec[rec_cap + 1] (record 0 = null), 16-byte aligned
+  int rec_off;   // LDS byte offset of the rec_cap + 1 records (dense_rec_pos; record 0 = null), 16-byte aligned
   int clip;      // 1: W*cs > width or H*cs > height -- the last cells overhang the frame, test the upper bounds
   double xmax, ymax;  // frame's upper bounds in window cell coordinates: width/cs - ox, height/cs - oy
 };
@@ -326,7 +336,7 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
 //
 // The window-relative cell coordinates come straight out of the transform:
 //   gx = x*C - y*S + TX,  C = cos/cs, S = sin/cs, TX = (tx + w/2)/cs - ox      (2 fp64 FMAs per axis)
-// and the Mahalanobis form is evaluated in cell units against DenseRec.  Per point: 4 FMA, 2 cvt, 2 cmp,
+// and the Mahalanobis form is evaluated in cell units against the dense records (DenseMean, DenseChol).  Per point: 4 FMA, 2 cvt, 2 cmp,
 // mul+add, select, 3 LDS reads, 2 sub, 2 cvt, 5 fp32, exp2, and per four points one cvt + add.
 // For a power-of-two cell side floor((x + w/2)/cs) = floor(fl(x + w/2) * 2^k) and the scaling commutes with
 // rounding; for any other cell side 1/cs is rounded once more.  Either way gx is within ~1e-14 cells of the
@@ -402,7 +412,7 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   for (int u = 0; u < U; ++u) {
     const unsigned r = BYTE ? e[u] : e[u] << 4;
     const v2d_t mm = *(lds_d2_t)(uintptr_t)r;
-    const v4f_t ff = *(lds_f4_t)(uintptr_t)(r + 16u);
+    const v4f_t ff = *(lds_f4_t)(uintptr_t)(r + kDenseCholOff);
     m[u] = make_double2(mm.x, mm.y);
     f[u] = make_float4(ff.x, ff.y, ff.z, ff.w);
   }
@@ -756,19 +766,15 @@ __device__ __forceinline__ unsigned bm_slot(const uint2* bm, int k) {
 
 // scratch: key[n], cellkey[n], cnt[n] ints (rounded up to 4), plist[n] u16 and bm2[n_words] uint2
 // hdr/out: where the table goes (LDS); out.ab/out.cd or out.chol may be null when a kernel needs one score form
-// dn/lds0 (optional): also emit the dense form (u16 table at lds0, DenseRec[] at lds0 + dn->rec_off)
+// dn/lds0 (optional): also emit the dense form (u16 table at lds0, the records at lds0 + dn->rec_off)
 __device__ inline void dense_clear_wg(const DenseP& dn, unsigned char* lds0, bool byte_entries = false) {
   const unsigned null16 = byte_entries ? (unsigned)dn.rec_off : (unsigned)dn.rec_off >> 4;
   uint32_t* t32 = reinterpret_cast<uint32_t*>(lds0);
   const int n32 = dense_tab_bytes(dn.dw, dn.dh) >> 2;
   for (int i = threadIdx.x; i < n32; i += blockDim.x) t32[i] = null16 | (null16 << 16);
   if (threadIdx.x == 0) {
-    DenseRec z;
-    z.mgx = 0.;
-    z.mgy = 0.;
-    z.l11 = z.l21 = z.l22 = 0.f;
-    z.w = __builtin_inff();
-    *reinterpret_cast<DenseRec*>(lds0 + dn.rec_off) = z;
+    *reinterpret_cast<DenseMean*>(lds0 + dn.rec_off) = DenseMean{0., 0.};
+    *reinterpret_cast<DenseChol*>(lds0 + dn.rec_off + kDenseCholOff) = DenseChol{0.f, 0.f, 0.f, __builtin_inff()};
   }
 }
 // one built cell -> dense record `slot + 1` and its table entry; (rx, ry) = cell inside the staging window
@@ -777,17 +783,11 @@ __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsi
                                           bool byte_entries = false) {
   float l[4];
   make_chol(ia, ib, ic, id, l, g.cs);  // Cholesky factor in cell units
-  DenseRec r;
-  r.mgx = (mx + g.hw) * g.inv_cs - (double)dn.ox;
-  r.mgy = (my + g.hh) * g.inv_cs - (double)dn.oy;
-  r.l11 = l[0];
-  r.l21 = l[1];
-  r.l22 = l[2];
-  r.w = l[3];  // 0, or NaN when the form has no Cholesky factor
-  reinterpret_cast<DenseRec*>(lds0 + dn.rec_off)[slot + 1] = r;
+  const unsigned at = (unsigned)dn.rec_off + dense_rec_pos(slot + 1);
+  *reinterpret_cast<DenseMean*>(lds0 + at) = DenseMean{(mx + g.hw) * g.inv_cs - (double)dn.ox, (my + g.hh) * g.inv_cs - (double)dn.oy};
+  *reinterpret_cast<DenseChol*>(lds0 + at + kDenseCholOff) = DenseChol{l[0], l[1], l[2], l[3]};  // w: 0, or NaN when the form has no Cholesky factor
   reinterpret_cast<unsigned short*>(lds0)[(ry + 1) * dense_stride(dn.dw) + (rx + 1)] =
-      byte_entries ? (unsigned short)((unsigned)dn.rec_off + 32u * (slot + 1))
-                   : (unsigned short)(((unsigned)dn.rec_off >> 4) + 2u * (slot + 1));
+      byte_entries ? (unsigned short)at : (unsigned short)(at >> 4);
 }
 
 __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const double2* pts, int n,
@@ -1223,7 +1223,7 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P, bool exact, bool
 struct ExactArgs {
   GridP g;
   int dw, dh, ox, oy;          // the dense cell table (DenseP): the cell lookup of the fp64 score goes through it too
-  unsigned null_entry, rec0;   // its null entry; entry of record slot 0 (entries step by 32 / 2 per slot: byte / 16-byte units)
+  unsigned null_entry;         // its null entry = record 0's (the record index of an entry: dense_rec_index)
   const double2* xmean;        // fp64 records by slot, in the table image in HBM: NDTCell::mean,
   const double2* xab;          //   s_inv_covar row 0,
   const double2* xcd;          //   s_inv_covar row 1
@@ -1308,8 +1308,10 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
       const bool ok = (rx < (unsigned)E.dn.dw) && (ry < (unsigned)E.dn.dh) && (!E.dn.clip || (gx < it.XMAX && gy < it.YMAX));
       const unsigned lin = ok ? ry * (unsigned)dense_stride(E.dn.dw) + rx : 0u;
       const unsigned e = reinterpret_cast<const unsigned short*>(E.lds0)[lin];
-      const DenseRec* r = reinterpret_cast<const DenseRec*>(E.lds0 + (PATH == 3 ? e : e << 4));
-      const double d0 = gx - r->mgx, d1 = gy - r->mgy;
+      const unsigned at = PATH == 3 ? e : e << 4;
+      const DenseMean* rm = reinterpret_cast<const DenseMean*>(E.lds0 + at);
+      const DenseChol* r = reinterpret_cast<const DenseChol*>(E.lds0 + at + kDenseCholOff);
+      const double d0 = gx - rm->mgx, d1 = gy - rm->mgy;
       const double a = (double)r->l11 * d0 + (double)r->l21 * d1, b = (double)r->l22 * d1;
       acc += exp2(-(a * a + b * b + (double)r->w));  // null record: w = +inf -> 0
     }
@@ -1396,7 +1398,7 @@ template <bool BYTE, bool POW2>
 __device__ __forceinline__ double eval_pose_wave_exact(const ExactArgs* ap, double c, double s, double tx, double ty) {
   const GridP g = ap->g;
   const int dw = ap->dw, dh = ap->dh, ox = ap->ox, oy = ap->oy;
-  const unsigned null_entry = ap->null_entry, rec0 = ap->rec0;
+  const unsigned null_entry = ap->null_entry;
   typedef double v2d_t __attribute__((ext_vector_type(2)));
   typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
   typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
@@ -1421,7 +1423,7 @@ __device__ __forceinline__ double eval_pose_wave_exact(const ExactArgs* ap, doub
     const unsigned lin = inwin ? ry * (unsigned)dense_stride(dw) + rx : 0u;  // entry 0: the empty low border, null
     const unsigned e = *(lds_u16_t)(uintptr_t)(lin << 1);
     const bool hit = e != null_entry;
-    const unsigned slot = hit ? (BYTE ? (e - rec0) >> 5 : (e - rec0) >> 1) : 0u;
+    const unsigned slot = hit ? dense_rec_index(BYTE ? e - null_entry : (e - null_entry) << 4) - 1u : 0u;
     // a miss adds exp(-inf) = +0. in the fp64 kernels, which leaves the accumulator as it was; slot 0 exists whenever
     // any cell is built, and a table without built cells has no hits
     const double2 m = xmean[slot], ab = xab[slot], cd = xcd[slot];
