@@ -1540,7 +1540,12 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
 #else
         if (it.TX >= gx.x && it.TX < gx.y && it.TY >= gy.x && it.TY < gy.y)
 #endif
+        {
+#ifdef NDTPSO_COUNT_NOCLAMP  // diagnostic builds: evaluations through the no-clamp loop, reported as `gbest_updates`
+          if (lane_id() == 0) atomicAdd(tiny + 1, 1);  // PsoShared::timed_out (unused by a single workgroup)
+#endif
           cost = eval_item_wave_dense<false, true, true>(E.g, E.dn, E.lds0, pts, n, it);
+        }
         else
           cost = eval_item_wave_dense<false, true>(E.g, E.dn, E.lds0, pts, n, it);
       } else {
@@ -2123,7 +2128,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       stats->rounds = arb_ticks;
 #endif
       stats->gbest_updates = n_gb;
-#ifdef NDTPSO_COUNT_AMBIG
+#if defined(NDTPSO_COUNT_AMBIG) || defined(NDTPSO_COUNT_NOCLAMP)
       if (!CLUSTER) stats->gbest_updates = (uint32_t)sh->timed_out;
 #endif
     }
