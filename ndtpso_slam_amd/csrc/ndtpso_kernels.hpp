@@ -365,10 +365,19 @@ __device__ __forceinline__ DenseItem dense_item(const GridP& g, const DenseP& dn
 // loop's issue time -- and nothing else changes, so the result is the clamped form's bit for bit.
 // MASKLAST (with NOCLAMP, on the trip that holds the list's last chunk): the padding behind point n - 1 is sent to the
 // null entry by index -- the clamps are what used to catch the sentinel coordinates.
-template <int U, bool DUMP, bool CLIP, bool BYTE = false, bool NOCLAMP = false, bool MASKLAST = false>
+// FOLD: how the trip's terms enter the lane accumulator.  The sum's order is the list's: groups of four chunks, each
+// folded as (t0 + t1) + (t2 + t3) in fp32 and added in fp64, then the chunks left over one by one -- whatever trips
+// the chunks are scored in.  kFoldByU: U = 4 / 8 whole groups, 5 a group and one left-over chunk, 1 a left-over chunk;
+// kFoldSingles: left-over chunks only; kFoldGroupSingles: a group and U - 4 left-over chunks; kFoldGroupCarry: a group,
+// then the first half of the next group goes out in `carry`; kFoldCarryGroup: `carry` + this trip's first two chunks
+// complete that group, a whole group follows.  (Six-chunk trips: three dependent LDS round trips per trip is what a
+// wave waits for, so 17 chunks go as 6 + 6 + 5 instead of 4 + 4 + 4 + 5: + 4.8 % on the batch.)
+enum { kFoldByU = 0, kFoldSingles, kFoldGroupSingles, kFoldGroupCarry, kFoldCarryGroup };
+template <int U, bool DUMP, bool CLIP, bool BYTE = false, bool NOCLAMP = false, bool MASKLAST = false, int FOLD = kFoldByU>
 __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                  const double2* __restrict__ pts, int base, int n,
-                                                 const DenseItem& it, double (&acc)[4], int32_t* __restrict__ dump) {
+                                                 const DenseItem& it, double (&acc)[4], int32_t* __restrict__ dump,
+                                                 float* carry = nullptr) {
   const int lane = lane_id();
   double2 p[U];
 #pragma unroll
@@ -442,7 +451,22 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
 #endif
   }
   // the U terms (each in [0,1]) are summed in fp32 first, then folded into the fp64 lane accumulator
-  if constexpr (U == 8) {  // two groups of four in flight together, folded in the order two U = 4 trips would be
+  if constexpr (FOLD == kFoldSingles) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[0] += (double)t[u];
+  } else if constexpr (FOLD == kFoldGroupSingles) {
+    acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));
+#pragma unroll
+    for (int u = 4; u < U; ++u) acc[0] += (double)t[u];
+  } else if constexpr (FOLD == kFoldGroupCarry) {
+    static_assert(U == 6, "a group and half a group");
+    acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));
+    *carry = t[4] + t[5];
+  } else if constexpr (FOLD == kFoldCarryGroup) {
+    static_assert(U == 6, "half a group and a group");
+    acc[0] += (double)(*carry + (t[0] + t[1]));
+    acc[0] += (double)((t[2] + t[3]) + (t[4] + t[5]));
+  } else if constexpr (U == 8) {  // two groups of four in flight together, folded in the order two U = 4 trips would be
     acc[0] += (double)((t[0] + t[1]) + (t[2] + t[3]));
     acc[0] += (double)((t[4] + t[5]) + (t[6] + t[7]));
   } else if constexpr (U == 5) {  // the last group of four and the one chunk behind it in one trip, folded as they
@@ -486,6 +510,44 @@ __device__ __forceinline__ double eval_pose_wave_dense_c(const GridP& g, const D
   for (; base < n_pad; base += kWave) score_trip_dense<1, DUMP, CLIP, BYTE>(g, dn, lds0, pts, base, n, it, acc, dump);
   return -wave_sum(acc[0]);
 }
+// The no-clamp loop's trips (DenseGuard).  The sum is the clamped sequence's bit for bit (score_trip_dense's FOLD);
+// the trip that holds the list's last chunk masks its padding.  A 1081-beam scan is 17 chunks: those go as two
+// six-chunk trips and a five-chunk one, straight-line code (three dependent LDS round trips per trip is what a wave
+// waits for: + 4 %); every other length in four-chunk trips as before.  This kernel's register allocation is decided
+// by everything inlined into it: the same three trips behind a general decomposition into six-, five- and four-chunk
+// trips for any length lost the whole gain (219 k against 230 k align/s), a second straight-line case for 16 chunks
+// cost 2 %, the same trips in the frame-clipping variant as well another 2 % (so a grid whose last cells overhang
+// the frame keeps the four-chunk trips), and moving the clamped and clipping forms into an out-of-line function cost
+// more than all of it (215 k: what is live across the call gets pinned).
+template <bool CLIP, bool BYTE>
+__device__ __forceinline__ void noclamp_trips(const GridP& g, const DenseP& dn, const unsigned char* lds0,
+                                              const double2* __restrict__ pts, int n, int n_pad, const DenseItem& it,
+                                              double (&acc)[4]) {
+  const int chunks = n_pad >> 6, rem = chunks & 3;
+  if (chunks == 0) return;  // (an empty list)
+  int base = 0;
+  if (!CLIP && chunks == 17) {
+    float carry;
+    score_trip_dense<6, false, CLIP, BYTE, true, false, kFoldGroupCarry>(g, dn, lds0, pts, 0, n, it, acc, nullptr, &carry);
+    score_trip_dense<6, false, CLIP, BYTE, true, false, kFoldCarryGroup>(g, dn, lds0, pts, 6 * kWave, n, it, acc, nullptr, &carry);
+    score_trip_dense<5, false, CLIP, BYTE, true, true>(g, dn, lds0, pts, 12 * kWave, n, it, acc, nullptr);
+    return;
+  }
+  const bool five = rem == 1 && chunks >= 5;
+  const int fours = five ? (chunks - 5) >> 2 : (rem == 0 ? (chunks >> 2) - 1 : chunks >> 2);
+  for (int i = 0; i < fours; ++i, base += 4 * kWave)
+    score_trip_dense<4, false, CLIP, BYTE, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+  if (five)
+    score_trip_dense<5, false, CLIP, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+  else if (rem == 0)
+    score_trip_dense<4, false, CLIP, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+  else {
+    for (; base + kWave < n_pad; base += kWave)
+      score_trip_dense<1, false, CLIP, BYTE, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+    score_trip_dense<1, false, CLIP, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
+  }
+}
+
 // the same with the folded constants already at hand (the PSO keeps them with each proposal)
 template <bool WIDE, bool BYTE, bool NOCLAMP = false>
 __device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
@@ -495,38 +557,11 @@ __device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const Den
   const int n_pad = round_up(n, kWave);
   int base = 0;
   if constexpr (NOCLAMP) {
-    // the same trips in the same order as below (so the sum is the same, bit for bit), the one that holds the last
-    // chunk masking the list's padding
-    static_assert(U == 4 && !WIDE, "the no-clamp form follows the four-chunk sequence");
-    const int chunks = n_pad >> 6, rem = chunks & 3;
-    if (chunks == 0) return -wave_sum(acc[0]);  // (an empty list)
-    const bool five = rem == 1 && chunks >= 5;
-    const int fours = five ? (chunks - 5) >> 2 : (rem == 0 ? (chunks >> 2) - 1 : chunks >> 2);
-    if (dn.clip) {
-      for (int i = 0; i < fours; ++i, base += 4 * kWave)
-        score_trip_dense<4, false, true, BYTE, true, false>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-      if (five)
-        score_trip_dense<5, false, true, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-      else if (rem == 0)
-        score_trip_dense<4, false, true, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-      else {
-        for (; base + kWave < n_pad; base += kWave)
-          score_trip_dense<1, false, true, BYTE, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-        score_trip_dense<1, false, true, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-      }
-    } else {
-      for (int i = 0; i < fours; ++i, base += 4 * kWave)
-        score_trip_dense<4, false, false, BYTE, true, false>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-      if (five)
-        score_trip_dense<5, false, false, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-      else if (rem == 0)
-        score_trip_dense<4, false, false, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-      else {
-        for (; base + kWave < n_pad; base += kWave)
-          score_trip_dense<1, false, false, BYTE, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-        score_trip_dense<1, false, false, BYTE, true, true>(g, dn, lds0, pts, base, n, it, acc, nullptr);
-      }
-    }
+    static_assert(U == 4 && !WIDE, "the no-clamp form is the one-workgroup kernels'");
+    if (dn.clip)
+      noclamp_trips<true, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
+    else
+      noclamp_trips<false, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
     return -wave_sum(acc[0]);
   }
   // a remainder of exactly five chunks (1081 beams are 17) goes as one trip instead of a trip of four and a lonely one
