@@ -21,6 +21,9 @@ Floor: a SIMD issues one VALU instruction at a time, so the loop cannot run fast
 whatever the LDS and the other waves do.  bench.py multiplies by the chunks a launch scores and divides by the 1024
 SIMDs: that is `roofline.peak` (as a rate) -- it ignores everything outside the loop (pose constants, the five-chunk
 tail trip, reductions, the PSO itself), so it is a true lower bound of the kernel time.
+(Since the no-clamp form of round 2 a 17-chunk list -- 1081 beams -- is scored in straight-line trips of 6 + 6 + 5 chunks
+with the same per-chunk instruction mix; the loop found here is that form's four-chunk loop, which every other list
+length runs.)
 """
 from __future__ import annotations
 
