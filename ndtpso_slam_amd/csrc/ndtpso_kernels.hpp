@@ -549,7 +549,9 @@ __device__ __forceinline__ void noclamp_trips(const GridP& g, const DenseP& dn, 
 }
 
 // the same with the folded constants already at hand (the PSO keeps them with each proposal)
-template <bool WIDE, bool BYTE, bool NOCLAMP = false>
+// NOCLIP: the kernel was chosen by the host for a grid whose cells do not overhang the frame (DenseP::clip == 0), and
+// carries none of the clipping variants of the trips.
+template <bool WIDE, bool BYTE, bool NOCLAMP = false, bool NOCLIP = false>
 __device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const DenseP& dn, const unsigned char* lds0,
                                                        const double2* __restrict__ pts, int n, const DenseItem& it) {
   constexpr int U = NDTPSO_UNROLL;
@@ -558,14 +560,16 @@ __device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const Den
   int base = 0;
   if constexpr (NOCLAMP) {
     static_assert(U == 4 && !WIDE, "the no-clamp form is the one-workgroup kernels'");
-    if (dn.clip)
+    if constexpr (NOCLIP)
+      noclamp_trips<false, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
+    else if (dn.clip)
       noclamp_trips<true, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
     else
       noclamp_trips<false, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
     return -wave_sum(acc[0]);
   }
   // a remainder of exactly five chunks (1081 beams are 17) goes as one trip instead of a trip of four and a lonely one
-  if (dn.clip) {
+  if (!NOCLIP && dn.clip) {
     if constexpr (WIDE && U == 4)
       for (; base + 8 * kWave <= n_pad; base += 8 * kWave)
         score_trip_dense<8, false, true, BYTE>(g, dn, lds0, pts, base, n, it, acc, nullptr);
@@ -1548,7 +1552,7 @@ __device__ __forceinline__ void exact_tasks_wg(const ExactArgs* ap, const unsign
 
 // One wave per item.  `improver` (optional): the evaluating wave itself records the lowest item index whose
 // cost beats `gbc` (core.cpp:97 under single-thread order), so no separate detection pass is needed.
-template <int MODE, int PATH, bool ARB = false>
+template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false>
 __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first,
                                   int last /*exclusive*/, double gbc, int* improver, int* tiny, int* near_cnt,
                                   unsigned short* near_list) {
@@ -1579,10 +1583,10 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
 #ifdef NDTPSO_COUNT_NOCLAMP  // diagnostic builds: evaluations through the no-clamp loop, reported as `gbest_updates`
           if (lane_id() == 0) atomicAdd(tiny + 1, 1);  // PsoShared::timed_out (unused by a single workgroup)
 #endif
-          cost = eval_item_wave_dense<false, true, true>(E.g, E.dn, E.lds0, pts, n, it);
+          cost = eval_item_wave_dense<false, true, true, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
         }
         else
-          cost = eval_item_wave_dense<false, true>(E.g, E.dn, E.lds0, pts, n, it);
+          cost = eval_item_wave_dense<false, true, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
       } else {
         cost = eval_item_wave_dense<false, PATH == 3>(E.g, E.dn, E.lds0, pts, n, it);
       }
@@ -1662,14 +1666,14 @@ constexpr unsigned long long kClusterWaitTicks = 2000000ull;  // 20 ms of the 10
 
 // Evaluates items [first, last) of the swarm; on return (after the caller's barrier) sw.tcost holds their costs and
 // *improver / *tiny are set as eval_items sets them.  `epoch` counts the cluster's exchanges.
-template <int MODE, int PATH, bool CLUSTER, bool ARB = false>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false>
 __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first, int last,
                                   double gbc, int* improver, int* tiny, const ClusterP& cl, unsigned& epoch,
                                   int* timed_out, int* near_cnt, unsigned short* near_list,
                                   RngState* gen_st = nullptr, int* gen_t = nullptr, int32_t* gen_dst = nullptr,
                                   int gen_cnt = 0, int gen_wave = -1) {
   if constexpr (!CLUSTER) {
-    eval_items<MODE, PATH, ARB>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
+    eval_items<MODE, PATH, ARB, NOCLIP>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
   } else {
     NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
@@ -1727,7 +1731,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
 // ARB: the exact mode (NDTPSO_SCORE_EXACT) of the fp32-score dense kernels.  A template parameter, not a run-time
 // switch: the arbitration code in the same kernel cost the plain fp32 mode 11 % (register pressure: spills in the
 // proposal / commit paths), see DESIGN.md.
-template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false>
+template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false>
 __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
@@ -1805,7 +1809,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     }
   }
   __syncthreads();
-  eval_round<MODE, PATH, CLUSTER, ARB>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
+  eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
                                   nullptr);
   n_evals += S;
   n_rounds += 1;
@@ -2009,7 +2013,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       const int hi_g = min(lo + ps.G, P);
       // a cluster draws the next iteration's numbers behind the first exchange of this one (eval_round)
       const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
-      eval_round<MODE, PATH, CLUSTER, ARB>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
+      eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
                                       &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
                                       dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
       if (gen_here) next_filled = n_draw;

@@ -10,7 +10,9 @@ import os
 # dense form with byte-address entries (what config 3 runs): the arbitrating kernel of the exact mode, the plain fp32-score
 # kernel, or the general dense form -- whichever the profiled run launched
 names = {r["Kernel_Name"] for r in csv.DictReader(open(f"{src}/p1/p_counter_collection.csv"))}
-KERNEL = next((k for k in ("k_align_pairs<0, 3, false, true>", "k_align_pairs<0, 3, false, false>", "k_align_pairs<0, 3, false>",
+KERNEL = next((k for k in ("k_align_pairs<0, 3, false, true, true>", "k_align_pairs<0, 3, false, false, true>",
+                           "k_align_pairs<0, 3, false, true, false>", "k_align_pairs<0, 3, false, false, false>",
+                           "k_align_pairs<0, 3, false, true>", "k_align_pairs<0, 3, false, false>", "k_align_pairs<0, 3, false>",
                            "k_align_pairs<0, 2, false") if any(k in n for n in names)), "k_align_pairs")
 vals = collections.defaultdict(list)
 disp = {}
