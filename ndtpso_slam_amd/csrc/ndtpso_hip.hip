@@ -979,6 +979,8 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, true, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, false, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, false, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, false, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, true, true>);
@@ -1697,13 +1699,13 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
                      d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
                      cl, dirs, d_ximg, ximg_stride)
-// the byte-entry kernel on one workgroup per alignment comes in a variant without the frame-clipping trips, for grids
+// the dense-form kernels on one workgroup per alignment come in a variant without the frame-clipping trips, for grids
 // whose cells do not overhang the frame (DenseP::clip == 0: the usual case) -- less code inlined, better registers:
 // + 3 % in both the fp32 and the exact mode.  (Dropping the copy of the PSO that keeps its swarm in HBM as well took the
 // fp32 kernel to 0 spills and + 0.5 %, the exact one from 61 to 36 spills and - 2 %: left in.)
 #define LAUNCH_PAIRS_CA(MODE, PATH, CL, ARB)                                              \
   do {                                                                                    \
-    if (PATH == 3 && !CL && !plan.dn.clip) LAUNCH_PAIRS_CAN(MODE, PATH, CL, ARB, (PATH == 3 && !CL)); \
+    if ((PATH == 3 || PATH == 2) && !CL && !plan.dn.clip) LAUNCH_PAIRS_CAN(MODE, PATH, CL, ARB, ((PATH == 3 || PATH == 2) && !CL)); \
     else LAUNCH_PAIRS_CAN(MODE, PATH, CL, ARB, false);                                    \
   } while (0)
 #define LAUNCH_PAIRS_C(MODE, PATH, CL) LAUNCH_PAIRS_CA(MODE, PATH, CL, false)

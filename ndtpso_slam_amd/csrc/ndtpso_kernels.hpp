@@ -568,6 +568,20 @@ __device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const Den
       noclamp_trips<false, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
     return -wave_sum(acc[0]);
   }
+  // a 2048-beam list (BASELINE config 5; 32 chunks, entries in 16-byte units) in six-chunk trips, as the no-clamp loop
+  // scores 17 chunks (noclamp_trips): 6 + 6 + 6 + 6 + 4 + 4, straight-line, folded in the four-chunk order
+  if constexpr (!BYTE && NOCLIP && U == 4 && !WIDE) {
+    if (n_pad == 32 * kWave) {
+      float carry;
+      score_trip_dense<6, false, false, BYTE, false, false, kFoldGroupCarry>(g, dn, lds0, pts, 0, n, it, acc, nullptr, &carry);
+      score_trip_dense<6, false, false, BYTE, false, false, kFoldCarryGroup>(g, dn, lds0, pts, 6 * kWave, n, it, acc, nullptr, &carry);
+      score_trip_dense<6, false, false, BYTE, false, false, kFoldGroupCarry>(g, dn, lds0, pts, 12 * kWave, n, it, acc, nullptr, &carry);
+      score_trip_dense<6, false, false, BYTE, false, false, kFoldCarryGroup>(g, dn, lds0, pts, 18 * kWave, n, it, acc, nullptr, &carry);
+      score_trip_dense<4, false, false, BYTE>(g, dn, lds0, pts, 24 * kWave, n, it, acc, nullptr);
+      score_trip_dense<4, false, false, BYTE>(g, dn, lds0, pts, 28 * kWave, n, it, acc, nullptr);
+      return -wave_sum(acc[0]);
+    }
+  }
   // a remainder of exactly five chunks (1081 beams are 17) goes as one trip instead of a trip of four and a lonely one
   if (!NOCLIP && dn.clip) {
     if constexpr (WIDE && U == 4)
@@ -1588,7 +1602,7 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
         else
           cost = eval_item_wave_dense<false, true, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
       } else {
-        cost = eval_item_wave_dense<false, PATH == 3>(E.g, E.dn, E.lds0, pts, n, it);
+        cost = eval_item_wave_dense<false, PATH == 3, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
       }
     } else {
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
