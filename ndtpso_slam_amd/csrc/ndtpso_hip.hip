@@ -504,7 +504,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   DenseGuard guard{1., 0., 1., 0.};  // (empty: every pose takes the clamped loop)
   if constexpr (path_is_dense(PATH)) {
     wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
-    if constexpr (PATH == 3 && !CLUSTER) {
+    if constexpr (!CLUSTER) {
       // Room in the table for scan B under any heading: all its points lie within rho of the sensor, so around the
       // guess -- plus a margin for the translations the particles try -- a box of rho / cell_side cells either way
       // holds every table coordinate the score loop can produce, and the loop may drop its clamps (DenseGuard).  The

@@ -526,6 +526,18 @@ __device__ __forceinline__ void noclamp_trips(const GridP& g, const DenseP& dn, 
   const int chunks = n_pad >> 6, rem = chunks & 3;
   if (chunks == 0) return;  // (an empty list)
   int base = 0;
+  if constexpr (!CLIP && !BYTE) {
+    if (chunks == 32) {  // 2048 beams (BASELINE config 5), as eval_item_wave_dense's clamped sequence
+      float carry;
+      score_trip_dense<6, false, CLIP, BYTE, true, false, kFoldGroupCarry>(g, dn, lds0, pts, 0, n, it, acc, nullptr, &carry);
+      score_trip_dense<6, false, CLIP, BYTE, true, false, kFoldCarryGroup>(g, dn, lds0, pts, 6 * kWave, n, it, acc, nullptr, &carry);
+      score_trip_dense<6, false, CLIP, BYTE, true, false, kFoldGroupCarry>(g, dn, lds0, pts, 12 * kWave, n, it, acc, nullptr, &carry);
+      score_trip_dense<6, false, CLIP, BYTE, true, false, kFoldCarryGroup>(g, dn, lds0, pts, 18 * kWave, n, it, acc, nullptr, &carry);
+      score_trip_dense<4, false, CLIP, BYTE, true>(g, dn, lds0, pts, 24 * kWave, n, it, acc, nullptr);
+      score_trip_dense<4, false, CLIP, BYTE, true, true>(g, dn, lds0, pts, 28 * kWave, n, it, acc, nullptr);
+      return;
+    }
+  }
   if (!CLIP && chunks == 17) {
     float carry;
     score_trip_dense<6, false, CLIP, BYTE, true, false, kFoldGroupCarry>(g, dn, lds0, pts, 0, n, it, acc, nullptr, &carry);
@@ -1583,7 +1595,7 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
     double cost;
     if constexpr (path_is_dense(PATH)) {
       const DenseItem it{c, s, sw.ttx[j], sw.tty[j], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
-      if constexpr (PATH == 3) {
+      if constexpr (PATH == 3 || (PATH == 2 && NOCLIP)) {  // (the fused pairs kernels: they set up the guard)
         typedef double v2d_t __attribute__((ext_vector_type(2)));
         typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
         const v2d_t gx = *(lds_d2_t)(uintptr_t)E.guard_lds, gy = *(lds_d2_t)(uintptr_t)(E.guard_lds + 16u);  // DenseGuard
@@ -1597,10 +1609,10 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
 #ifdef NDTPSO_COUNT_NOCLAMP  // diagnostic builds: evaluations through the no-clamp loop, reported as `gbest_updates`
           if (lane_id() == 0) atomicAdd(tiny + 1, 1);  // PsoShared::timed_out (unused by a single workgroup)
 #endif
-          cost = eval_item_wave_dense<false, true, true, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
+          cost = eval_item_wave_dense<false, PATH == 3, true, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
         }
         else
-          cost = eval_item_wave_dense<false, true, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
+          cost = eval_item_wave_dense<false, PATH == 3, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
       } else {
         cost = eval_item_wave_dense<false, PATH == 3, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
       }
