@@ -1600,11 +1600,7 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
         typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
         const v2d_t gx = *(lds_d2_t)(uintptr_t)E.guard_lds, gy = *(lds_d2_t)(uintptr_t)(E.guard_lds + 16u);  // DenseGuard
         // (NaN translations fail the tests and take the clamped loop)
-#ifdef NDTPSO_FORCE_NOCLAMP  // diagnostic builds: the guard's upper bound (wrong results when a point does leave the table)
-        if (gx.x == gx.x)
-#else
         if (it.TX >= gx.x && it.TX < gx.y && it.TY >= gy.x && it.TY < gy.y)
-#endif
         {
 #ifdef NDTPSO_COUNT_NOCLAMP  // diagnostic builds: evaluations through the no-clamp loop, reported as `gbest_updates`
           if (lane_id() == 0) atomicAdd(tiny + 1, 1);  // PsoShared::timed_out (unused by a single workgroup)
