@@ -227,6 +227,33 @@ def main():
             if m != mode:
                 modes[name] = timed(B, m, steps, geom, grid, cfg, d_ref, d_new, d_seeds)
         out["extra"]["modes"] = modes
+        # Two batches in flight: the same launches issued alternately through two contexts on two streams (each with its
+        # own outputs and workspaces).  A launch lasts as long as its slowest workgroup -- 7 % after the median one --
+        # and on one stream the next launch waits for it; on two streams the next batch's workgroups fill the compute
+        # units the tail leaves idle.  What a caller with a queue of batches gets; not the headline (one batch per step).
+        try:
+            ctx2 = capi.Context(local_rank)
+            stream2 = torch.cuda.Stream(dev)
+            ctx2.set_stream(stream2.cuda_stream)
+            d_pose2, d_cost2, d_stats2 = torch.zeros_like(d_pose), torch.zeros_like(d_cost), torch.zeros_like(d_stats)
+            lanes = ((ctx, d_pose, d_cost, d_stats), (ctx2, d_pose2, d_cost2, d_stats2))
+
+            def both(steps):
+                for k in range(steps):
+                    c, po, co, st = lanes[k & 1]
+                    c.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(), cfg,
+                                      d_seeds.data_ptr(), 0, mode, po.data_ptr(), co.data_ptr(), st.data_ptr())
+                torch.cuda.synchronize()
+            both(8)
+            t1 = time.perf_counter()
+            both(150)
+            dt = time.perf_counter() - t1
+            same = bool(torch.equal(d_pose, d_pose2))
+            out["extra"]["two_batches_in_flight"] = {"alignments_per_s": B * 150 / dt, "ms_per_step": 1e3 * dt / 150, "steps": 150,
+                                                     "pairs": B, "score": args.score, "poses_equal_between_the_two": same}
+            del ctx2
+        except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench run fails
+            out["extra"]["two_batches_in_flight"] = {"error": str(e)}
         try:
             B5 = min(256, B)
             p5 = synth.make_pairs(B5, n_beams=2048, seed=21)
