@@ -370,7 +370,9 @@ def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs):
                           "algorithmic_bytes_per_launch": algo_bytes,
                           "note": "SURVEY 8(d)'s streaming-equivalent accounting: 40 B per point evaluation (16 B point + 24 B cell "
                                   "record); the kernel serves them from LDS, so this exceeds the HBM peak by construction -- HBM is "
-                                  "not the roof (traffic = measured HBM bytes per launch, 1.3 x the compulsory 8.7 KB per alignment)"}
+                                  "not the roof (traffic = measured HBM bytes per launch of the profiled mode: compulsory 8.7 KB per "
+                                  "alignment, x 1.3 in the plain fp32 kernel; the exact kernel adds its fp64 table image per workgroup "
+                                  "and the scratch traffic of its arbitration calls)"}
     return r
 
 
