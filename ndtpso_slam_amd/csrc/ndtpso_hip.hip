@@ -353,23 +353,13 @@ k_cells_build_windowed(CellWindow* __restrict__ cells, int n_cells, const uint32
       w.global_covar_sum[k] = (w.global_covar_sum[k] + cov[k]) - w.slot_covar[k];
       w.slot_covar[k] = cov[k];
     }
-    // s_calc_covar_inverse, ndtcell.cpp:93-111 (eigenvalues of the 2x2 in closed form)
+    // s_calc_covar_inverse, ndtcell.cpp:93-111 (eigenvalues as Eigen's EigenSolver computes them)
     const double nn = (double)w.global_count;
     const double v00 = w.global_covar_sum[0] / nn, v01 = w.global_covar_sum[1] / nn;
     const double v10 = w.global_covar_sum[2] / nn, v11 = w.global_covar_sum[3] / nn;
-    const double hp = 0.5 * (v00 - v11);
-    const double q = sqrt(hp * hp + v01 * v10);
-    const double mid = 0.5 * (v00 + v11);
-    const double e0 = mid + q, e1 = mid - q;
-    const double large_val = (e0 > e1) ? e0 : e1;
-    const double small_val = (e0 < e1) ? e0 : e1;
-    const double det = (small_val < .001 * large_val) ? .001 * large_val * large_val : v00 * v11 - v10 * v01;
     w.mean[0] = mx;
     w.mean[1] = my;
-    w.icov[0] = v11 / det;
-    w.icov[1] = -v01 / det;
-    w.icov[2] = -v10 / det;
-    w.icov[3] = v00 / det;
+    covar_inverse_eigen(v00, v01, v10, v11, w.icov);
     w.built = 1;
   }
   cells[c] = w;

@@ -169,6 +169,104 @@ __host__ __device__ inline void make_chol(double a, double b, double c, double d
   out[3] = ok ? 0.f : __builtin_nanf("");
 }
 
+// ---- NDTCell::s_calc_covar_inverse (ndtcell.cpp:93-111) -------------------
+// The eigenvalues come from EigenSolver<Matrix2d>(covar).pseudoEigenvalueMatrix().diagonal() in the reference
+// (ndtcell.cpp:96-97).  Restated here in the operation order of Eigen 3.3.7 for a 2x2 -- RealSchur::compute (scale by
+// the largest |coefficient|, the Hessenberg step is the identity), computeFromHessenberg / findSmallSubdiagEntry,
+// splitOffTwoRows (p, q, z, one Givens rotation applied on the left and on the right), unscale, EigenSolver::compute --
+// so that the larger eigenvalue, which becomes the determinant of a thin cell (.001 * large^2), carries Eigen's
+// roundings and not those of a closed form (a few ulp apart in 11 % of the cells of the synthetic world).  Same
+// function, line by line, as oracle/ndtpso_oracle.c:orc_eigen_eigenvalues_2x2 (variant 0).  fp64 division and sqrt
+// are correctly rounded on the device and the library is built with -ffp-contract=off.
+__device__ __forceinline__ void eigen_givens(double p, double q, double& c, double& s) {  // JacobiRotation::makeGivens, real case
+  if (q == 0.) {
+    c = p < 0. ? -1. : 1.;
+    s = 0.;
+  } else if (p == 0.) {
+    c = 0.;
+    s = q < 0. ? 1. : -1.;
+  } else if (fabs(p) > fabs(q)) {
+    const double t = q / p;
+    double u = sqrt(1. + t * t);
+    if (p < 0.) u = -u;
+    c = 1. / u;
+    s = -t * c;
+  } else {
+    const double t = p / q;
+    double u = sqrt(1. + t * t);
+    if (q < 0.) u = -u;
+    s = -1. / u;
+    c = -t * s;
+  }
+}
+
+__device__ __forceinline__ void covar_inverse_eigen(double c00, double c01, double c10, double c11, double* inv) {
+  constexpr double kDblMin = 2.2250738585072014e-308, kDblEps = 2.220446049250313e-16;
+  double e0 = 0., e1 = 0.;
+  // RealSchur::compute: scale = matrix.cwiseAbs().maxCoeff()
+  double scale = fabs(c00);
+  if (fabs(c01) > scale) scale = fabs(c01);
+  if (fabs(c10) > scale) scale = fabs(c10);
+  if (fabs(c11) > scale) scale = fabs(c11);
+  if (!(scale < kDblMin)) {
+    double t00 = c00 / scale, t01 = c01 / scale, t10 = c10 / scale, t11 = c11 / scale;
+    const double norm = (fabs(t00) + fabs(t10)) + (fabs(t01) + fabs(t11));  // computeNormOfT (only tested against 0)
+    if (norm != 0.) {
+      double sd = (fabs(t00) + fabs(t11)) * kDblEps;  // findSmallSubdiagEntry(1)
+      if (!(sd > kDblMin)) sd = kDblMin;
+      if (fabs(t10) <= sd) {
+        t10 = 0.;
+      } else {  // splitOffTwoRows(1)
+        const double p = 0.5 * (t00 - t11);
+        const double q = p * p + t10 * t01;
+        if (q >= 0.) {
+          const double z = sqrt(fabs(q));
+          double c, sn;
+          eigen_givens(p >= 0. ? p + z : p - z, t10, c, sn);
+          if (!(c == 1. && sn == 0.)) {
+            const double ms = -sn;
+            // applyOnTheLeft(0, 1, rot.adjoint()): rows, rotation (c, -s)
+            double x = t00, y = t10;
+            t00 = c * x + ms * y;
+            t10 = -ms * x + c * y;
+            x = t01, y = t11;
+            t01 = c * x + ms * y;
+            t11 = -ms * x + c * y;
+            // applyOnTheRight(0, 1, rot): columns, rotation rot.transpose() = (c, -s)
+            x = t00, y = t01;
+            t00 = c * x + ms * y;
+            t01 = -ms * x + c * y;
+            x = t10, y = t11;
+            t10 = c * x + ms * y;
+            t11 = -ms * x + c * y;
+          }
+          t10 = 0.;
+        }
+      }
+    }
+    t00 *= scale;  // m_matT *= scale
+    t10 *= scale;
+    t11 *= scale;
+    if (t10 == 0.) {
+      e0 = t00;
+      e1 = t11;
+    } else {  // complex pair (not reachable for a symmetric matrix): its real part on both diagonal entries
+      e0 = e1 = t11 + 0.5 * (t00 - t11);
+    }
+  }
+  const double large_val = (e0 > e1) ? e0 : e1;  // ndtcell.cpp:100
+  const double small_val = (e0 < e1) ? e0 : e1;  // ndtcell.cpp:101
+  double det;
+  if (small_val < .001 * large_val)
+    det = .001 * large_val * large_val;  // ndtcell.cpp:103-105
+  else
+    det = c00 * c11 - c10 * c01;  // Matrix2d::determinant(), ndtcell.cpp:107
+  inv[0] = c11 / det;  // ndtcell.cpp:109-110
+  inv[1] = -c01 / det;
+  inv[2] = -c10 / det;
+  inv[3] = c00 / det;
+}
+
 // ---- small device helpers ------------------------------------------------
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
@@ -1044,27 +1142,18 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
         fold(p3);
       }
       for (; t < c; ++t) fold(pts[mine[t]]);
-      // s_calc_covar_inverse, ndtcell.cpp:93-111 (eigenvalues of the 2x2 in closed form)
+      // s_calc_covar_inverse, ndtcell.cpp:93-111 (eigenvalues as Eigen's EigenSolver computes them)
       const double nn = (double)c;
       c00 = c00 / nn;
       c01 = c01 / nn;
       c10 = c10 / nn;
       c11 = c11 / nn;
-      const double hp = 0.5 * (c00 - c11);
-      const double q = sqrt(hp * hp + c01 * c10);
-      const double mid = 0.5 * (c00 + c11);
-      const double e0 = mid + q, e1 = mid - q;
-      const double large_val = (e0 > e1) ? e0 : e1;
-      const double small_val = (e0 < e1) ? e0 : e1;
-      double det;
-      if (small_val < .001 * large_val)
-        det = .001 * large_val * large_val;
-      else
-        det = c00 * c11 - c10 * c01;
-      ia = c11 / det;
-      ib = -c01 / det;
-      ic = -c10 / det;
-      id = c00 / det;
+      double inv[4];
+      covar_inverse_eigen(c00, c01, c10, c11, inv);
+      ia = inv[0];
+      ib = inv[1];
+      ic = inv[2];
+      id = inv[3];
       const unsigned slot = bm_slot(bm, mykey);
       if ((int)slot < wn.rec_cap) {
         if (dn) dense_put(g, *dn, lds0, slot, mykey % wn.w, mykey / wn.w, mx, my, ia, ib, ic, id, byte_entries);

@@ -153,19 +153,187 @@ static void cell_add_point(orc_cell *c, v2 p) {
   c->built = 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* Eigen::EigenSolver<Matrix2d>, as the reference reaches it (ndtcell.cpp:96-97):
+ *   EigenSolver<Matrix2d> solver(covar);                      -> EigenSolver::compute(covar, true)
+ *   solver.pseudoEigenvalueMatrix().diagonal()
+ * Restated from Eigen 3.3.7's published sources, function by function (Eigen is not in this image; the reference does
+ * not pin a version -- find_package(Eigen3 REQUIRED), CMakeLists.txt:30):
+ *   Eigen/src/Eigenvalues/EigenSolver.h    EigenSolver::compute, ::pseudoEigenvalueMatrix
+ *   Eigen/src/Eigenvalues/RealSchur.h      RealSchur::compute, ::computeFromHessenberg, ::computeNormOfT,
+ *                                          ::findSmallSubdiagEntry, ::splitOffTwoRows
+ *   Eigen/src/Eigenvalues/HessenbergDecomposition.h  -- for a 2x2 the one Householder step has an empty tail
+ *                                          (makeHouseholder: tau = 0, beta = c0) and both applications multiply by
+ *                                          (1 - tau) = 1: H = the input, Q = I, no rounding
+ *   Eigen/src/Jacobi/Jacobi.h              JacobiRotation::makeGivens (real case), apply_rotation_in_the_plane
+ *                                          (x' = c x + s y, y' = -s x + c y; its packet path computes
+ *                                          c y - s x, the same value; no FMA in a baseline x86-64 build)
+ * Operation order, for the 2x2 input M (column-major storage plays no part):
+ *   RealSchur::compute:   scale = max |M_ij|; scale < DBL_MIN -> T = 0 (eigenvalues 0, 0);
+ *                         T = M / scale (coefficient-wise division); ...; T *= scale at the end
+ *   computeFromHessenberg, iu = 1: findSmallSubdiagEntry: s = |T00| + |T11|; s = max(s * eps, DBL_MIN);
+ *                         |T10| <= s -> the diagonal is the answer (both "one root found" steps add exshift = 0)
+ *                         else splitOffTwoRows(1):
+ *   splitOffTwoRows:      p = 0.5 (T00 - T11); q = p p + T10 T01; q >= 0: z = sqrt|q|;
+ *                         rot.makeGivens(p >= 0 ? p + z : p - z, T10);
+ *                         T.applyOnTheLeft(0, 1, rot.adjoint()); T.applyOnTheRight(0, 1, rot); T10 = 0
+ *                         (q < 0, a complex pair, cannot happen for a symmetric input; restated all the same)
+ *   EigenSolver::compute: T10 == 0 -> eigenvalue i = T_ii (real); otherwise the pair (T11 + p, +-z) with
+ *                         z = maxval * sqrt|p0 p0 + t0 t1|
+ *   pseudoEigenvalueMatrix: real eigenvalues land on the diagonal; a complex pair puts its real part on both.
+ * `variant`: 0 = as above (3.3.7; also what 3.4.0 does for a 2x2); 1 = the same without the scale / unscale steps of
+ * RealSchur::compute and without the DBL_MIN floor in findSmallSubdiagEntry (RealSchur.h before those were added --
+ * which 3.3.x release first carried them cannot be established offline, 3.3.4 is the other version the reference's
+ * README leads to); 2 = the closed form mid +- sqrt(hp^2 + c01 c10) that rounds 1 and 2 of this repository used.
+ * tests/test_oracle.py reports the ulp distribution between the three over >= 1e6 covariance matrices. */
+static int g_eigen_variant = 0;
+void orc_set_eigen_variant(int variant) { g_eigen_variant = variant; }
+int orc_get_eigen_variant(void) { return g_eigen_variant; }
+
+/* JacobiRotation<double>::makeGivens(p, q, 0), real specialisation (Jacobi.h) */
+static void eig_make_givens(double p, double q, double *c, double *s) {
+  if (q == 0.) {
+    *c = p < 0. ? -1. : 1.;
+    *s = 0.;
+  } else if (p == 0.) {
+    *c = 0.;
+    *s = q < 0. ? 1. : -1.;
+  } else if (fabs(p) > fabs(q)) {
+    double t = q / p;
+    double u = sqrt(1. + t * t);
+    if (p < 0.) u = -u;
+    *c = 1. / u;
+    *s = -t * *c;
+  } else {
+    double t = p / q;
+    double u = sqrt(1. + t * t);
+    if (q < 0.) u = -u;
+    *s = -1. / u;
+    *c = -t * *s;
+  }
+}
+
+/* internal::apply_rotation_in_the_plane(x, y, JacobiRotation(c, s)) on two vectors of n coefficients with strides */
+static void eig_apply_rotation(double *x, double *y, int n, int stride, double c, double s) {
+  int i;
+  if (c == 1. && s == 0.) return;
+  for (i = 0; i < n; ++i) {
+    double xi = x[i * stride], yi = y[i * stride];
+    x[i * stride] = c * xi + s * yi;
+    y[i * stride] = -s * xi + c * yi;
+  }
+}
+
+void orc_eigen_eigenvalues_2x2(const double m[4], int variant, double ev[2]) {
+  /* m = {M00, M01, M10, M11}; T is kept row-major here: T[2*i + j] */
+  double T[4];
+  double scale = 1.;
+  int k;
+  if (variant == 2) { /* closed form (rounds 1-2) */
+    double hp = 0.5 * (m[0] - m[3]);
+    double q = sqrt(hp * hp + m[1] * m[2]);
+    double mid = 0.5 * (m[0] + m[3]);
+    ev[0] = mid + q;
+    ev[1] = mid - q;
+    return;
+  }
+  if (variant == 0) { /* RealSchur::compute: scale = matrix.cwiseAbs().maxCoeff() */
+    scale = fabs(m[0]);
+    for (k = 1; k < 4; ++k)
+      if (fabs(m[k]) > scale) scale = fabs(m[k]);
+    if (scale < 2.2250738585072014e-308) { /* considerAsZero = numeric_limits<double>::min() */
+      ev[0] = ev[1] = 0.;
+      return;
+    }
+    for (k = 0; k < 4; ++k) T[k] = m[k] / scale; /* m_hess.compute(matrix / scale); H = the input for a 2x2 */
+  } else {
+    for (k = 0; k < 4; ++k) T[k] = m[k];
+  }
+  {
+    /* computeNormOfT: sum of |T_ij| over the upper Hessenberg part = all four entries */
+    double norm = 0.;
+    norm += fabs(T[0]) + fabs(T[2]); /* column 0, rows 0..1 */
+    norm += fabs(T[1]) + fabs(T[3]); /* column 1, rows 0..1 */
+    if (norm != 0.) {
+      /* findSmallSubdiagEntry(iu = 1) */
+      double s = fabs(T[0]) + fabs(T[3]);
+      int small;
+      if (variant == 0) {
+        s = s * 2.220446049250313e-16;
+        if (!(s > 2.2250738585072014e-308)) s = 2.2250738585072014e-308; /* numext::maxi(s * eps, considerAsZero) */
+        small = fabs(T[2]) <= s;
+      } else {
+        small = fabs(T[2]) <= 2.220446049250313e-16 * s;
+      }
+      if (small) {
+        T[2] = 0.; /* "one root found", twice; exshift = 0 */
+      } else {
+        /* splitOffTwoRows(iu = 1, computeU, exshift = 0) */
+        double p = 0.5 * (T[0] - T[3]);
+        double q = p * p + T[2] * T[1];
+        if (q >= 0.) {
+          double z = sqrt(fabs(q));
+          double c, sn;
+          if (p >= 0.)
+            eig_make_givens(p + z, T[2], &c, &sn);
+          else
+            eig_make_givens(p - z, T[2], &c, &sn);
+          /* m_matT.rightCols(2).applyOnTheLeft(0, 1, rot.adjoint()): rows 0 and 1, rotation (c, -s) */
+          eig_apply_rotation(&T[0], &T[2], 2, 1, c, -sn);
+          /* m_matT.topRows(2).applyOnTheRight(0, 1, rot): columns 0 and 1, rotation rot.transpose() = (c, -s) */
+          eig_apply_rotation(&T[0], &T[1], 2, 2, c, -sn);
+          T[2] = 0.;
+        }
+      }
+    }
+  }
+  if (variant == 0)
+    for (k = 0; k < 4; ++k) T[k] *= scale; /* m_matT *= scale */
+  /* EigenSolver::compute + pseudoEigenvalueMatrix().diagonal() */
+  if (T[2] == 0.) {
+    ev[0] = T[0];
+    ev[1] = T[3];
+  } else { /* complex pair: real part T11 + p on both diagonal entries (unreachable for symmetric input) */
+    double p = 0.5 * (T[0] - T[3]);
+    ev[0] = ev[1] = T[3] + p;
+  }
+}
+
+/* ndtcell.cpp:93-111 from a covariance matrix on, for the eigenvalue-variant comparison of tests/test_oracle.py:
+ * out rows = {large eigenvalue, small eigenvalue, det as used, degenerate branch taken (0/1), inv00, inv01, inv10, inv11} */
+void orc_covar_inverse_batch(const double *m, size_t n, int variant, double *out) {
+  size_t i;
+  for (i = 0; i < n; ++i) {
+    const double *c = m + 4 * i;
+    double ev[2], large_val, small_val, det;
+    int deg;
+    orc_eigen_eigenvalues_2x2(c, variant, ev);
+    large_val = ev[ev[0] > ev[1] ? 0 : 1];
+    small_val = ev[ev[0] < ev[1] ? 0 : 1];
+    deg = small_val < .001 * large_val;
+    det = deg ? .001 * large_val * large_val : c[0] * c[3] - c[2] * c[1];
+    out[8 * i + 0] = large_val;
+    out[8 * i + 1] = small_val;
+    out[8 * i + 2] = det;
+    out[8 * i + 3] = (double)deg;
+    out[8 * i + 4] = c[3] / det;
+    out[8 * i + 5] = -c[1] / det;
+    out[8 * i + 6] = -c[2] / det;
+    out[8 * i + 7] = c[0] / det;
+  }
+}
+
 /* NDTCell::s_calc_covar_inverse, ndtcell.cpp:93-111 */
 static void cell_calc_covar_inverse(orc_cell *c) {
   double n = (double)c->global_count;
+  double m[4], ev[2];
   double c00 = c->global_covar_sum[0] / n, c01 = c->global_covar_sum[1] / n;
   double c10 = c->global_covar_sum[2] / n, c11 = c->global_covar_sum[3] / n;
-  /* eigenvalues of the (symmetric) 2x2, closed form; EigenSolver in the reference (ndtcell.cpp:96-97) */
-  double hp = 0.5 * (c00 - c11);
-  double q = sqrt(hp * hp + c01 * c10);
-  double mid = 0.5 * (c00 + c11);
-  double e0 = mid + q, e1 = mid - q;
-  double large_val = (e0 > e1) ? e0 : e1; /* ndtcell.cpp:100 */
-  double small_val = (e0 < e1) ? e0 : e1; /* ndtcell.cpp:101 */
-  double det;
+  double large_val, small_val, det;
+  m[0] = c00; m[1] = c01; m[2] = c10; m[3] = c11;
+  orc_eigen_eigenvalues_2x2(m, g_eigen_variant, ev); /* ndtcell.cpp:96-97 */
+  large_val = ev[ev[0] > ev[1] ? 0 : 1]; /* ndtcell.cpp:100 */
+  small_val = ev[ev[0] < ev[1] ? 0 : 1]; /* ndtcell.cpp:101 */
   if (small_val < .001 * large_val)
     det = .001 * large_val * large_val; /* ndtcell.cpp:103-105 */
   else

@@ -17,9 +17,10 @@
  *     README names): DenseBase::Random() = x + (y-x)*double(rand())/double(RAND_MAX)
  *     with x=-1,y=1 (Eigen/src/Core/MathFunctions.h, random_default_impl<double>),
  *     coefficient-wise +,-,*,/ on 2- and 3-vectors, 2x2 determinant, and
- *     EigenSolver<Matrix2d> eigenvalues (restated in closed form -- only the
- *     ordering test and, in the degenerate branch, the larger eigenvalue are
- *     consumed, ndtcell.cpp:96-105).
+ *     EigenSolver<Matrix2d>::pseudoEigenvalueMatrix().diagonal() (ndtcell.cpp:96-97),
+ *     restated step by step from Eigen 3.3.7's RealSchur / JacobiRotation sources
+ *     (orc_eigen_eigenvalues_2x2; rounds 1-2 used a closed form that differs from it
+ *     by a few ulp -- kept as variant 2 so that the difference stays measurable).
  *   - glibc rand()/srand() (TYPE_3 additive feedback generator, RAND_MAX 2^31-1).
  *
  * Every function cites the reference file:line (relative to the reference
@@ -84,6 +85,17 @@ void orc_pso_config_default(orc_pso_config *c);
 
 /* glibc srand(seed); rand() x n, restated (stdlib/random_r.c, TYPE_3). */
 void orc_glibc_rand_fill(uint32_t seed, int32_t *out, size_t n);
+
+/* EigenSolver<Matrix2d>(M).pseudoEigenvalueMatrix().diagonal() for M = {M00, M01, M10, M11} (ndtcell.cpp:96-97).
+ * variant 0: Eigen 3.3.7's operation order (scaled RealSchur, Givens rotation) -- what the oracle uses;
+ * variant 1: the same without RealSchur::compute's scaling (older 3.3.x); variant 2: closed form (rounds 1-2). */
+void orc_eigen_eigenvalues_2x2(const double m[4], int variant, double ev[2]);
+/* Which variant NDTCell::s_calc_covar_inverse uses from now on (process-wide; default 0). */
+void orc_set_eigen_variant(int variant);
+int orc_get_eigen_variant(void);
+/* s_calc_covar_inverse (ndtcell.cpp:93-111) on n covariance matrices {c00,c01,c10,c11}; out: 8 doubles per matrix =
+ * {large, small, det used, degenerate branch (0/1), inv00, inv01, inv10, inv11}. */
+void orc_covar_inverse_batch(const double *m, size_t n, int variant, double *out);
 /* number of rand() draws one pso_optimization call consumes: 3 + 3P + 6PI */
 size_t orc_pso_rand_draws(const orc_pso_config *c);
 

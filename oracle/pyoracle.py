@@ -90,6 +90,10 @@ def lib():
     L.orc_frame_occupancy_grid.restype = C.POINTER(C.c_int8)
     L.orc_frame_occupancy_grid.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.orc_glibc_rand_fill.argtypes = [C.c_uint32, C.POINTER(C.c_int32), C.c_size_t]
+    L.orc_eigen_eigenvalues_2x2.argtypes = [dp, C.c_int, dp]
+    L.orc_set_eigen_variant.argtypes = [C.c_int]
+    L.orc_get_eigen_variant.restype = C.c_int
+    L.orc_covar_inverse_batch.argtypes = [dp, C.c_size_t, C.c_int, dp]
     L.orc_pso_rand_draws.restype = C.c_size_t
     L.orc_pso_rand_draws.argtypes = [C.POINTER(PSOConfig)]
     L.orc_align_pairs.restype = C.c_int
@@ -112,6 +116,29 @@ def glibc_rand(seed: int, n: int) -> np.ndarray:
     out = np.empty(n, dtype=np.int32)
     lib().orc_glibc_rand_fill(C.c_uint32(int(seed)), out.ctypes.data_as(C.POINTER(C.c_int32)), n)
     return out
+
+
+EIGEN_337, EIGEN_NOSCALE, EIGEN_CLOSED_FORM = 0, 1, 2
+
+
+def eigenvalues_2x2(m, variant=EIGEN_337):
+    """EigenSolver<Matrix2d>(m).pseudoEigenvalueMatrix().diagonal() as the oracle restates it (ndtcell.cpp:96-97)."""
+    a = np.ascontiguousarray(np.asarray(m, dtype=np.float64).reshape(4))
+    ev = np.empty(2)
+    lib().orc_eigen_eigenvalues_2x2(_dp(a), int(variant), _dp(ev))
+    return ev
+
+
+def covar_inverse_batch(covars, variant=EIGEN_337):
+    """ndtcell.cpp:93-111 on an (n, 4) array of covariance matrices -> (n, 8): large, small, det, degenerate, inv[4]."""
+    a = np.ascontiguousarray(np.asarray(covars, dtype=np.float64).reshape(-1, 4))
+    out = np.empty((a.shape[0], 8))
+    lib().orc_covar_inverse_batch(_dp(a), a.shape[0], int(variant), _dp(out))
+    return out
+
+
+def set_eigen_variant(variant):
+    lib().orc_set_eigen_variant(int(variant))
 
 
 class Frame:

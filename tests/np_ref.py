@@ -62,6 +62,74 @@ def cell_index(x, y, width, height, cs):
     return -1
 
 
+DBL_MIN = 2.2250738585072014e-308
+DBL_EPS = 2.220446049250313e-16
+
+
+def _givens(p, q):
+    """JacobiRotation<double>::makeGivens, real case (Eigen/src/Jacobi/Jacobi.h)."""
+    if q == 0.0:
+        return (-1.0 if p < 0.0 else 1.0), 0.0
+    if p == 0.0:
+        return 0.0, (1.0 if q < 0.0 else -1.0)
+    if abs(p) > abs(q):
+        t = q / p
+        u = math.sqrt(1.0 + t * t)
+        if p < 0.0:
+            u = -u
+        c = 1.0 / u
+        return c, -t * c
+    t = p / q
+    u = math.sqrt(1.0 + t * t)
+    if q < 0.0:
+        u = -u
+    s = -1.0 / u
+    return -t * s, s
+
+
+def eigen_solver_2x2(m00, m01, m10, m11, scaled=True):
+    """EigenSolver<Matrix2d>(M).pseudoEigenvalueMatrix().diagonal() (ndtcell.cpp:96-97), second restatement of Eigen
+    3.3.7's RealSchur path (RealSchur::compute -> computeFromHessenberg -> splitOffTwoRows, EigenSolver::compute),
+    written on a matrix of Python floats [[t00, t01], [t10, t11]] instead of the C oracle's flat array.
+    scaled=False: without RealSchur::compute's scale / unscale (older 3.3.x)."""
+    scale = 1.0
+    if scaled:
+        scale = max(abs(m00), abs(m01), abs(m10), abs(m11))
+        if scale < DBL_MIN:
+            return 0.0, 0.0
+    t = [[m00 / scale, m01 / scale], [m10 / scale, m11 / scale]] if scaled else [[m00, m01], [m10, m11]]
+    norm = abs(t[0][0]) + abs(t[1][0]) + abs(t[0][1]) + abs(t[1][1])
+    if norm != 0.0:
+        s = abs(t[0][0]) + abs(t[1][1])
+        thr = max(s * DBL_EPS, DBL_MIN) if scaled else DBL_EPS * s
+        if abs(t[1][0]) <= thr:
+            t[1][0] = 0.0
+        else:
+            p = 0.5 * (t[0][0] - t[1][1])
+            q = p * p + t[1][0] * t[0][1]
+            if q >= 0.0:
+                z = math.sqrt(abs(q))
+                c, sn = _givens(p + z if p >= 0.0 else p - z, t[1][0])
+                if not (c == 1.0 and sn == 0.0):
+                    # applyOnTheLeft(0, 1, rot.adjoint()): rotation (c, -sn) on the two rows
+                    for j in (0, 1):
+                        x, y = t[0][j], t[1][j]
+                        t[0][j] = c * x + (-sn) * y
+                        t[1][j] = sn * x + c * y
+                    # applyOnTheRight(0, 1, rot): rot.transpose() = (c, -sn) on the two columns
+                    for i in (0, 1):
+                        x, y = t[i][0], t[i][1]
+                        t[i][0] = c * x + (-sn) * y
+                        t[i][1] = sn * x + c * y
+                t[1][0] = 0.0
+    if scaled:
+        t = [[v * scale for v in row] for row in t]
+    if t[1][0] == 0.0:
+        return t[0][0], t[1][1]
+    re = t[1][1] + 0.5 * (t[0][0] - t[1][1])
+    return re, re
+
+
 def build_cells(points, width, height, cs):
     """Fresh-frame NDTCell::build + s_calc_covar_inverse, ndtcell.cpp:36-68,93-111.
     Returns {index: dict(count, built, mean, icov)}."""
@@ -90,7 +158,7 @@ def build_cells(points, width, height, cs):
                 c10 += d1 * d0
                 c11 += d1 * d1
             c00, c01, c10, c11 = c00 / n, c01 / n, c10 / n, c11 / n
-            ev = np.linalg.eigvalsh(np.array([[c00, c01], [c10, c11]]))   # LAPACK, not the closed form
+            ev = np.linalg.eigvalsh(np.array([[c00, c01], [c10, c11]]))   # LAPACK, not Eigen's RealSchur path
             large, small = max(ev), min(ev)
             det = 0.001 * large * large if small < 0.001 * large else c00 * c11 - c10 * c01
             cell["mean"] = (mx, my)

@@ -121,7 +121,7 @@ def test_cell_table_matches_numpy_restatement(oracle, pairs8):
             assert got[k]["count"] == w["count"] and got[k]["built"] == w["built"]
             if w["built"]:
                 assert tuple(got[k]["mean"]) == w["mean"]
-                np.testing.assert_allclose(got[k]["icov"], w["icov"], rtol=1e-9)   # LAPACK vs closed-form eigenvalues
+                np.testing.assert_allclose(got[k]["icov"], w["icov"], rtol=1e-9)   # LAPACK vs Eigen's RealSchur eigenvalues
 
 
 def test_cost_matches_numpy_restatement(oracle, pairs8):
@@ -345,3 +345,69 @@ def test_headings_and_beam_directions_go_through_one_sincos(oracle):
         c, s = np_ref.cos_sin(pose[2])
         want = np.stack([xy[:, 0] * c - xy[:, 1] * s + pose[0], xy[:, 0] * s + xy[:, 1] * c + pose[1]], axis=1)
         assert np.array_equal(ref.points(), want)
+
+
+# ---- EigenSolver<Matrix2d> (ndtcell.cpp:96-97): the restated RealSchur path and its neighbours -------------------
+
+def test_eigen_solver_c_and_python_restatements_agree_bit_for_bit(oracle):
+    """oracle/ndtpso_oracle.c:orc_eigen_eigenvalues_2x2 against the independent Python restatement of the same Eigen
+    3.3.7 functions (tests/np_ref.py:eigen_solver_2x2), scaled and unscaled, on cell covariances of the synthetic
+    world and on the edge cases of each branch."""
+    import eigen_cases
+    M = eigen_cases.world_covariances(6000, seed=5)
+    edge = [(0, 0, 0, 0), (2, 0, 0, 1), (1, 0, 0, 2), (1, 1e-20, 1e-20, 2), (1, 1, 1, 1), (1, -1, -1, 1),
+            (3e-310, 1e-310, 1e-310, 2e-310), (1e300, 5e299, 5e299, 2e300), (0.02, -0.0199, -0.0199, 0.02),
+            (1e-4, 0.0, 0.0, 1e-4), (0.0, 1e-3, 1e-3, 0.0), (5.0, 2.0, 2.0, 5.0), (1.0, 2.0, -2.0, 1.0)]
+    M = np.concatenate([M, np.asarray(edge, dtype=np.float64)])
+    for m in M:
+        for variant, scaled in ((oracle.EIGEN_337, True), (oracle.EIGEN_NOSCALE, False)):
+            got = oracle.eigenvalues_2x2(m, variant)
+            want = np_ref.eigen_solver_2x2(*m, scaled=scaled)
+            assert got[0] == want[0] and got[1] == want[1], (m, variant, got, want)
+    # the two real eigenvalues of a symmetric matrix, to LAPACK's accuracy (largest one relative, both absolute)
+    for m in M[:2000]:
+        ev = np.sort(oracle.eigenvalues_2x2(m))
+        ref = np.linalg.eigvalsh(m.reshape(2, 2))
+        np.testing.assert_allclose(ev, ref, rtol=0, atol=4e-15 * max(abs(ref).max(), 1e-300))
+
+
+def test_eigen_variants_ulp_distribution(oracle, capsys):
+    """What 'bit-identical to the oracle' is relative to: s_calc_covar_inverse (ndtcell.cpp:93-111) with the
+    eigenvalues of (0) Eigen 3.3.7's RealSchur path -- the oracle's and the device's --, (1) the same without
+    RealSchur::compute's scaling, (2) the closed form of rounds 1-2, over >= 1e6 covariance matrices of the synthetic
+    world.  The three never disagree on the degenerate branch here; where they differ it is by a few ulp of the larger
+    eigenvalue, hence of det = .001 * large^2 and of the inverse covariance of thin cells.  The bounds asserted below
+    are what DESIGN.md section 2 quotes."""
+    import eigen_cases
+    M = eigen_cases.world_covariances(1_000_000)
+    assert M.shape[0] >= 1_000_000
+    o = {v: oracle.covar_inverse_batch(M, v) for v in (0, 1, 2)}
+    deg = o[0][:, 3] == 1.0
+    assert 0.05 < deg.mean() < 0.6           # thin (wall) cells take the clamped determinant
+    rng = np.random.default_rng(3)
+    d = rng.uniform(-0.25, 0.25, (M.shape[0], 2))   # a point within half a cell of the mean
+
+    def term(inv):   # exp(-(d^T inv d) / 2), ndtcell.cpp:70-76
+        q = (d[:, 0] * inv[:, 0] + d[:, 1] * inv[:, 2]) * d[:, 0] + (d[:, 0] * inv[:, 1] + d[:, 1] * inv[:, 3]) * d[:, 1]
+        return np.exp(-q / 2.0)
+
+    t0 = term(o[0][:, 4:8])
+    lines = []
+    for v, name in ((1, "unscaled RealSchur"), (2, "closed form")):
+        assert np.array_equal(o[0][:, 3], o[v][:, 3]), "degenerate-branch decision differs"
+        same_branch_nondeg = ~deg
+        # outside the degenerate branch the eigenvalues are not consumed at all: identical inverse
+        assert np.array_equal(o[0][same_branch_nondeg, 4:8], o[v][same_branch_nondeg, 4:8])
+        ul = eigen_cases.ulp_diff(o[0][deg, 0], o[v][deg, 0])
+        ud = eigen_cases.ulp_diff(o[0][deg, 2], o[v][deg, 2])
+        ui = eigen_cases.ulp_diff(o[0][deg, 4:8], o[v][deg, 4:8]).max(axis=1)
+        dt = np.abs(term(o[v][:, 4:8]) - t0)
+        lines.append("%-20s thin cells %.1f %%: large_val differs in %.1f %% of them (max %d ulp, p99 %d), det max %d ulp, "
+                     "inverse covariance max %d ulp, |d term| max %.2e"
+                     % (name, 100 * deg.mean(), 100 * (ul > 0).mean(), ul.max(), np.percentile(ul, 99), ud.max(), ui.max(), dt.max()))
+        assert ul.max() <= 16 and ud.max() <= 40 and ui.max() <= 48
+        assert dt.max() < 5e-12             # per-point Gaussian term (q = d^T inv d reaches hundreds in a thin cell)
+    with capsys.disabled():
+        print()
+        for ln in lines:
+            print("   ", ln)
