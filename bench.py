@@ -16,11 +16,15 @@ both are timed as `extra.modes` of the default run.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), with
   roofline      bound "valu": the kernel keeps table, points and swarm in LDS, HBM sees 8.7 KB per alignment; what
-                bounds it is vector-ALU issue.  peak = the issue-time floor of the score loop's instruction mix
-                (profiles/r02_isa_mix.json: llvm-objdump of the shipped kernel x the per-instruction issue times of
-                scripts/ubench_valu.hip measured on this chip), achieved = algorithmic point evaluations / kernel time
-                measured here with events; the 40-byte-per-point-eval "effective bandwidth" of SURVEY 8(d) is kept
-                under roofline.hbm_effective.
+                bounds it is the chip's vector ALU.  achieved = SURVEY 8(d)'s flops per point evaluation (16 fp64 + 34
+                fp32 + 1 exp) x the algorithmic point evaluations of a launch / the launch's duration (events, one
+                launch at a time); peak = the same flop mix at the vector peaks of the chip (fp32 157.3, fp64 78.6
+                TFLOP/s).  roofline.floor keeps the issue-time figure of the score loop's own instruction mix
+                (scripts/isa_mix.py); the 40-byte-per-point-eval "effective bandwidth" of SURVEY 8(d) is under
+                roofline.hbm_effective.
+  value         steps / time with two batches in flight in the one context (ndtpso_set_pipeline_depth(2): step k + 1 is
+                launched while step k's slowest alignments finish); extra.batches_in_flight.one_batch_at_a_time is the
+                figure of rounds 1-2 (--pipeline 1 makes it the headline).
   cpu_baseline  the oracle (a port of the reference's algorithm) on this box's host cores, SURVEY 8(d)'s four numbers.
 """
 from __future__ import annotations
@@ -52,6 +56,9 @@ def main():
     ap.add_argument("--particles", type=int, default=70)
     ap.add_argument("--iterations", type=int, default=70)
     ap.add_argument("--score", choices=["exact", "f32", "f64"], default="exact")
+    ap.add_argument("--pipeline", type=int, choices=[1, 2], default=2,
+                    help="batches in flight in the context (ndtpso_set_pipeline_depth): 2 = step k + 1 is launched while step k's "
+                         "slowest alignments finish (the default, what a caller with a queue of batches does); 1 = one at a time")
     ap.add_argument("--cpu-sample", type=int, default=512, help="pairs of this step timed on the host oracle (0 = skip the CPU baseline)")
     ap.add_argument("--no-latency", action="store_true", help="skip the extras (other score modes, config 5, latency, live sequence)")
     ap.add_argument("--identical", action="store_true", help="diagnostic: replicate pair 0 (no load imbalance)")
@@ -109,31 +116,47 @@ def main():
     d_cost = torch.zeros(B, dtype=torch.float64, device=dev)
     d_stats = torch.zeros(B, 8, dtype=torch.int32, device=dev)
 
-    def step():
-        ctx.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(),
-                            cfg, d_seeds.data_ptr(), 0, mode, d_pose.data_ptr(), d_cost.data_ptr(),
-                            d_stats.data_ptr())
-        if use_dist:
-            sharding.gather_poses(d_pose, equal_sizes=True, force=True)  # the single RCCL gather of poses over xGMI
+    # Two output sets: with two batches in flight, step k writes set k & 1 while step k - 1's slowest alignments finish.
+    outs = [(d_pose, d_cost, d_stats), (torch.zeros_like(d_pose), torch.zeros_like(d_cost), torch.zeros_like(d_stats))]
+    depth = args.pipeline
+    ctx.set_pipeline_depth(depth)
 
-    for _ in range(args.warmup):
-        step()
+    def launch(k):
+        po, co, st = outs[k & 1] if depth > 1 else outs[0]
+        ctx.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(),
+                            cfg, d_seeds.data_ptr(), 0, mode, po.data_ptr(), co.data_ptr(), st.data_ptr())
+
+    def run_steps(n, events=None):
+        """n steps.  One step = one launch over the rank's B pairs + (N > 1) the single RCCL gather of its poses.  With two
+        batches in flight the gather of step k - 1 is enqueued behind the launch of step k (ndtpso_pipeline_flush(1) orders
+        step k - 1's poses before it on the stream), the last one after the loop: n launches, n gathers either way."""
+        for k in range(n):
+            if events is not None:
+                events[k][0].record(stream)
+            launch(k)
+            if events is not None:
+                events[k][1].record(stream)
+            if use_dist:
+                if depth == 1:
+                    sharding.gather_poses(outs[0][0], equal_sizes=True, force=True)  # the single RCCL gather of poses over xGMI
+                elif k > 0:
+                    ctx.pipeline_flush(1)
+                    sharding.gather_poses(outs[(k - 1) & 1][0], equal_sizes=True, force=True)
+        if depth > 1:
+            ctx.pipeline_flush(0)
+            if use_dist and n > 0:
+                sharding.gather_poses(outs[(n - 1) & 1][0], equal_sizes=True, force=True)
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
 
-    # per-launch kernel duration with events on the launch stream
+    # the timed region: exactly `steps` steps between two synchronisations
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        ev[k][0].record(stream)
-        ctx.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(),
-                            cfg, d_seeds.data_ptr(), 0, mode, d_pose.data_ptr(), d_cost.data_ptr(),
-                            d_stats.data_ptr())
-        ev[k][1].record(stream)
-        if use_dist:
-            sharding.gather_poses(d_pose, equal_sizes=True, force=True)
+    run_steps(args.steps, ev if depth == 1 else None)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -143,7 +166,30 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+    ctx.synchronize()
+    poses_equal_between_sets = bool(torch.equal(outs[0][0], outs[1][0])) if depth > 1 and args.steps > 1 else None
+
+    # Per-launch duration of the kernel, one launch at a time (events on the launch stream): what the rocprofv3 kernel
+    # trace of `bench.py --pipeline 1` averages, and what the roofline divides by.  With two batches in flight a
+    # launch's own duration says nothing (two launches share the device); the serial figure is measured here, after
+    # the timed region, over min(steps, 60) launches.
+    ctx.set_pipeline_depth(1)
+    if depth == 1:
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if args.steps else float("nan")
+        serial_ms = 1e3 * elapsed / max(args.steps, 1)
+    else:
+        ns = max(1, min(args.steps, 60))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(ns)]
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for k in range(ns):
+            evs[k][0].record(stream)
+            ctx.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(),
+                                cfg, d_seeds.data_ptr(), 0, mode, d_pose.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr())
+            evs[k][1].record(stream)
+        torch.cuda.synchronize()
+        serial_ms = 1e3 * (time.perf_counter() - t1) / ns
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
 
     stats = d_stats.cpu().numpy().view(capi.STATS_DTYPE).reshape(B)
     pose = d_pose.cpu().numpy()
@@ -176,8 +222,9 @@ def main():
                 "pairs_per_gpu": B, "particles": P, "iterations": I, "score": args.score,
                 "parallelism": "pairs sharded by contiguous index range, 1 RCCL all_gather of poses per step"
                                if world > 1 else "single GPU",
+                "batches_in_flight": depth,
             },
-            "roofline": _roofline(stats, evals_nominal, kern_ms, algo_bytes, achieved),
+            "roofline": _roofline(stats, evals_nominal, kern_ms, algo_bytes, achieved, 1e3 * elapsed / max(args.steps, 1), depth),
             "extra": {
                 "mean_cost_evals_per_alignment": float(stats["cost_evals"].mean()),
                 "mean_replay_overhead": float(stats["cost_evals"].mean()) / evals_nominal - 1.0,
@@ -189,6 +236,14 @@ def main():
                 "n_points_min_max": [int(stats["n_points"].min()), int(stats["n_points"].max())],
                 "comparisons_arbitrated_in_f64_per_alignment": float(stats["arbitrated"].mean()),
                 "timed_region_s": elapsed,
+                "batches_in_flight": {
+                    "depth": depth,
+                    "note": "value / ms_per_step: `steps` launches of one context issued back to back with ndtpso_set_pipeline_depth(%d); "
+                            "one_batch_at_a_time: the same launches one after the other on one stream (what rounds 1-2 reported)" % depth,
+                    "one_batch_at_a_time": {"alignments_per_s": B * world / (serial_ms * 1e-3) if world == 1 else None,
+                                            "ms_per_step": serial_ms, "kernel_ms_by_events": kern_ms},
+                    "poses_equal_between_the_two_output_sets": poses_equal_between_sets,
+                },
             },
         }
 
@@ -227,33 +282,6 @@ def main():
             if m != mode:
                 modes[name] = timed(B, m, steps, geom, grid, cfg, d_ref, d_new, d_seeds)
         out["extra"]["modes"] = modes
-        # Two batches in flight: the same launches issued alternately through two contexts on two streams (each with its
-        # own outputs and workspaces).  A launch lasts as long as its slowest workgroup -- 7 % after the median one --
-        # and on one stream the next launch waits for it; on two streams the next batch's workgroups fill the compute
-        # units the tail leaves idle.  What a caller with a queue of batches gets; not the headline (one batch per step).
-        try:
-            ctx2 = capi.Context(local_rank)
-            stream2 = torch.cuda.Stream(dev)
-            ctx2.set_stream(stream2.cuda_stream)
-            d_pose2, d_cost2, d_stats2 = torch.zeros_like(d_pose), torch.zeros_like(d_cost), torch.zeros_like(d_stats)
-            lanes = ((ctx, d_pose, d_cost, d_stats), (ctx2, d_pose2, d_cost2, d_stats2))
-
-            def both(steps):
-                for k in range(steps):
-                    c, po, co, st = lanes[k & 1]
-                    c.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(), cfg,
-                                      d_seeds.data_ptr(), 0, mode, po.data_ptr(), co.data_ptr(), st.data_ptr())
-                torch.cuda.synchronize()
-            both(8)
-            t1 = time.perf_counter()
-            both(150)
-            dt = time.perf_counter() - t1
-            same = bool(torch.equal(d_pose, d_pose2))
-            out["extra"]["two_batches_in_flight"] = {"alignments_per_s": B * 150 / dt, "ms_per_step": 1e3 * dt / 150, "steps": 150,
-                                                     "pairs": B, "score": args.score, "poses_equal_between_the_two": same}
-            del ctx2
-        except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench run fails
-            out["extra"]["two_batches_in_flight"] = {"error": str(e)}
         try:
             B5 = min(256, B)
             p5 = synth.make_pairs(B5, n_beams=2048, seed=21)
@@ -345,27 +373,53 @@ def _load_json(name):
         return None
 
 
-def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs):
-    """bound = "valu".  Work of a launch: the reference's 1 + P + P*I cost evaluations per alignment x the points each
-    scores (algorithmic point evaluations, replays of the exact-order scheme not counted).  achieved = that / the
-    kernel time measured here.  peak = the same work at the issue-time floor of the score loop: every 64 points cost
-    profiles/r02_isa_mix.json's `valu_issue_ns_per_chunk` of one SIMD's time (instruction mix from llvm-objdump of the
-    shipped kernel, issue time per instruction from scripts/ubench_valu.hip on this chip), 1024 SIMDs working.  What is
-    outside the loop -- pose constants, wave reductions, the PSO's proposals and commits, barriers -- is not in the
-    floor, so frac < 1 by construction and 1 - frac is what those and the stalls cost together."""
-    mix = _load_json("r02_isa_mix.json")
+# Vector-ALU peaks of the chip: fp32 157.3 TFLOP/s (MI355X_MICROARCH.md, "Peak FP32 (vector)"); fp64 vector = half of it
+# (16 lanes per SIMD and clock against 32: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz = 78.6 TFLOP/s).
+VEC_FP32_TFLOPS = 157.3
+VEC_FP64_TFLOPS = 78.6
+# flops of one point evaluation as this kernel performs it -- fp64: the transform (2 x 2 FMA = 8) and the
+# two subtractions of the cell mean + two conversions to the table index + two to fp32 (8, counted one flop each);
+# fp32: the Cholesky-form Gaussian and the fold of the terms (34 by the survey's count, 2 per FMA); one v_exp_f32.
+FLOP_FP64, FLOP_FP32, FLOP_EXP = 16.0, 34.0, 1.0
+
+
+def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms, depth):
+    """The kernel keeps table, points and swarm in LDS: HBM sees 8.7 KB per alignment and no matrix instruction applies
+    (DESIGN 5), so the roof is the VECTOR ALU of the chip.  Work of a launch = the reference's 1 + P + P*I cost
+    evaluations per alignment x the points each scores (replays of the exact-order scheme not counted) x the flops of
+    one point evaluation (16 fp64 + 34 fp32 + 1 exp).  achieved = that / the launch's duration (one launch
+    at a time, HIP events on the launch stream).  peak = the same flop mix at the chip's vector peaks -- the time
+    fp64_flops / 78.6 T + fp32_flops / 157.3 T, expressed as a rate -- so frac = (that time) / (kernel time).  The
+    v_exp_f32 is charged as ONE fp32 flop although it issues at a quarter of the fp32 rate (frac_exp_at_quarter_rate
+    charges it 4).  `floor` keeps round 2's instruction-level figure: the issue time of the score loop's actual
+    instruction mix (scripts/isa_mix.py x scripts/ubench_valu.hip) -- useful for tuning, not a roofline."""
+    mix = _load_json("r03_isa_mix.json") or _load_json("r02_isa_mix.json")
     point_evals = float(stats["n_points"].astype(np.float64).sum()) * evals_nominal
-    achieved = point_evals / (kern_ms * 1e-3)
-    r = {"bound": "valu", "achieved": achieved, "peak": None, "unit": "point-evals/s", "frac": None,
+    flops = point_evals * (FLOP_FP64 + FLOP_FP32 + FLOP_EXP)
+    t_peak_s = point_evals * (FLOP_FP64 / (VEC_FP64_TFLOPS * 1e12) + (FLOP_FP32 + FLOP_EXP) / (VEC_FP32_TFLOPS * 1e12))
+    t_peak_q_s = point_evals * (FLOP_FP64 / (VEC_FP64_TFLOPS * 1e12) + (FLOP_FP32 + 4.0 * FLOP_EXP) / (VEC_FP32_TFLOPS * 1e12))
+    achieved = flops / (kern_ms * 1e-3) / 1e12
+    peak = flops / t_peak_s / 1e12
+    r = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
          "traffic": _pmc_traffic_bytes(), "kernel": "k_align_pairs (fused scan ingest + cell statistics + PSO)",
-         "kernel_ms": kern_ms, "algorithmic_point_evals_per_launch": point_evals}
+         "kernel_ms": kern_ms, "algorithmic_point_evals_per_launch": point_evals,
+         "flops_per_point_eval": {"fp64": FLOP_FP64, "fp32": FLOP_FP32, "exp": FLOP_EXP},
+         "vector_peaks_tflops": {"fp32": VEC_FP32_TFLOPS, "fp64": VEC_FP64_TFLOPS},
+         "flop_floor_ms_per_launch": t_peak_s * 1e3,
+         "frac_exp_at_quarter_rate": t_peak_q_s * 1e3 / kern_ms,
+         "note": "achieved / frac are per launch, one launch at a time (kernel_ms).  With %d batch(es) in flight a step takes "
+                 "%.3f ms of device time (ms_per_step): the same flops / that time = %.1f TFLOP/s, %.3f of the peak"
+                 % (depth, step_ms, flops / (step_ms * 1e-3) / 1e12, t_peak_s * 1e3 / step_ms),
+         "frac_of_step_time": t_peak_s * 1e3 / step_ms}
     if mix:
         ns_chunk = float(mix["valu_issue_ns_per_chunk"])
-        r["peak"] = N_SIMD * 64.0 / (ns_chunk * 1e-9)
-        r["frac"] = achieved / r["peak"]
+        issue_peak = N_SIMD * 64.0 / (ns_chunk * 1e-9)
         r["floor"] = {"valu_instructions_per_64_points": mix["valu_per_chunk"], "valu_issue_ns_per_64_points": ns_chunk,
-                      "floor_ms_per_launch": point_evals / r["peak"] * 1e3, "source": "profiles/r02_isa_mix.json (scripts/isa_mix.py), "
-                      "profiles/r02_score_loop_isa.txt, profiles/r02_ubench_valu.txt"}
+                      "floor_ms_per_launch": point_evals / issue_peak * 1e3,
+                      "frac_of_kernel_ms": point_evals / issue_peak * 1e3 / kern_ms,
+                      "what": "issue time of the score loop's own instruction mix on 1024 SIMDs (a shorter loop lowers it): a tuning "
+                              "figure, not the roofline",
+                      "source": "profiles/r02_isa_mix.json (scripts/isa_mix.py), profiles/r02_score_loop_isa.txt, profiles/r02_ubench_valu.txt"}
     r["hbm_effective"] = {"achieved": hbm_equiv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_equiv_gbs / HBM_PEAK_GBS,
                           "algorithmic_bytes_per_launch": algo_bytes,
                           "note": "SURVEY 8(d)'s streaming-equivalent accounting: 40 B per point evaluation (16 B point + 24 B cell "
@@ -380,7 +434,7 @@ def _pmc_traffic_bytes():
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 per the
     gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE; separate --pmc runs, scripts/pmc.sh).  A profile of
     THIS workload measured on MI355X, not collected live (rocprofv3 cannot wrap the timed run); null if absent."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         d = _load_json(name)
         try:
             d = d["derived"]

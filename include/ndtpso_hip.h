@@ -110,6 +110,19 @@ const char *ndtpso_last_error(const ndtpso_ctx *ctx);
 /* hipStream_t to enqueue on (NULL = the context's own stream) */
 int ndtpso_set_stream(ndtpso_ctx *ctx, void *hip_stream);
 int ndtpso_synchronize(ndtpso_ctx *ctx);
+/* Batches in flight.  depth 1 (default): every call is enqueued on the context's stream, one after the other.
+ * depth 2: consecutive ndtpso_align_pairs_dev calls (batches of more pairs than half the device's compute units) run
+ * on two internal streams with their own workspaces, so that the next batch's workgroups fill the compute units the
+ * previous launch's tail leaves idle (one launch lasts as long as its slowest alignment).  Each call still starts
+ * after everything enqueued on the context's stream before it (its inputs), but its OUTPUTS are ordered before later
+ * work on the context's stream only by ndtpso_pipeline_flush / ndtpso_synchronize -- until then neither the inputs
+ * nor the outputs of a call in flight may be touched, and two calls in flight need distinct output buffers.
+ * The results do not depend on the depth (each alignment is its own workgroup).  Reference: none -- the reference
+ * aligns one pair at a time (ndtpso_slam_node.cpp:194); this is the batch path of BASELINE configs 3/4. */
+int ndtpso_set_pipeline_depth(ndtpso_ctx *ctx, int depth);
+/* The context's stream waits (device-side, the host does not block) for the calls in flight, except the
+ * `keep_newest` most recent ones (0: for all of them). */
+int ndtpso_pipeline_flush(ndtpso_ctx *ctx, int keep_newest);
 /* number of std::rand() draws one alignment consumes: 3 + 3P + 6PI (core.cpp:14,84) */
 size_t ndtpso_rand_draws(const ndtpso_pso_config *cfg);
 

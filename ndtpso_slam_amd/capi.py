@@ -98,6 +98,7 @@ assert CELL_WINDOW_DTYPE.itemsize == C.sizeof(CellWindow) == 160
 
 EXPORTS = [
     "ndtpso_ctx_create", "ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_set_stream", "ndtpso_synchronize",
+    "ndtpso_set_pipeline_depth", "ndtpso_pipeline_flush",
     "ndtpso_rand_draws", "ndtpso_scan_to_points", "ndtpso_ref_from_points", "ndtpso_ref_from_scan",
     "ndtpso_ref_set_cells", "ndtpso_ref_get_cells", "ndtpso_points_to_cells", "ndtpso_scan_to_cells", "ndtpso_cells_build_windowed", "ndtpso_occupancy_values", "ndtpso_cost_batch", "ndtpso_align", "ndtpso_align_pairs",
     "ndtpso_align_pairs_dev", "ndtpso_align_pairs_footprint", "ndtpso_align_pairs_describe",
@@ -134,6 +135,8 @@ def load(build_if_missing: bool = True):
     L.ndtpso_last_error.restype = C.c_char_p
     L.ndtpso_set_stream.argtypes = [vp, vp]
     L.ndtpso_synchronize.argtypes = [vp]
+    L.ndtpso_set_pipeline_depth.argtypes = [vp, C.c_int]
+    L.ndtpso_pipeline_flush.argtypes = [vp, C.c_int]
     L.ndtpso_rand_draws.argtypes = [C.POINTER(PSOConfig)]
     L.ndtpso_rand_draws.restype = C.c_size_t
     L.ndtpso_scan_to_points.argtypes = [vp, fp, C.POINTER(ScanGeom), dp, dp, up]
@@ -229,6 +232,14 @@ class Context:
 
     def synchronize(self):
         self._chk(self._lib.ndtpso_synchronize(self._h))
+
+    def set_pipeline_depth(self, depth: int):
+        """1: one batch at a time on the context's stream; 2: consecutive align_pairs_dev calls overlap on the device
+        (ndtpso_set_pipeline_depth) -- outputs are ordered on the context's stream by pipeline_flush / synchronize."""
+        self._chk(self._lib.ndtpso_set_pipeline_depth(self._h, int(depth)))
+
+    def pipeline_flush(self, keep_newest: int = 0):
+        self._chk(self._lib.ndtpso_pipeline_flush(self._h, int(keep_newest)))
 
     # ---- K3 ----
     def scan_to_points(self, ranges, geom: ScanGeom, trans=(0.0, 0.0, 0.0)) -> np.ndarray:

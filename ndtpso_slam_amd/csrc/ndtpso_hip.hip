@@ -691,6 +691,22 @@ struct ndtpso_ctx {
   PinnedRing pinned;
   BeamDirs beam_dirs[4];  // cached beam directions of the scan geometries in use (beam_directions)
   unsigned beam_dirs_next = 0;
+  // Batches in flight (ndtpso_set_pipeline_depth): consecutive ndtpso_align_pairs_dev calls alternate between lanes --
+  // a stream of the context's own and the workspaces a launch writes (HBM swarms, fp64 table images, internal stats) --
+  // so that call k + 1's workgroups take the compute units call k's tail leaves idle (a launch lasts as long as its
+  // slowest workgroup, 8 % after the median one).
+  struct PipeLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    bool pending = false;
+    unsigned long long ticket = 0;  // number of the call it last ran
+    DevBuf ws, gate, ximg;
+  };
+  static constexpr int kMaxPipe = 2;
+  PipeLane lanes[kMaxPipe];
+  int pipe_depth = 1;
+  unsigned long long pipe_calls = 0;  // pipelined calls issued so far
+  hipEvent_t pipe_in = nullptr;       // "inputs of the call are ready on the context's stream"
 };
 
 namespace {
@@ -762,6 +778,8 @@ int beam_directions(ndtpso_ctx* c, const ndtpso_scan_geom* s, const double2** ou
       ::sincos((double)theta, &host[2 * i + 1], &host[2 * i]);
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // a launch still reading the slot's previous table
+    for (ndtpso_ctx::PipeLane& l : c->lanes)
+      if (l.stream) HIP_TRY(c, hipStreamSynchronize(l.stream));
     HIP_TRY(c, b.buf.reserve(host.size() * 8));
     HIP_TRY(c, hipMemcpy(b.buf.p, host.data(), host.size() * 8, hipMemcpyHostToDevice));
     b.n = s->n_beams;
@@ -1004,6 +1022,15 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
     b->release();
   for (BeamDirs& b : c->beam_dirs) b.buf.release();
   c->pinned.release();
+  for (ndtpso_ctx::PipeLane& l : c->lanes) {
+    if (l.stream) (void)hipStreamSynchronize(l.stream);
+    l.ws.release();
+    l.gate.release();
+    l.ximg.release();
+    if (l.done) (void)hipEventDestroy(l.done);
+    if (l.stream) (void)hipStreamDestroy(l.stream);
+  }
+  if (c->pipe_in) (void)hipEventDestroy(c->pipe_in);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1016,8 +1043,36 @@ int ndtpso_set_stream(ndtpso_ctx* c, void* s) {
   return NDTPSO_OK;
 }
 
+int ndtpso_pipeline_flush(ndtpso_ctx* c, int keep_newest) {
+  if (!c || keep_newest < 0) return NDTPSO_E_ARG;
+  for (ndtpso_ctx::PipeLane& l : c->lanes) {
+    if (!l.pending) continue;
+    if ((unsigned long long)keep_newest >= c->pipe_calls - l.ticket) continue;  // one of the newest calls: left in flight
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, l.done, 0));
+    l.pending = false;
+  }
+  return NDTPSO_OK;
+}
+
+int ndtpso_set_pipeline_depth(ndtpso_ctx* c, int depth) {
+  if (!c || depth < 1 || depth > ndtpso_ctx::kMaxPipe) return fail(c, NDTPSO_E_ARG, "pipeline depth must be 1 or 2");
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (int rc = ndtpso_pipeline_flush(c, 0)) return rc;
+  if (depth > 1) {
+    if (!c->pipe_in) HIP_TRY(c, hipEventCreateWithFlags(&c->pipe_in, hipEventDisableTiming));
+    for (int i = 0; i < depth; ++i) {
+      ndtpso_ctx::PipeLane& l = c->lanes[i];
+      if (!l.stream) HIP_TRY(c, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+      if (!l.done) HIP_TRY(c, hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+    }
+  }
+  c->pipe_depth = depth;
+  return NDTPSO_OK;
+}
+
 int ndtpso_synchronize(ndtpso_ctx* c) {
   if (!c) return NDTPSO_E_ARG;
+  if (int rc = ndtpso_pipeline_flush(c, 0)) return rc;
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NDTPSO_OK;
 }
@@ -1726,11 +1781,54 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   return NDTPSO_OK;
 }
 
+static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, const float* d_new,
+                                     const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess,
+                                     const double* d_dev, const ndtpso_pso_config* cfg, const uint32_t* d_seeds,
+                                     const int32_t* d_tables, int mode, double* d_pose, double* d_cost,
+                                     ndtpso_align_stats* d_stats);
+
 int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, const float* d_new,
                            const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess,
                            const double* d_dev, const ndtpso_pso_config* cfg, const uint32_t* d_seeds,
                            const int32_t* d_tables, int mode, double* d_pose, double* d_cost,
                            ndtpso_align_stats* d_stats) {
+  if (!c) return NDTPSO_E_ARG;
+  // one batch at a time (the default), or a batch too small to fill the device (those run as clusters of workgroups
+  // with per-context counters): on the context's stream, behind whatever is still in flight
+  if (c->pipe_depth < 2 || n_pairs * 2u <= (uint32_t)c->n_cus) {
+    if (c->pipe_depth > 1)
+      if (int rc = ndtpso_pipeline_flush(c, 0)) return rc;
+    return align_pairs_dev_on_stream(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode,
+                                     d_pose, d_cost, d_stats);
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  ndtpso_ctx::PipeLane& lane = c->lanes[c->pipe_calls % (unsigned)c->pipe_depth];
+  // the lane's previous call is ordered before this one by the lane's stream; the inputs by an event of the caller's
+  HIP_TRY(c, hipEventRecord(c->pipe_in, c->stream));
+  HIP_TRY(c, hipStreamWaitEvent(lane.stream, c->pipe_in, 0));
+  hipStream_t caller = c->stream;
+  c->stream = lane.stream;
+  std::swap(c->ws, lane.ws);
+  std::swap(c->gate, lane.gate);
+  std::swap(c->ximg, lane.ximg);
+  const int rc = align_pairs_dev_on_stream(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables,
+                                           mode, d_pose, d_cost, d_stats);
+  std::swap(c->ws, lane.ws);
+  std::swap(c->gate, lane.gate);
+  std::swap(c->ximg, lane.ximg);
+  c->stream = caller;
+  if (rc != NDTPSO_OK) return rc;
+  HIP_TRY(c, hipEventRecord(lane.done, lane.stream));
+  lane.pending = true;
+  lane.ticket = c->pipe_calls++;
+  return NDTPSO_OK;
+}
+
+static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, const float* d_new,
+                                     const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess,
+                                     const double* d_dev, const ndtpso_pso_config* cfg, const uint32_t* d_seeds,
+                                     const int32_t* d_tables, int mode, double* d_pose, double* d_cost,
+                                     ndtpso_align_stats* d_stats) {
   if (!c || !d_ref || !d_new || !d_guess || !d_dev || !d_pose || (!d_seeds && !d_tables))
     return fail(c, NDTPSO_E_ARG, "null argument");
   if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64 && mode != NDTPSO_SCORE_EXACT) return fail(c, NDTPSO_E_ARG, "bad score mode");

@@ -175,9 +175,9 @@ __host__ __device__ inline void make_chol(double a, double b, double c, double d
 // the largest |coefficient|, the Hessenberg step is the identity), computeFromHessenberg / findSmallSubdiagEntry,
 // splitOffTwoRows (p, q, z, one Givens rotation applied on the left and on the right), unscale, EigenSolver::compute --
 // so that the larger eigenvalue, which becomes the determinant of a thin cell (.001 * large^2), carries Eigen's
-// roundings and not those of a closed form (a few ulp apart in 11 % of the cells of the synthetic world).  Same
-// function, line by line, as oracle/ndtpso_oracle.c:orc_eigen_eigenvalues_2x2 (variant 0).  fp64 division and sqrt
-// are correctly rounded on the device and the library is built with -ffp-contract=off.
+// roundings and not those of a closed form (a few ulp apart in 11 % of the cells of the synthetic world).  The tests'
+// CPU restatement of the reference carries the same function, line by line.  fp64 division and sqrt are correctly
+// rounded on the device and the library is built with -ffp-contract=off.
 __device__ __forceinline__ void eigen_givens(double p, double q, double& c, double& s) {  // JacobiRotation::makeGivens, real case
   if (q == 0.) {
     c = p < 0. ? -1. : 1.;
