@@ -102,6 +102,10 @@ typedef struct {
   uint32_t t_start, t_end; /* low 32 bits of the device's 100 MHz real-time counter when the alignment's workgroup
                               started / finished (fused pairs kernel; load-balance diagnostics) */
 } ndtpso_align_stats;
+/* `status` is two fields in one word: test NDTPSO_STATUS_FLAGS(s) != 0 for "something went wrong", never the raw word
+ * (in NDTPSO_SCORE_EXACT the upper half counts arbitrated comparisons of a perfectly good alignment). */
+#define NDTPSO_STATUS_FLAGS(status) ((uint32_t)(status) & 0xffffu)
+#define NDTPSO_STATUS_ARBITRATED(status) ((uint32_t)(status) >> 16)
 
 /* ---- context --------------------------------------------------------- */
 int ndtpso_ctx_create(int device, ndtpso_ctx **out);
@@ -319,6 +323,29 @@ typedef struct {
 } ndtpso_pairs_plan;
 int ndtpso_align_pairs_describe(const ndtpso_scan_geom *geom, const ndtpso_grid *grid, const ndtpso_pso_config *cfg,
                                 int score_mode, uint32_t n_pairs, ndtpso_pairs_plan *out);
+
+/* ---- one batch on several devices, one process (BASELINE config 4) ---------------------------------
+ * The pairs are independent (each is one NDTFrame::align of a recorded pair, ndtpso_slam_node.cpp:194; the reference's
+ * own parallelism is an OpenMP loop over particles, core.cpp:81), so the batch is partitioned by contiguous index
+ * range -- device d of G takes ndtpso_shard_range(n_pairs, d, G) -- and each device runs ndtpso_align_pairs_dev on its
+ * shard in a context and stream of its own, with no traffic between devices.  The only exchange is ONE ncclAllGather
+ * (RCCL over xGMI, single-process communicator from ncclCommInitAll) of pose + cost, 4 doubles per pair, after which
+ * every device holds the poses of the whole batch; device 0's copy is returned.  Results are those of
+ * ndtpso_align_pairs on the same arguments, bit for bit, whatever the number of devices.
+ * RCCL is loaded at run time: ndtpso_shard_group_create returns NDTPSO_E_HIP when it (or a listed device) is absent.
+ * A group is used by one host thread at a time; buffers are host memory (the scatter is part of the call). */
+typedef struct ndtpso_shard_group ndtpso_shard_group;
+int ndtpso_shard_group_create(const int *devices, int n_devices, ndtpso_shard_group **out);
+void ndtpso_shard_group_destroy(ndtpso_shard_group *group);
+int ndtpso_shard_group_size(const ndtpso_shard_group *group);
+const char *ndtpso_shard_last_error(const ndtpso_shard_group *group);
+/* [first, last) of device `rank` of `n_devices`: contiguous, sizes differing by at most one */
+void ndtpso_shard_range(uint32_t n_pairs, int rank, int n_devices, uint32_t *first, uint32_t *last);
+int ndtpso_align_pairs_sharded(ndtpso_shard_group *group, uint32_t n_pairs, const float *ref_ranges,
+                               const float *new_ranges, const ndtpso_scan_geom *geom, const ndtpso_grid *grid,
+                               const double *guess, const double *deviation, const ndtpso_pso_config *cfg,
+                               const uint32_t *seeds, const int32_t *rand_tables, int score_mode, double *out_pose,
+                               double *out_cost, ndtpso_align_stats *stats);
 
 #ifdef __cplusplus
 }

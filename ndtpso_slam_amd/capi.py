@@ -106,6 +106,8 @@ EXPORTS = [
     "ndtpso_map_create", "ndtpso_map_destroy", "ndtpso_map_reset", "ndtpso_map_clear", "ndtpso_map_mark_unbuilt", "ndtpso_map_insert", "ndtpso_map_insert_host",
     "ndtpso_map_build", "ndtpso_map_speculate_build", "ndtpso_map_align", "ndtpso_map_cost", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
     "ndtpso_map_get_occupancy",
+    "ndtpso_shard_group_create", "ndtpso_shard_group_destroy", "ndtpso_shard_group_size", "ndtpso_shard_last_error",
+    "ndtpso_shard_range", "ndtpso_align_pairs_sharded",
 ]
 
 _lib = None
@@ -181,10 +183,20 @@ def load(build_if_missing: bool = True):
     L.ndtpso_map_get_cells.argtypes = [vp, C.POINTER(CellRow), C.c_uint32, up]
     L.ndtpso_map_get_points.argtypes = [vp, C.c_int, dp, C.c_uint64, C.POINTER(C.c_uint64)]
     L.ndtpso_map_get_occupancy.argtypes = [vp, C.POINTER(C.c_int8), C.c_uint64, up, up, up]
+    L.ndtpso_shard_group_create.argtypes = [ip, C.c_int, C.POINTER(vp)]
+    L.ndtpso_shard_group_destroy.argtypes = [vp]
+    L.ndtpso_shard_group_destroy.restype = None
+    L.ndtpso_shard_group_size.argtypes = [vp]
+    L.ndtpso_shard_last_error.argtypes = [vp]
+    L.ndtpso_shard_last_error.restype = C.c_char_p
+    L.ndtpso_shard_range.argtypes = [C.c_uint32, C.c_int, C.c_int, up, up]
+    L.ndtpso_shard_range.restype = None
+    L.ndtpso_align_pairs_sharded.argtypes = [vp, C.c_uint32, fp, fp, C.POINTER(ScanGeom), C.POINTER(Grid), dp, dp,
+                                             C.POINTER(PSOConfig), up, ip, C.c_int, dp, dp, vp]
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_rand_draws", "ndtpso_points_destroy",
-                        "ndtpso_map_destroy"):
+                        "ndtpso_map_destroy", "ndtpso_shard_group_destroy", "ndtpso_shard_last_error", "ndtpso_shard_range"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -372,6 +384,61 @@ class Context:
         self._chk(self._lib.ndtpso_align_pairs_dev(self._h, int(n_pairs), vp(d_ref), vp(d_new), C.byref(geom),
                                                    C.byref(grid), vp(d_guess), vp(d_dev), C.byref(cfg), vp(d_seeds),
                                                    vp(d_tables), mode, vp(d_pose), vp(d_cost), vp(d_stats)))
+
+
+class ShardGroup:
+    """ndtpso_shard_group: one batch of scan pairs on several devices from one process -- contiguous index ranges, one
+    context and stream per device, ONE ncclAllGather of the poses (include/ndtpso_hip.h).  Raises when RCCL or a device
+    is missing: nothing is computed anywhere else."""
+
+    def __init__(self, devices):
+        self._lib = load()
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        h = C.c_void_p()
+        rc = self._lib.ndtpso_shard_group_create(_p(devs, C.c_int32), int(devs.size), C.byref(h))
+        if rc != OK:
+            raise NdtpsoError(rc, "ndtpso_shard_group_create failed (devices %s): a device or RCCL is missing" % list(devs))
+        self._h = h
+
+    def size(self) -> int:
+        return int(self._lib.ndtpso_shard_group_size(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ndtpso_shard_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def align_pairs(self, ref_ranges, new_ranges, geom: ScanGeom, grid: Grid, guess, deviation, cfg: PSOConfig,
+                    seeds=None, rand_tables=None, mode=SCORE_EXACT):
+        ref = np.ascontiguousarray(ref_ranges, dtype=np.float32)
+        new = np.ascontiguousarray(new_ranges, dtype=np.float32)
+        B = ref.shape[0]
+        assert ref.shape == new.shape == (B, geom.n_beams)
+        guess = np.ascontiguousarray(np.broadcast_to(_f64(guess), (B, 3)))
+        deviation = np.ascontiguousarray(np.broadcast_to(_f64(deviation), (B, 3)))
+        pose, cost, stats = np.empty((B, 3)), np.empty(B), np.zeros(B, dtype=STATS_DTYPE)
+        sd = np.ascontiguousarray(seeds, dtype=np.uint32) if seeds is not None else None
+        tb = np.ascontiguousarray(rand_tables, dtype=np.int32) if rand_tables is not None else None
+        rc = self._lib.ndtpso_align_pairs_sharded(
+            self._h, B, _p(ref, C.c_float), _p(new, C.c_float), C.byref(geom), C.byref(grid), _p(guess, C.c_double),
+            _p(deviation, C.c_double), C.byref(cfg), _p(sd, C.c_uint32) if sd is not None else None,
+            _p(tb, C.c_int32) if tb is not None else None, mode, _p(pose, C.c_double), _p(cost, C.c_double),
+            stats.ctypes.data_as(C.c_void_p))
+        if rc != OK:
+            raise NdtpsoError(rc, self._lib.ndtpso_shard_last_error(self._h).decode())
+        return pose, cost, stats
+
+
+def shard_range(n_pairs: int, rank: int, n_devices: int):
+    a, b = C.c_uint32(), C.c_uint32()
+    load().ndtpso_shard_range(int(n_pairs), int(rank), int(n_devices), C.byref(a), C.byref(b))
+    return a.value, b.value
 
 
 def align_pairs_footprint(geom: ScanGeom, grid: Grid, cfg: PSOConfig):

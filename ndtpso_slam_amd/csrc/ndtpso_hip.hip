@@ -562,6 +562,9 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
            (tk[3] - tk[2]) * 0.01, (tk[4] - tk[3]) * 0.01);
 #endif
 
+#ifdef NDTPSO_PHASE_BUDGET
+  const uint32_t t_setup_end = (uint32_t)wall_clock64();
+#endif
   EvalCtx E = make_eval_ctx(g, wn, L, dn);
   E.light = CLUSTER ? 0 : ps.light;
   E.guard_lds = (unsigned)(uintptr_t)(const DenseGuard __attribute__((address_space(3)))*)&lds_ctrl(L.ctrl_off)->guard;
@@ -583,6 +586,12 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     stats[b].status |= hdr->status;
     stats[b].t_start = t_start;
     stats[b].t_end = (uint32_t)wall_clock64();
+#ifdef NDTPSO_PHASE_BUDGET
+    if (!CLUSTER && blockIdx.x < kBudgetMaxBlocks) {
+      g_budget[(size_t)blockIdx.x * 16 + 0] = t_setup_end - t_start;
+      g_budget[(size_t)blockIdx.x * 16 + 15] = stats[b].t_end - t_start;
+    }
+#endif
   }
 }
 
@@ -1920,6 +1929,17 @@ int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges,
   return NDTPSO_OK;
 }
 
+#ifdef NDTPSO_PHASE_BUDGET
+// diagnostic builds only (scripts/phase_budget.py): the per-workgroup phase times of the last fused-pairs launches
+int ndtpso_profile_phase_budget(uint32_t* out, uint32_t n_blocks) {
+  if (!out || n_blocks > kBudgetMaxBlocks) return NDTPSO_E_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return NDTPSO_E_HIP;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_budget), (size_t)n_blocks * 16 * sizeof(uint32_t)) != hipSuccess) return NDTPSO_E_HIP;
+  return NDTPSO_OK;
+}
+#endif
+
 }  // extern "C"
 
 #include "ndtpso_map.inc"
+#include "ndtpso_shard.inc"

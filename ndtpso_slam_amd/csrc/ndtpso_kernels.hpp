@@ -1766,6 +1766,30 @@ __device__ unsigned long long g_phase_last;
 #define NDTPSO_PHASE_MARK(k) do { } while (0)
 #endif
 
+// NDTPSO_PHASE_BUDGET (diagnostic builds only, scripts/phase_budget.py): every workgroup of the fused pairs kernel
+// accounts for its own time, phase by phase, on the 100 MHz real-time counter -- contiguous marks, so that the phases
+// of a workgroup sum to its duration -- and leaves 16 words in g_budget[blockIdx.x]:
+//   0 setup (scan A, window, table, scan B)   1 swarm initialisation   2 generator at the top of an iteration
+//   3 proposals (+ barrier)   4 wave 0's own evaluations   5 wave 0's slice of the generator   6 wave 0's wait at the
+//   round's barrier   7 arbitration   8 commits (+ gbest barriers)   9 end of iteration   10 final fp64 cost
+//   12 / 13 / 14 the same as 4 / 5 / 6 seen from wave 1 (a wave with two items per round)   15 the whole workgroup
+#ifdef NDTPSO_PHASE_BUDGET
+constexpr unsigned kBudgetMaxBlocks = 8192;
+__device__ unsigned g_budget[kBudgetMaxBlocks * 16];
+#define NDTPSO_PB_DECL                          \
+  unsigned long long pb_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
+  unsigned long long pb_last = wall_clock64()
+#define NDTPSO_PB(k)                                   \
+  do {                                                 \
+    const unsigned long long now__ = wall_clock64();   \
+    pb_t[k] += now__ - pb_last;                        \
+    pb_last = now__;                                   \
+  } while (0)
+#else
+#define NDTPSO_PB_DECL do { } while (0)
+#define NDTPSO_PB(k) do { } while (0)
+#endif
+
 struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, doubles per exchange buffer
   int absent;           // test hook: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout
@@ -1860,6 +1884,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #endif
   static_assert(!ARB || (MODE == kScoreF32 && path_is_dense(PATH)), "the exact mode runs on the fp32-score dense kernels");
 
+  NDTPSO_PB_DECL;
   // ---- swarm initialisation: core.cpp:58-69 ----
   if (tid == 0) sh->tiny = sh->timed_out = 0;
   if constexpr (ARB) {
@@ -2035,8 +2060,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   const bool overlapped = gen && sw.raw2 != nullptr, sliced = overlapped && !CLUSTER && ps.light;
   const int n_draw = 6 * P;
   const int slice = 30 * max(1, (n_draw + 30 * ((P + ps.G - 1) / ps.G) - 1) / (30 * ((P + ps.G - 1) / ps.G)));
+  NDTPSO_PB(1);
   for (int it = 0; it < ps.I; ++it) {
     NDTPSO_PSO_MARK(4);
+    NDTPSO_PB(9);
     if (gen) {
       if (overlapped && it > 0) {  // what the previous iteration's rounds left time for, and the rest now
         if (next_filled < n_draw) {
@@ -2053,6 +2080,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       }
     }
     NDTPSO_PSO_MARK(0);
+    NDTPSO_PB(2);
     const int32_t* draws = gen ? dcur : (prefetch ? sw.raw : (table + 3 * S + (size_t)it * 6 * P));
     if (prefetch && it + 1 < ps.I) {
       const int32_t* next = table + 3 * S + (size_t)(it + 1) * 6 * P;
@@ -2104,6 +2132,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         need_propose = false;
         __syncthreads();  // proposals (and the commits before them) visible to every wave
         NDTPSO_PSO_MARK(1);
+        NDTPSO_PB(3);
       }
 #if NDTPSO_ALTERNATE_PRIO
       // Two workgroups share a CU.  VALU issue is arbitrated by priority, then age, so the earlier-dispatched
@@ -2128,6 +2157,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
                                       &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
                                       dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
       if (gen_here) next_filled = n_draw;
+      NDTPSO_PB(4);
       if constexpr (!CLUSTER) {
         // the light wave's other job: a slice of the next iteration's draws (published by the barriers that follow)
         if (sliced && it + 1 < ps.I && next_filled < n_draw) {
@@ -2141,8 +2171,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       }
       n_evals += (uint32_t)(hi_g - lo);
       n_rounds += 1;
+      NDTPSO_PB(5);
       __syncthreads();
       NDTPSO_PSO_MARK(2);
+      NDTPSO_PB(6);
       if (CLUSTER && sh->timed_out) {
         if (tid == 0 && stats && writer) stats->status |= kStatusClusterTimeout;
         return false;
@@ -2186,6 +2218,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           }
         }
       }
+      NDTPSO_PB(7);
       const int js = sh->jstar[slot];
       if (tid == 0) {
         sh->jstar[(grp + 2u) % 3u] = P;
@@ -2236,6 +2269,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         lo = hi_g;
       }
       NDTPSO_PSO_MARK(3);
+      NDTPSO_PB(8);
     }
     if (prefetch && it + 1 < ps.I) {  // every proposal of this iteration has read its draws (barriers above)
       if (tid < 6 * P) sw.raw[tid] = pre0;
@@ -2257,12 +2291,26 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     g_phase_ticks[0] = g_phase_ticks[1] = g_phase_ticks[2] = g_phase_ticks[3] = 0;
   }
 #endif
+  NDTPSO_PB(9);
   bool exact_cost = false;
 #ifndef NDTPSO_NO_FINAL_EXACT
   if constexpr (ARB) {
     {  // exact mode: the returned cost is the fp64 score of the returned pose (what the fp64 mode holds)
       exact_tasks_wg<PATH == 3>(&sh->xa, nullptr, 0, 2);
       exact_cost = true;
+    }
+  }
+#endif
+#ifdef NDTPSO_PHASE_BUDGET
+  NDTPSO_PB(10);
+  if (!CLUSTER && blockIdx.x < kBudgetMaxBlocks) {
+    unsigned* o = g_budget + (size_t)blockIdx.x * 16;
+    if (tid == 0)
+      for (int k = 1; k <= 10; ++k) o[k] = (unsigned)pb_t[k];
+    if (tid == 64) {
+      o[12] = (unsigned)pb_t[4];
+      o[13] = (unsigned)pb_t[5];
+      o[14] = (unsigned)pb_t[6];
     }
   }
 #endif

@@ -160,3 +160,105 @@ def test_bench_multi_rank_path_under_torch_distributed_run(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 1e4 and d["scaling"] == "weak"
     assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
+
+
+# ---- one process, several devices: the C-ABI's sharded entry point (ndtpso_align_pairs_sharded) --------------------
+
+def test_c_abi_shard_range_is_the_python_partition():
+    from ndtpso_slam_amd import capi, sharding
+    for n in (0, 1, 5, 7, 512, 4096, 4099):
+        for G in (1, 2, 3, 8):
+            for r in range(G):
+                assert capi.shard_range(n, r, G) == sharding.shard_range(n, r, G)
+
+
+def test_shard_group_fails_loudly_without_a_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from ndtpso_slam_amd import capi
+    with pytest.raises(capi.NdtpsoError):
+        capi.ShardGroup([0])
+    with pytest.raises(capi.NdtpsoError):
+        capi.ShardGroup([0, 0])
+
+
+def write_batch_file(path, p, grid_m, cell_side, I, P, mode, guess=(0.0, 0.0, 0.0), deviation=(0.1, 0.1, 3.1415e-3)):
+    """The batch format host/replay/batch_sharded.cpp reads."""
+    import struct
+    B = p.n_pairs
+    with open(path, "wb") as f:
+        f.write(b"NDTB")
+        f.write(struct.pack("<III", 1, B, p.n_beams))
+        f.write(struct.pack("<ffff", float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1))
+        f.write(struct.pack("<IId", grid_m, grid_m, cell_side))
+        f.write(struct.pack("<ii", I, P))
+        f.write(struct.pack("<dddd", 0.8, 2.0, 2.0, 1.0))
+        f.write(struct.pack("<i", mode))
+        f.write(np.ascontiguousarray(p.ref_ranges, dtype=np.float32).tobytes())
+        f.write(np.ascontiguousarray(p.new_ranges, dtype=np.float32).tobytes())
+        f.write(np.tile(np.asarray(guess, dtype=np.float64), (B, 1)).tobytes())
+        f.write(np.tile(np.asarray(deviation, dtype=np.float64), (B, 1)).tobytes())
+        f.write(np.ascontiguousarray(p.seeds, dtype=np.uint32).tobytes())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_pairs", [3, 130, 301])
+def test_sharded_entry_point_equals_align_pairs(ctx, n_pairs):
+    """ndtpso_align_pairs_sharded over every device of the box (one on the test box: the n = 1 case -- scatter, launch,
+    a one-rank ncclAllGather through RCCL, copy back) returns ndtpso_align_pairs' poses, costs and statistics bit for
+    bit; with more devices the same assertion covers the partition and the gather order."""
+    import torch
+    from ndtpso_slam_amd import capi, synth
+    p = synth.make_pairs(n_pairs, seed=31)
+    geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+    grid, cfg = capi.Grid(60, 60, 0.5), capi.PSOConfig.make(12, 20)
+    dev = (0.1, 0.1, 3.1415e-3)
+    want, wcost, wst = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+    for devices in ([0], list(range(torch.cuda.device_count()))):
+        g = capi.ShardGroup(devices)
+        assert g.size() == len(devices)
+        for _ in range(2):   # a group is reusable
+            got, cost, st = g.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+            assert np.array_equal(got, want) and np.array_equal(cost, wcost)
+            assert np.array_equal(st["status"], wst["status"]) and np.array_equal(st["cost_evals"], wst["cost_evals"])
+        g.close()
+
+
+@pytest.mark.gpu
+def test_cpp_batch_driver_on_all_devices(tmp_path, ctx):
+    """host/replay/batch_sharded (C++, the C-ABI only) on a batch file: same poses as the Python binding."""
+    from ndtpso_slam_amd import capi, synth
+    exe = os.path.join(ROOT, "host", "replay", "batch_sharded")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s", "replay/batch_sharded"])
+    p = synth.make_pairs(140, seed=52)
+    batch, out = str(tmp_path / "batch.bin"), str(tmp_path / "poses.bin")
+    write_batch_file(batch, p, 60, 0.5, 10, 16, capi.SCORE_EXACT)
+    r = subprocess.run([exe, batch, out, "all", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    raw = np.fromfile(out, dtype=np.float64)
+    got, gcost = raw[:3 * 140].reshape(140, 3), raw[3 * 140:]
+    geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+    want, wcost, _ = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, capi.Grid(60, 60, 0.5), (0, 0, 0), (0.1, 0.1, 3.1415e-3),
+                                     capi.PSOConfig.make(10, 16), seeds=p.seeds, mode=capi.SCORE_EXACT)
+    assert np.array_equal(got, want) and np.array_equal(gcost, wcost)
+    import json
+    info = json.loads(r.stdout.strip().splitlines()[-1])
+    assert info["pairs"] == 140 and info["devices"] >= 1 and info["flagged"] == 0
+
+
+def test_cpp_batch_driver_refuses_to_run_without_a_device(tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from ndtpso_slam_amd import capi, synth
+    exe = os.path.join(ROOT, "host", "replay", "batch_sharded")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "host"), "-s", "replay/batch_sharded"])
+    p = synth.make_pairs(2, n_beams=91, seed=1)
+    batch = str(tmp_path / "batch.bin")
+    write_batch_file(batch, p, 60, 0.5, 3, 4, capi.SCORE_EXACT)
+    r = subprocess.run([exe, batch, str(tmp_path / "o.bin"), "all"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "nothing is computed on the CPU" in r.stderr
+    assert not os.path.exists(str(tmp_path / "o.bin"))
