@@ -47,8 +47,11 @@ extern "C" {
 #define NDTPSO_SCORE_F64 1 /* everything in fp64, reference operation order */
 /* NDTPSO_SCORE_EXACT: the results of NDTPSO_SCORE_F64 at (nearly) the speed of NDTPSO_SCORE_F32.  The PSO only ever
  * COMPARES costs (core.cpp:63,94,97), so the fp32 score decides every comparison whose two sides are further apart
- * than 2e-5 relative -- three orders of magnitude above its error -- and the rest ("near-ties", 0.1-1 per 70 x 70
- * alignment) are arbitrated with the fp64 score of the poses involved, evaluated exactly as SCORE_F64 evaluates them;
+ * than the margin tau = max(5e-6 x |gbest cost|, 7e-7 x points of the scan) -- the fp32 form's rounding error is below
+ * 2.95e-7 per point whatever the cells look like (derivation: ndtpso_kernels.hpp verify_pose_wave), i.e.
+ * below tau / 2 for ANY input, so a comparison outside the margin falls as it would in fp64 by proof, not by luck
+ * (tests/test_gpu_margin.py checks the inequality for every evaluation with a diagnostic build) -- and the rest
+ * ("near-ties", about 0.5 per 70 x 70 alignment) are arbitrated with the fp64 score of the poses involved, evaluated exactly as SCORE_F64 evaluates them;
  * the returned cost is the fp64 score of the returned pose.  Pose and cost equal SCORE_F64's bit for bit (tests:
  * every pair of BASELINE configs 3, 4 and 5).  Where the fp32 kernel cannot arbitrate (tables too large for the dense
  * LDS form, degenerate overlaps, swarms of near-identical costs) the fp64-score kernel does the alignment.

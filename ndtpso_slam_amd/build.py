@@ -80,5 +80,48 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+# Diagnostic builds of the same sources (never loaded by the product path; NDTPSO_LIB selects one for a process):
+#   budget  -DNDTPSO_PHASE_BUDGET   per-workgroup, per-phase clocks (scripts/phase_budget.py)
+#   verify  -DNDTPSO_VERIFY_MARGIN  every fp32 score checked against its fp64 value and an a-priori error bound
+#                                   (scripts/verify_margin.py, tests/test_gpu_margin.py)
+VARIANTS = {"budget": ["-DNDTPSO_PHASE_BUDGET"], "verify": ["-DNDTPSO_VERIFY_MARGIN"]}
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(LIB_DIR, "libndtpso_hip_%s.so" % name)
+
+
+def build_variant(name: str, force: bool = False, verbose: bool = False) -> str:
+    """Compile a diagnostic variant next to the shipped library (content-stamped like it)."""
+    out, stamp = variant_path(name), variant_path(name) + ".sources"
+    want = _sources_hash() + " " + " ".join(VARIANTS[name])
+    fresh = False
+    if os.path.exists(out) and not force:
+        try:
+            with open(stamp) as f:
+                fresh = f.read().strip() == want
+        except OSError:
+            fresh = False
+    if not fresh:
+        os.makedirs(LIB_DIR, exist_ok=True)
+        tmp = "%s.%d.tmp" % (out, os.getpid())
+        cmd = [hipcc()] + FLAGS + VARIANTS[name] + [SRC, "-o", tmp]
+        if verbose:
+            print(" ".join(cmd[:-1] + [out]))
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp, out)
+            with open(stamp, "w") as f:
+                f.write(want + "\n")
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return out
+
+
 if __name__ == "__main__":
-    print(build_hip(force=True, verbose=True))
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] in VARIANTS:
+        print(build_variant(sys.argv[1], force=True, verbose=True))
+    else:
+        print(build_hip(force=True, verbose=True))

@@ -569,6 +569,9 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   E.light = CLUSTER ? 0 : ps.light;
   E.guard_lds = (unsigned)(uintptr_t)(const DenseGuard __attribute__((address_space(3)))*)&lds_ctrl(L.ctrl_off)->guard;
   if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg);
+#ifdef NDTPSO_VERIFY_MARGIN
+  if constexpr (ARB && !CLUSTER) E.xa = &lds_ctrl(L.ctrl_off)->xa;
+#endif
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
   if (L.swarm_global) {  // (two copies: see k_align)
     const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P, ARB, true);
@@ -1928,6 +1931,21 @@ int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges,
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return NDTPSO_OK;
 }
+
+#ifdef NDTPSO_VERIFY_MARGIN
+// diagnostic builds only (tests/test_gpu_margin.py): per alignment of the fused-pairs launches since the last reset, 16 doubles
+int ndtpso_profile_verify_margin(double* out, uint32_t n_blocks, int reset) {
+  if (n_blocks > kVerifyMaxBlocks) return NDTPSO_E_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return NDTPSO_E_HIP;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_verify), (size_t)n_blocks * 16 * sizeof(double)) != hipSuccess) return NDTPSO_E_HIP;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_verify)) != hipSuccess || hipMemset(p, 0, sizeof(double) * 16 * kVerifyMaxBlocks) != hipSuccess)
+      return NDTPSO_E_HIP;
+  }
+  return NDTPSO_OK;
+}
+#endif
 
 #ifdef NDTPSO_PHASE_BUDGET
 // diagnostic builds only (scripts/phase_budget.py): the per-workgroup phase times of the last fused-pairs launches

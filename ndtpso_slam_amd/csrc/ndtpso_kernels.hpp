@@ -85,18 +85,35 @@ struct TableOut {  // same arrays, writable (table build); null = not wanted
 // staging window (plus one empty border row/column on the low sides) holding the LDS address / 16 of the
 // cell's 32-byte record; cells that are not built point at a null record whose exponent is -inf, so a miss
 // needs no mask, select or compare.  The table sits at LDS offset 0: entry address = cell index * 2.
-struct __attribute__((aligned(16))) DenseMean {
-  double mgx, mgy;        // NDTCell::mean in cell units, relative to the dense window origin
+// Record of a built cell in the dense form (round 3).  With (L11, L21, L22) the Cholesky factor of 0.5 log2(e) s_inv_covar
+// in cell units and (mgx, mgy) the cell's mean in window cell coordinates, the exponent of a point at table coordinates
+// (gx, gy) is q = a^2 + b^2 with
+//     a = L11 d0 + L21 d1 = L11 (d0 + r d1),   r = L21 / L11      ->  a = l11 * float(fma(r, gy, gx) + alpha),  alpha = -(mgx + r mgy)
+//     b = L22 d1                                                  ->  b = l22 * float(gy - mgy)
+// The inner sum d0 + r d1 is formed in fp64 straight from the table coordinates and only then rounded to fp32; the
+// magnitudes l11, l22 are fp32.  Rounds 1-2 rounded d0, d1 and all three factors to fp32 and formed `a` in fp32: in a
+// thin cell that is rotated against the axes the two products of `a` cancel, so its rounding error was relative to
+// |L11 d0| + |L21 d1|, up to a hundred times |a|, and the score's error depended on the shape of the cells.  Here the
+// cancellation happens in fp64 -- the DIRECTION (1, r) of the thin axis is kept in fp64, only the scale is fp32 -- so
+// `a` and `b` are each off by three fp32 roundings of themselves and the error of a term is bounded whatever the cell
+// looks like (eval_items / verify_pose_wave / DESIGN 3.6).  |r| <= sqrt(1000): the determinant clamp of
+// s_calc_covar_inverse (ndtcell.cpp:103-105) bounds the form's condition number.
+// Same footprint as before: two 16-byte parts, A = {r, alpha} and B = {mgy, l11, l22}; one more fp64 operation and one
+// fp32 operation less per point.  Records live in blocks of sixteen -- sixteen parts A, then the sixteen parts B 256
+// bytes behind (an immediate offset) -- so that the 16-lane groups of a ds_read_b128 see sixteen different 16-byte
+// positions of a 256-byte LDS row.
+// Record 0 is the null record every non-built cell points at: alpha = +inf, l11 = 1 -> a = +inf -> exp2(-inf) = 0, so
+// a miss needs no mask, select or compare.  A cell whose inverse covariance has no Cholesky factor (make_chol) gets
+// alpha = NaN: a pose that touches it scores NaN and is handed to the fp64 form.
+struct __attribute__((aligned(16))) DenseRecA {
+  double r, alpha;
 };
-struct __attribute__((aligned(16))) DenseChol {
-  float l11, l21, l22, w; // Cholesky factor of 0.5*log2(e)*s_inv_covar scaled to cell units; w: 0, or +inf for the null record
+struct __attribute__((aligned(16))) DenseRecB {
+  double mgy;
+  float l11, l22;
 };
-static_assert(sizeof(DenseMean) == 16 && sizeof(DenseChol) == 16, "dense record halves must be 16 bytes");
-// Record k (0 = the null record, built cell slot s = record s + 1) lives in blocks of sixteen: sixteen means, then the
-// sixteen factors -- the factor kDenseCholOff bytes behind its mean (an immediate offset of the second ds_read_b128).
-// A 16-lane group of a ds_read_b128 conflicts when two different records sit at the same 16-byte position of a
-// 256-byte LDS row: with mean and factor side by side (32-byte records) there were 8 positions, this way there are 16.
-constexpr unsigned kDenseCholOff = 256;
+static_assert(sizeof(DenseRecA) == 16 && sizeof(DenseRecB) == 16, "dense record parts must be 16 bytes");
+constexpr unsigned kDenseRecBOff = 256;
 __host__ __device__ inline unsigned dense_rec_pos(unsigned k) { return ((k >> 4) << 9) + ((k & 15u) << 4); }
 __host__ __device__ inline unsigned dense_rec_index(unsigned pos) { return ((pos >> 9) << 4) + ((pos >> 4) & 15u); }
 __host__ __device__ inline int dense_rec_bytes(int n_records) { return 512 * ((n_records + 15) / 16); }
@@ -150,7 +167,8 @@ __host__ __device__ inline int image_bytes(int n_words, int cap) { return image_
 // the fp32 form, and the callers hand NaN scores to the fp64 form, which evaluates the reference's expression as
 // it stands (NaN, or an exponential above 1).  Negative values at rounding level (a wall: rank-one covariance,
 // sliding-window cancellation) are clamped as before.
-__host__ __device__ inline void make_chol(double a, double b, double c, double d, float out[4], double scale = 1.) {
+// make_chol_d: the factor in fp64 (the dense records keep it so); returns whether the form has one.
+__host__ __device__ inline bool make_chol_d(double a, double b, double c, double d, double out[3], double scale = 1.) {
   const double k = 0.72134752044448170368;  // 0.5 * log2(e)
   const double A = k * a, B = k * (0.5 * (b + c)), D = k * d;
   const double T = fabs(A) + fabs(D), tol = 1e-12 * T;
@@ -163,9 +181,17 @@ __host__ __device__ inline void make_chol(double a, double b, double c, double d
   }
   const double rem = D - l21 * l21;
   const double l22 = rem > 0. ? sqrt(rem) : 0.;
-  out[0] = (float)(l11 * scale);
-  out[1] = (float)(l21 * scale);
-  out[2] = (float)(l22 * scale);
+  out[0] = l11 * scale;
+  out[1] = l21 * scale;
+  out[2] = l22 * scale;
+  return ok;
+}
+__host__ __device__ inline void make_chol(double a, double b, double c, double d, float out[4], double scale = 1.) {
+  double l[3];
+  const bool ok = make_chol_d(a, b, c, d, l, scale);
+  out[0] = (float)l[0];
+  out[1] = (float)l[1];
+  out[2] = (float)l[2];
   out[3] = ok ? 0.f : __builtin_nanf("");
 }
 
@@ -434,8 +460,9 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
 //
 // The window-relative cell coordinates come straight out of the transform:
 //   gx = x*C - y*S + TX,  C = cos/cs, S = sin/cs, TX = (tx + w/2)/cs - ox      (2 fp64 FMAs per axis)
-// and the Mahalanobis form is evaluated in cell units against the dense records (DenseMean, DenseChol).  Per point: 4 FMA, 2 cvt, 2 cmp,
-// mul+add, select, 3 LDS reads, 2 sub, 2 cvt, 5 fp32, exp2, and per four points one cvt + add.
+// and the Mahalanobis form is evaluated in cell units against the dense records (DenseRecA / B: a = l11 * float(fma(r, gy,
+// gx) + alpha), b = l22 * float(gy - mgy)).  Per point: 4 + 1 fp64 FMA, 2 fp64 adds, 2 cvt to the index, mad24, 3 LDS
+// reads, 2 cvt to fp32, 3 fp32 mul + 1 fma, exp2, and per four points three fp32 adds, one cvt + fp64 add.
 // For a power-of-two cell side floor((x + w/2)/cs) = floor(fl(x + w/2) * 2^k) and the scaling commutes with
 // rounding; for any other cell side 1/cs is rounded once more.  Either way gx is within ~1e-14 cells of the
 // reference's value, so only a point that close to a cell edge can bin differently (probability ~1e-7 per
@@ -513,27 +540,26 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   unsigned e[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) e[u] = *(lds_u16_t)(uintptr_t)(lin[u] << 1);
-  double2 m[U];
-  float4 f[U];
+  v2d_t ra[U], rb[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const unsigned r = BYTE ? e[u] : e[u] << 4;
-    const v2d_t mm = *(lds_d2_t)(uintptr_t)r;
-    const v4f_t ff = *(lds_f4_t)(uintptr_t)(r + kDenseCholOff);
-    m[u] = make_double2(mm.x, mm.y);
-    f[u] = make_float4(ff.x, ff.y, ff.z, ff.w);
+    ra[u] = *(lds_d2_t)(uintptr_t)r;                     // {r, alpha}
+    rb[u] = *(lds_d2_t)(uintptr_t)(r + kDenseRecBOff);   // {mgy, (l11, l22) in the two words of the second double}
   }
   float t[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
-    const float d0 = (float)(gx[u] - m[u].x), d1 = (float)(gy[u] - m[u].y);
-    const float a = fmaf(f[u].x, d0, f[u].y * d1), b = f[u].z * d1;
-    t[u] = __builtin_amdgcn_exp2f(-fmaf(a, a, fmaf(b, b, f[u].w)));  // null record: w = +inf -> 0
+    // (the two fp32 magnitudes are taken out of the register pair as they are: no arithmetic touches them as a double)
+    const float l11 = __int_as_float(__double2loint(rb[u].y)), l22 = __int_as_float(__double2hiint(rb[u].y));
+    const float a = l11 * (float)(fma(ra[u].x, gy[u], gx[u]) + ra[u].y);
+    const float b = l22 * (float)(gy[u] - rb[u].x);
+    t[u] = __builtin_amdgcn_exp2f(-fmaf(a, a, b * b));  // null record: alpha = +inf -> 0
 #if NDTPSO_DIAG >= 1 && NDTPSO_DIAG <= 16  // timing diagnostics: that many extra independent v_fma_f32 per chunk
     {
-      float dz = d0;
+      float dz = a;
 #pragma unroll
-      for (int q = 0; q < NDTPSO_DIAG; ++q) asm volatile("v_fma_f32 %0, %1, %1, %1" : "=v"(dz) : "v"(d1));
+      for (int q = 0; q < NDTPSO_DIAG; ++q) asm volatile("v_fma_f32 %0, %1, %1, %1" : "=v"(dz) : "v"(b));
     }
 #elif NDTPSO_DIAG == 17  // one extra (independent) 16-byte LDS read per chunk
     {
@@ -930,25 +956,33 @@ __device__ __forceinline__ unsigned bm_slot(const uint2* bm, int k) {
 // scratch: key[n], cellkey[n], cnt[n] ints (rounded up to 4), plist[n] u16 and bm2[n_words] uint2
 // hdr/out: where the table goes (LDS); out.ab/out.cd or out.chol may be null when a kernel needs one score form
 // dn/lds0 (optional): also emit the dense form (u16 table at lds0, the records at lds0 + dn->rec_off)
+// part A of a cell's dense record from its Cholesky factor (cell units) and mean (window cell coordinates); l11 == 0
+// (a form without extent along x: both products of `a` vanish) keeps r = 0.  alpha = NaN marks a form without a factor.
+__host__ __device__ inline DenseRecA dense_rec_a(const double l[3], double mgx, double mgy, bool ok) {
+  const double r = l[0] > 0. ? l[1] / l[0] : 0.;
+  return DenseRecA{r, ok ? -fma(r, mgy, mgx) : (double)__builtin_nanf("")};
+}
 __device__ inline void dense_clear_wg(const DenseP& dn, unsigned char* lds0, bool byte_entries = false) {
   const unsigned null16 = byte_entries ? (unsigned)dn.rec_off : (unsigned)dn.rec_off >> 4;
   uint32_t* t32 = reinterpret_cast<uint32_t*>(lds0);
   const int n32 = dense_tab_bytes(dn.dw, dn.dh) >> 2;
   for (int i = threadIdx.x; i < n32; i += blockDim.x) t32[i] = null16 | (null16 << 16);
   if (threadIdx.x == 0) {
-    *reinterpret_cast<DenseMean*>(lds0 + dn.rec_off) = DenseMean{0., 0.};
-    *reinterpret_cast<DenseChol*>(lds0 + dn.rec_off + kDenseCholOff) = DenseChol{0.f, 0.f, 0.f, __builtin_inff()};
+    *reinterpret_cast<DenseRecA*>(lds0 + dn.rec_off) = DenseRecA{0., (double)__builtin_inff()};
+    *reinterpret_cast<DenseRecB*>(lds0 + dn.rec_off + kDenseRecBOff) = DenseRecB{0., 1.f, 0.f};
   }
 }
 // one built cell -> dense record `slot + 1` and its table entry; (rx, ry) = cell inside the staging window
 __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsigned char* lds0, unsigned slot, int rx,
                                           int ry, double mx, double my, double ia, double ib, double ic, double id,
                                           bool byte_entries = false) {
-  float l[4];
-  make_chol(ia, ib, ic, id, l, g.cs);  // Cholesky factor in cell units
+  double l[3];
+  const bool ok = make_chol_d(ia, ib, ic, id, l, g.cs);  // Cholesky factor in cell units
   const unsigned at = (unsigned)dn.rec_off + dense_rec_pos(slot + 1);
-  *reinterpret_cast<DenseMean*>(lds0 + at) = DenseMean{(mx + g.hw) * g.inv_cs - (double)dn.ox, (my + g.hh) * g.inv_cs - (double)dn.oy};
-  *reinterpret_cast<DenseChol*>(lds0 + at + kDenseCholOff) = DenseChol{l[0], l[1], l[2], l[3]};  // w: 0, or NaN when the form has no Cholesky factor
+  const double mgx = (mx + g.hw) * g.inv_cs - (double)dn.ox, mgy = (my + g.hh) * g.inv_cs - (double)dn.oy;
+  const DenseRecA ra = dense_rec_a(l, mgx, mgy, ok);
+  *reinterpret_cast<DenseRecA*>(lds0 + at) = ra;
+  *reinterpret_cast<DenseRecB*>(lds0 + at + kDenseRecBOff) = DenseRecB{mgy, (float)l[0], (float)l[2]};
   reinterpret_cast<unsigned short*>(lds0)[(ry + 1) * dense_stride(dn.dw) + (rx + 1)] =
       byte_entries ? (unsigned short)at : (unsigned short)(at >> 4);
 }
@@ -1430,6 +1464,9 @@ struct EvalCtx {
   const unsigned char* lds0;
   int light;  // PsoP::light (the item -> wave deal of eval_items)
   unsigned guard_lds;  // LDS byte address of the DenseGuard, 0: none
+#ifdef NDTPSO_VERIFY_MARGIN
+  const struct ExactArgs* xa = nullptr;  // diagnostic builds: every fp32 score is checked against its fp64 value
+#endif
 };
 
 // ---- fp32 score mode, underflow regime ----------------------------------------------------------------
@@ -1463,11 +1500,10 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
       const unsigned lin = ok ? ry * (unsigned)dense_stride(E.dn.dw) + rx : 0u;
       const unsigned e = reinterpret_cast<const unsigned short*>(E.lds0)[lin];
       const unsigned at = PATH == 3 ? e : e << 4;
-      const DenseMean* rm = reinterpret_cast<const DenseMean*>(E.lds0 + at);
-      const DenseChol* r = reinterpret_cast<const DenseChol*>(E.lds0 + at + kDenseCholOff);
-      const double d0 = gx - rm->mgx, d1 = gy - rm->mgy;
-      const double a = (double)r->l11 * d0 + (double)r->l21 * d1, b = (double)r->l22 * d1;
-      acc += exp2(-(a * a + b * b + (double)r->w));  // null record: w = +inf -> 0
+      const DenseRecA* ra = reinterpret_cast<const DenseRecA*>(E.lds0 + at);
+      const DenseRecB* rb = reinterpret_cast<const DenseRecB*>(E.lds0 + at + kDenseRecBOff);
+      const double a = (double)rb->l11 * (fma(ra->r, gy, gx) + ra->alpha), b = (double)rb->l22 * (gy - rb->mgy);
+      acc += exp2(-(a * a + b * b));  // null record: alpha = +inf -> 0
     }
   } else {
     const GridP& g = E.g;
@@ -1523,6 +1559,17 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
 #define NDTPSO_ARB_REL 5e-6
 #endif
 constexpr double kArbRel = NDTPSO_ARB_REL;
+// ... and never less than kArbAbsPerPoint x (points of the scan): the fp32 form's error is below 2.95e-7 per point
+// whatever the cells look like (verify_pose_wave / DESIGN 3.6: u = 2^-24, at most 4.87 u per term, times 1.01), so half
+// of 7e-7 n covers it for ANY input -- in particular when the gbest cost is small against the number of points (poor
+// overlap), where the relative margin alone would not.
+#ifndef NDTPSO_ARB_ABS
+#define NDTPSO_ARB_ABS 7e-7
+#endif
+constexpr double kArbAbsPerPoint = NDTPSO_ARB_ABS;
+__device__ __forceinline__ double arb_margin(double gbest_cost, int n_points) {
+  return fmax(kArbRel * fabs(gbest_cost), kArbAbsPerPoint * (double)n_points);
+}
 
 __device__ __forceinline__ void near_note(int* near_cnt, unsigned short* near_list, int j) {
 #ifdef NDTPSO_X_NODETECT
@@ -1615,6 +1662,135 @@ __device__ __forceinline__ double eval_pose_wave_exact(const ExactArgs* ap, doub
   return -wave_sum((a0 + a1) + (a2 + a3));
 }
 
+// ---- NDTPSO_VERIFY_MARGIN (diagnostic builds only, tests/test_gpu_margin.py) ------------------------------------
+// The exact mode rests on one inequality: every fp32 score the PSO stores differs from the fp64 score of the same pose by
+// less than half the arbitration margin, tau / 2 = kArbRel * |gbest cost| / 2 -- then a comparison whose sides are more
+// than tau apart falls the same way in either arithmetic, and the closer ones are arbitrated.  This build checks it for
+// EVERY evaluation of an alignment, two ways:
+//   measured   err = |fp32 score - fp64 score| (the fp64 score is the arbitration's own, eval_pose_wave_exact);
+//   derived    B >= err, an a-priori bound of the fp32 form's rounding error evaluated for this pose.  Per point that
+//              hits a built cell, with u = 2^-24, s = d0 + r d1 formed in fp64 as fma(r, gy, gx) + alpha (error e64 <=
+//              3.4e-16 (|gx| + |r gy| + |alpha|)), a = l11 s, b = l22 d1, q = a^2 + b^2, t = 2^-q:
+//                s, d1 are rounded to fp32 once, l11 and l22 are fp32 roundings, the products round
+//                                                                     -> |da| <= 3u |a| + |l11| e64,  |db| <= 3u |b|
+//                q = fma(a, a, b * b): the product and the fma round   -> |dq| <= 6u a^2 + 7u b^2 + u q + ... <= 8u q + 2 |a l11| e64
+//                t = v_exp_f32(-q), 1 ulp                             -> |dt| <= t (ln2 |dq| + 2u)
+//                groups of four terms are added in fp32               -> <= 2u t each
+//              B = 1.01 * sum_points t (u (5.55 q + 4) + 1.4 |a l11| e64) + n 2^-126       (1.01: second-order terms; the
+//              last term: v_exp_f32 flushes results below 2^-126 to zero)
+//              t (5.55 q + 4) <= 4.87 for every q >= 0, so B <= 2.95e-7 x (points that hit a cell) WHATEVER the cells look
+//              like: that is what kArbAbsPerPoint rests on.  (The form of rounds 1-2 -- differences and factors rounded
+//              to fp32, a formed in fp32 -- had |da| <= 4u (|L11 d0| + |L21 d1|), up to a hundred times |a| in a thin
+//              rotated cell: its bound exceeded the margin eleven-fold on BASELINE config 3, measured with this build.)
+// and counts the points the folded binning of the fp32 loop (gx = fma(x, C, fma(-y, S, TX))) would file under another
+// table entry than the reference's floor((x + w/2) / cs).  Per alignment (g_verify[blockIdx.x][8], doubles):
+//   0 max err   1 max err / B   2 max B / (tau / 2)   3 max err / (tau / 2)   4 evaluations checked
+//   5 points binned differently (entries differ)   6 max B   7 points checked
+#ifdef NDTPSO_VERIFY_MARGIN
+constexpr unsigned kVerifyMaxBlocks = 8192;
+__device__ double g_verify[kVerifyMaxBlocks * 16];
+__device__ __forceinline__ void verify_max(double* slot, double v) {  // non-negative doubles order like their bit patterns
+  atomicMax(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(v));
+}
+template <bool BYTE, bool POW2>
+__device__ __forceinline__ void verify_pose_wave(const ExactArgs* ap, double c, double s, double tx, double ty, double* bound_out,
+                                                 double* misbinned_out) {
+  const GridP g = ap->g;
+  const int dw = ap->dw, dh = ap->dh, ox = ap->ox, oy = ap->oy;
+  const unsigned null_entry = ap->null_entry;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+  typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
+  const int lane = lane_id();
+  const double u = 5.9604644775390625e-08;  // 2^-24
+  // the folded constants of this pose, as dense_item / the proposal step form them
+  const double C = c * g.inv_cs, S = s * g.inv_cs;
+  const double TX = (tx + g.hw) * g.inv_cs - (double)ox, TY = (ty + g.hh) * g.inv_cs - (double)oy;
+  const double XMAX = (2. * g.hw) * g.inv_cs - (double)ox, YMAX = (2. * g.hh) * g.inv_cs - (double)oy;
+  double bound = 0., mis = 0.;
+  for (int i = lane; i < ap->n; i += kWave) {
+    const v2d_t p = *(lds_d2_t)(uintptr_t)(ap->pts_lds + (unsigned)i * 16u);
+    // reference binning (eval_pose_wave_exact)
+    const double qx = (p.x * c - p.y * s) + tx, qy = (p.x * s + p.y * c) + ty;
+    const bool inframe = (int)(fabs(qx) < g.hw) & (int)(fabs(qy) < g.hh);
+    int ix, iy;
+    cell_coords<POW2>(g, qx, qy, ix, iy);
+    const bool wrap = (ix == g.W);
+    ix = wrap ? 0 : ix;
+    iy = wrap ? iy + 1 : iy;
+    const unsigned rx = (unsigned)(ix - ox), ry = (unsigned)(iy - oy);
+    const bool inwin = (int)inframe & (int)(rx <= (unsigned)dw) & (int)(ry <= (unsigned)dh);
+    const unsigned lin = inwin ? ry * (unsigned)dense_stride(dw) + rx : 0u;
+    const unsigned e = *(lds_u16_t)(uintptr_t)(lin << 1);
+    // the fp32 loop's binning (score_trip_dense, clamped form; the no-clamp form is the same wherever its guard holds)
+    const double gx = fma(p.x, C, fma(-p.y, S, TX)), gy = fma(p.x, S, fma(p.y, C, TY));
+    const unsigned fx = min((unsigned)(int)gx, (unsigned)dw), fy = min((unsigned)(int)gy, (unsigned)dh);
+    unsigned flin = fy * (unsigned)dense_stride(dw) + fx;
+    if (!((int)(gx < XMAX) & (int)(gy < YMAX))) flin = 0u;  // (DenseP::clip; never true on a grid that does not overhang)
+    const unsigned fe = *(lds_u16_t)(uintptr_t)(flin << 1);
+    if (fe != e) mis += 1.;
+    if (e != null_entry) {
+      const unsigned slot = dense_rec_index(BYTE ? e - null_entry : (e - null_entry) << 4) - 1u;
+      const double2 m = ap->xmean[slot], ab = ap->xab[slot], cd = ap->xcd[slot];
+      double l[3];
+      const bool okc = make_chol_d(ab.x, ab.y, cd.x, cd.y, l, g.cs);
+      const double mgx = (m.x + g.hw) * g.inv_cs - (double)ox, mgy = (m.y + g.hh) * g.inv_cs - (double)oy;
+      const DenseRecA ra = dense_rec_a(l, mgx, mgy, okc);
+      const double sv = fma(ra.r, gy, gx) + ra.alpha;
+      const double a = l[0] * sv, b = l[2] * (gy - mgy);
+      const double e64 = 3.4e-16 * (fabs(gx) + fabs(ra.r * gy) + fabs(ra.alpha));
+      const double q = a * a + b * b, t = exp2(-q);
+      bound += t * (u * (5.55 * q + 4.) + 1.4 * fabs(a * l[0]) * e64);
+    }
+  }
+  *bound_out = 1.01 * wave_sum(bound) + (double)ap->n * 1.1754943508222875e-38;
+  *misbinned_out = wave_sum(mis);
+}
+template <bool BYTE>
+__device__ __forceinline__ void verify_item(const ExactArgs* ap, int j, double cost32, double ref_cost) {
+  const double c = ap->pcs[j], s = ap->pcs[ap->S + j], tx = ap->tpos[j], ty = ap->tpos[ap->S + j];
+  double cost64, bound, mis;
+  if (ap->g.cs_pow2) {
+    cost64 = eval_pose_wave_exact<BYTE, true>(ap, c, s, tx, ty);
+    verify_pose_wave<BYTE, true>(ap, c, s, tx, ty, &bound, &mis);
+  } else {
+    cost64 = eval_pose_wave_exact<BYTE, false>(ap, c, s, tx, ty);
+    verify_pose_wave<BYTE, false>(ap, c, s, tx, ty, &bound, &mis);
+  }
+  if (lane_id() == 0 && blockIdx.x < kVerifyMaxBlocks && cost32 == cost32 && cost64 == cost64) {
+    double* o = g_verify + (size_t)blockIdx.x * 16;
+    const double err = fabs(cost32 - cost64);
+    const double ref = fabs(ref_cost) > 0. ? fabs(ref_cost) : fabs(cost64);  // (swarm initialisation: relative to the cost itself)
+    const double half_tau = 0.5 * arb_margin(ref, ap->n);
+    verify_max(o + 0, err);
+    if (bound > 0.) verify_max(o + 1, err / bound);
+    if (half_tau > 1e-30) {
+      verify_max(o + 2, bound / half_tau);
+      verify_max(o + 3, err / half_tau);
+    }
+    atomicAdd(o + 4, 1.);
+    atomicAdd(o + 5, mis);
+    verify_max(o + 6, bound);
+    atomicAdd(o + 7, (double)ap->n);
+    // 8 evaluations with err > B   9 iteration-phase evaluations with err > tau / 2   10 max err / (tau / 2), iteration phase
+    // 11-13 fp32 score, fp64 score and B of the evaluation with the largest err / B so far   14 max err, iteration phase
+    if (err > bound) {
+      atomicAdd(o + 8, 1.);
+      if (bound > 0. && err / bound >= o[1]) {
+        o[11] = cost32;
+        o[12] = cost64;
+        o[13] = bound;
+      }
+    }
+    if (ref_cost != 0. && half_tau > 1e-30) {
+      if (err > half_tau) atomicAdd(o + 9, 1.);
+      verify_max(o + 10, err / half_tau);
+      verify_max(o + 14, err);
+    }
+  }
+}
+#endif
+
 #ifndef NDTPSO_EXACT_CALL
 #define NDTPSO_EXACT_CALL 1
 #endif
@@ -1705,6 +1881,10 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
     }
+#ifdef NDTPSO_VERIFY_MARGIN
+    if constexpr (ARB && (PATH == 2 || PATH == 3))
+      if (E.xa) verify_item<PATH == 3>(E.xa, j, cost, improver ? gbc : 0.);
+#endif
     if (lane_id() == 0) {
       sw.tcost[j] = cost;
       // A cost in the fp32 underflow regime is only ambiguous when what it is compared with is there too: an
@@ -1728,7 +1908,7 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       // exact mode: a comparison too close to call is noted for arbitration (pso_run_wg)
       if constexpr (ARB) {
         if (improver) {
-          const double tau = kArbRel * fabs(gbc);  // (uniform: scalar-unit work)
+          const double tau = arb_margin(gbc, n);  // (uniform: scalar-unit work)
           if (near_tie(cost, pbc_j, tau) || near_tie(cost, gbc, tau)) near_note(near_cnt, near_list, j);
         }
       }
@@ -1970,7 +2150,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         sh->near_cnt[0] = 0;
       }
       __syncthreads();
-      const double lim = sh->xgbc + kArbRel * fabs(sh->xgbc);
+      const double lim = sh->xgbc + arb_margin(sh->xgbc, n);
       for (int i = tid; i < S; i += blockDim.x)
         if (sw.tcost[i] <= lim) near_note(&sh->near_cnt[0], sh->near_list[0], i);
       __syncthreads();

@@ -17,7 +17,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-BUDGET_LIB = os.path.join(ROOT, "ndtpso_slam_amd", "lib", "libndtpso_hip_budget.so")
+BUDGET_LIB = os.path.join(ROOT, "ndtpso_slam_amd", "lib", "libndtpso_hip_budget.so")   # ndtpso_slam_amd.build.variant_path("budget")
 
 PHASES = ["setup (scan A, window, table, scan B)", "swarm initialisation (71 evaluations)", "generator at the top of an iteration",
           "proposals + barrier", "evaluation: wave 0's own item", "generator slice inside a round (wave 0)",
@@ -27,9 +27,7 @@ PHASES = ["setup (scan A, window, table, scan B)", "swarm initialisation (71 eva
 
 def build():
     from ndtpso_slam_amd import build as b
-    cmd = [b.hipcc()] + b.FLAGS + ["-DNDTPSO_PHASE_BUDGET", b.SRC, "-o", BUDGET_LIB]
-    print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    print(b.build_variant("budget", verbose=True))
 
 
 def timed_launches(score, launches=12):

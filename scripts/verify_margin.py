@@ -1,0 +1,85 @@
+"""Checks the inequality the exact mode rests on, for EVERY evaluation of every alignment of a workload, with the
+diagnostic build -DNDTPSO_VERIFY_MARGIN (ndtpso_kernels.hpp: verify_item):
+
+    err = |fp32 score - fp64 score|  <=  B (the derived rounding-error bound of the fp32 form for that pose)
+    B  <  tau / 2 = kArbRel * |gbest cost| / 2
+
+and counts the points the fp32 loop's folded binning would file under another table entry than the reference's.
+
+    python -m ndtpso_slam_amd.build verify                        # build container
+    python scripts/verify_margin.py [--workload config3|config5|random] [--pairs N] [--seed S]   # GPU box; prints JSON
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="config3", choices=["config3", "config5", "random", "converged"])
+    ap.add_argument("--pairs", type=int, default=0)
+    ap.add_argument("--seed", type=int, default=2024)
+    args = ap.parse_args()
+    from ndtpso_slam_amd import build as b
+    os.environ["NDTPSO_LIB"] = b.build_variant("verify")
+    import numpy as np
+    from ndtpso_slam_amd import capi, synth
+    L = capi.load()
+    assert hasattr(L, "ndtpso_profile_verify_margin"), "not a -DNDTPSO_VERIFY_MARGIN build"
+    L.ndtpso_profile_verify_margin.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    ctx = capi.Context(0)
+    rng = np.random.default_rng(args.seed)
+    runs = []
+    if args.workload == "config3":
+        runs.append(dict(pairs=args.pairs or 512, beams=1081, cs=0.5, P=70, I=70, dev=(0.1, 0.1, 3.1415e-3), seed=2024))
+    elif args.workload == "config5":
+        runs.append(dict(pairs=args.pairs or 2, beams=2048, cs=0.25, P=2048, I=200, dev=(0.1, 0.1, 3.1415e-3), seed=21))
+    elif args.workload == "converged":   # tight deviations: the swarm converges, near-ties everywhere
+        for k in range(4):
+            runs.append(dict(pairs=args.pairs or 160, beams=1081, cs=0.5, P=30, I=50, dev=tuple(10.0 ** -(k + 2) * np.array([1, 1, 0.03])), seed=90 + k))
+    else:
+        for k in range(8):
+            runs.append(dict(pairs=args.pairs or 140, beams=int(rng.choice([361, 721, 1081, 1441, 2048])),
+                             cs=float(rng.choice([0.25, 0.3, 0.5, 0.75, 1.0])), P=int(rng.integers(8, 90)), I=int(rng.integers(5, 60)),
+                             dev=tuple(rng.uniform(0.02, 0.3, 2)) + (float(rng.uniform(1e-3, 0.03)),), seed=int(rng.integers(1, 1 << 30))))
+    out = {"workload": args.workload, "kArbRel": 5e-6, "runs": []}
+    worst = np.zeros(16)
+    for r in runs:
+        p = synth.make_pairs(r["pairs"], n_beams=r["beams"], seed=r["seed"])
+        geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+        B = r["pairs"]
+        assert L.ndtpso_profile_verify_margin(None, 0, 1) == 0
+        pose, cost, st = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, capi.Grid(60, 60, r["cs"]), (0, 0, 0), r["dev"],
+                                         capi.PSOConfig.make(r["I"], r["P"]), seeds=p.seeds, mode=capi.SCORE_EXACT)
+        v = np.zeros((B, 16))
+        assert L.ndtpso_profile_verify_margin(v.ctypes.data_as(C.c_void_p), B, 0) == 0
+        handed_over = int(((st["status"] & 0xffff) != 0).sum())
+        row = dict(r, dev=list(map(float, r["dev"])), evaluations_checked=float(v[:, 4].sum()), points_checked=float(v[:, 7].sum()),
+                   max_err=float(v[:, 0].max()), max_err_over_bound=float(v[:, 1].max()), max_bound_over_half_tau=float(v[:, 2].max()),
+                   max_err_over_half_tau=float(v[:, 3].max()), points_binned_differently=float(v[:, 5].sum()), max_bound=float(v[:, 6].max()),
+                   alignments_flagged=handed_over, arbitrated_mean=float(st["arbitrated"].mean()),
+                   mean_abs_cost=float(np.abs(cost).mean()),
+                   evaluations_with_err_above_bound=float(v[:, 8].sum()), iteration_evaluations_with_err_above_half_tau=float(v[:, 9].sum()),
+                   max_err_over_half_tau_iterations=float(v[:, 10].max()), max_err_iterations=float(v[:, 14].max()),
+                   worst_err_over_bound_case=dict(zip(("fp32", "fp64", "bound"), map(float, v[int(np.argmax(v[:, 1])), 11:14]))))
+        out["runs"].append(row)
+        worst = np.maximum(worst, v.max(axis=0))
+    out["max_err_over_bound"] = float(worst[1])
+    out["max_bound_over_half_tau"] = float(worst[2])
+    out["max_err_over_half_tau"] = float(worst[3])
+    out["max_err_over_half_tau_iterations"] = float(worst[10])
+    out["evaluations_with_err_above_bound"] = float(sum(r["evaluations_with_err_above_bound"] for r in out["runs"]))
+    out["iteration_evaluations_with_err_above_half_tau"] = float(sum(r["iteration_evaluations_with_err_above_half_tau"] for r in out["runs"]))
+    out["evaluations_checked"] = float(sum(r["evaluations_checked"] for r in out["runs"]))
+    out["points_checked"] = float(sum(r["points_checked"] for r in out["runs"]))
+    out["points_binned_differently"] = float(sum(r["points_binned_differently"] for r in out["runs"]))
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
