@@ -86,6 +86,10 @@ class NDTFrame {
   const vector<int8_t>& occupancyGrid(uint32_t* og_width = nullptr, uint32_t* og_height = nullptr,
                                       uint32_t extent[4] = nullptr) const;
 #endif
+  // false when the last align() / pso_optimization against this frame could not run on the device and returned its
+  // initial guess unrefined (the reference's API has no error channel; see also ndtpso_slam/status.h).  A caller that
+  // is about to update() the map with that pose can look first.
+  bool lastAlignOk() const { return s_last_align_ok; }
   // pso_optimization against this frame (used by align() and by the free function in core.h)
   Vector3d optimize(const Vector3d& guess, const NDTFrame* new_frame, const Vector3d& deviation, const PSOConfig& cfg);
   double cost(const Vector3d& trans, const NDTFrame* new_frame);
@@ -108,6 +112,7 @@ class NDTFrame {
 #endif
   std::vector<uint32_t> s_created;  // indices of created cells, in creation order
   bool s_table_dirty{true};         // the device reference table must be re-uploaded before the next align
+  bool s_last_align_ok{true};
   void append(const double* xy, const int32_t* idx, uint32_t n);
   bool uploadTable();  // false: the device refused the table (error recorded, see status.h)
   // resident mode

@@ -468,6 +468,7 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
                                                         nullptr, nullptr), "align");
     if (ok) built = true;
     if (tmp) ndtpso_host::release_scan(tmp, tmp_cap);
+    s_last_align_ok = ok;
     return ok ? Vector3d(pose[0], pose[1], pose[2]) : guess;  // device fault: the initial guess, never a CPU estimate
   }
   if (!built) build();  // core.cpp:27-28 (lazy build inside cost_function)
@@ -480,9 +481,9 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
   const double g[3] = {guess.x(), guess.y(), guess.z()};
   const double dv[3] = {deviation.x(), deviation.y(), deviation.z()};
   double pose[3] = {g[0], g[1], g[2]};
-  if (!table_ok || !ndtpso_host::check(ndtpso_align(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), g, dv, &abi, 0u,
-                                                    draws.data(), ndtpso_host::score_mode(), pose, nullptr, nullptr), "align"))
-    return guess;
+  s_last_align_ok = table_ok && ndtpso_host::check(ndtpso_align(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), g, dv, &abi,
+                                                               0u, draws.data(), ndtpso_host::score_mode(), pose, nullptr, nullptr), "align");
+  if (!s_last_align_ok) return guess;
   return Vector3d(pose[0], pose[1], pose[2]);
 }
 
@@ -567,7 +568,11 @@ void NDTFrame::transform(Vector3d trans) {
     ndtpso_map* m = ensureMap();
     if (!ndtpso_host::check(ndtpso_map_clear(m), "transform")) return;  // fresh cells (ndtframe.cpp:123): not built
     const double t[3] = {trans.x(), trans.y(), trans.z()};
-    ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), t), "transform");
+    if (!ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), t), "transform")) {
+      // the device refused the transformed points after the map was emptied: put the points back where they were
+      // rather than leave an empty frame behind (the failure itself is on record, ndtpso_slam/status.h)
+      ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), nullptr), "transform (restore)");
+    }
     built = false;
     return;
   }

@@ -1453,6 +1453,7 @@ int ndtpso_cost_batch(ndtpso_ctx* c, const double* xy, uint32_t n, const double*
   if (!c || (!xy && n) || !poses || !costs || m == 0) return fail(c, NDTPSO_E_ARG, "null argument");
   if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64 && mode != NDTPSO_SCORE_EXACT) return fail(c, NDTPSO_E_ARG, "bad score mode");
   if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
+  if (mode == NDTPSO_SCORE_EXACT) mode = NDTPSO_SCORE_F64;  // a cost has nothing to arbitrate: the fp64 score (as ndtpso_map_cost)
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
   if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
