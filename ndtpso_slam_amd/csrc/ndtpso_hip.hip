@@ -719,6 +719,8 @@ struct ndtpso_ctx {
   int pipe_depth = 1;
   unsigned long long pipe_calls = 0;  // pipelined calls issued so far
   hipEvent_t pipe_in = nullptr;       // "inputs of the call are ready on the context's stream"
+  void* result_pinned = nullptr;      // pinned landing slot of one alignment's pose / cost / statistics (align_once)
+  hipEvent_t result_event = nullptr;
 };
 
 namespace {
@@ -1043,6 +1045,8 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
     if (l.stream) (void)hipStreamDestroy(l.stream);
   }
   if (c->pipe_in) (void)hipEventDestroy(c->pipe_in);
+  if (c->result_event) (void)hipEventDestroy(c->result_event);
+  if (c->result_pinned) (void)hipHostFree(c->result_pinned);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1596,10 +1600,21 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
 #undef LAUNCH_ALIGN_C
 #undef LAUNCH_ALIGN_CA
   HIP_TRY(c, hipGetLastError());
-  HIP_TRY(c, hipMemcpyAsync(host, c->out.p, (4 + sizeof(AlignStats) / 8) * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  // The result comes back through a pinned slot and an event of its own: the host waits for the pose only, while what
+  // `after` enqueues (the occupancy grid a committed speculative build still owes) runs in the shadow of the host's
+  // wake-up.  (With a pageable destination the copy call itself blocked until the kernel was done, `after` was
+  // enqueued late and then waited for: 30 us per scan on the live path.)
+  constexpr size_t kResultBytes = (4 + sizeof(AlignStats) / 8) * sizeof(double);
+  if (!c->result_pinned) {
+    HIP_TRY(c, hipHostMalloc(&c->result_pinned, 256, hipHostMallocDefault));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->result_event, hipEventDisableTiming));
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->result_pinned, c->out.p, kResultBytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipEventRecord(c->result_event, c->stream));
   if (after.fn)
     if (int rc = after.fn(after.arg)) return rc;
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipEventSynchronize(c->result_event));
+  std::memcpy(host, c->result_pinned, kResultBytes);
   if (K > 1) {
     AlignStats st;
     std::memcpy(&st, host + 4, sizeof(st));
