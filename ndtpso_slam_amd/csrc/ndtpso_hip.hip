@@ -21,7 +21,7 @@ static_assert(sizeof(AlignStats) == sizeof(ndtpso_align_stats), "stats ABI");
 namespace {
 
 constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
-constexpr int kCtrlBytes = 864;      // control block (PsoShared + compaction counters)
+constexpr int kCtrlBytes = 976;      // control block (PsoShared + compaction counters)
 
 // LDS layout shared by every kernel.
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
@@ -32,12 +32,13 @@ struct Layout {
   int ctrl_off, hdr_off, bm_off, mean_off, ab_off, cd_off, chol_off, drec_off, pts_off, region_off, total;
   int key_off, cellkey_off, cnt_off, bm2_off, plist_off;  // build scratch inside region
   int swarm_global;  // 1: the swarm does not fit in LDS and lives in an HBM workspace (large-swarm configs)
+  int xs_off, xs_slots;  // exact mode: partial-sum scratch of the arbitration, xs_slots x 512 bytes (exact_tasks_wg); -1: none
 };
 
 // fmt: kScoreF32 -> mean+chol, kScoreF64 -> mean+ab+cd, 2 -> everything (table build kernel);
 // ddw > 0: dense form with a ddw x ddh cell table (fp32 score only)
 Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw = 0, int ddh = 0,
-                   bool swarm_global = false, bool exact = false) {
+                   bool swarm_global = false, bool exact = false, bool exact_units = false) {
   Layout L;
   L.swarm_global = swarm_global ? 1 : 0;
   const bool dense = ddw > 0;
@@ -83,6 +84,13 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
   }
   const int swarm = (P > 0 && !swarm_global) ? swarm_bytes(P, exact, swarm_has_raw2(P, false)) : 0;
   L.total = L.region_off + std::max(scratch, swarm);
+  L.xs_off = -1;
+  L.xs_slots = 0;
+  if (exact && exact_units) {  // (the fused pairs kernels; a single alignment's kernels score whole tasks per wave)
+    L.xs_slots = swarm_global ? 16 : 8;  // one unit per wave of the workgroup: 8 waves (16 with the swarm in HBM, one per CU)
+    L.xs_off = L.total;
+    L.total += L.xs_slots * kWave * 8;
+  }
   return L;
 }
 
@@ -163,9 +171,11 @@ __device__ __forceinline__ TableView image_table_view(const WinP& wn, const unsi
 // the LDS parameter block of exact_tasks (thread 0 writes; the barriers of the swarm initialisation publish it)
 template <bool BYTE>
 __device__ __forceinline__ void enable_arbitration(PsoShared* sh, const GridP& g, const WinP& wn, const DenseP& dn,
-                                                   const unsigned char* __restrict__ image) {
+                                                   const unsigned char* __restrict__ image, const Layout& L) {
   if (threadIdx.x == 0) {
     ExactArgs& a = sh->xa;
+    a.xs_lds = L.xs_slots ? (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)(g_lds + L.xs_off) : 0u;
+    a.xs_slots = L.xs_slots;
     a.g = g;
     a.dw = dn.dw;
     a.dh = dn.dh;
@@ -428,7 +438,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   __syncthreads();
   EvalCtx E = PATH >= 4 ? make_eval_ctx_global(g, wn, dn, image) : make_eval_ctx(g, wn, L, dn);
   E.light = CLUSTER ? 0 : ps.light;
-  if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, image);  // exact mode: the staged image holds the fp64 records
+  if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, image, L);  // exact mode: the staged image holds the fp64 records
   // a swarm too large for LDS lives in an HBM workspace, one per workgroup of a cluster (each keeps the whole swarm)
   // Two copies of the PSO, one per home of the swarm, so that in each the compiler knows the address space of the
   // swarm arrays: selecting the base pointer at run time made every swarm access a FLAT instruction (74 of them), and
@@ -568,7 +578,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   EvalCtx E = make_eval_ctx(g, wn, L, dn);
   E.light = CLUSTER ? 0 : ps.light;
   E.guard_lds = (unsigned)(uintptr_t)(const DenseGuard __attribute__((address_space(3)))*)&lds_ctrl(L.ctrl_off)->guard;
-  if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg);
+  if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg, L);
 #ifdef NDTPSO_VERIFY_MARGIN
   if constexpr (ARB && !CLUSTER) E.xa = &lds_ctrl(L.ctrl_off)->xa;
 #endif
@@ -877,7 +887,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
     if (swarm_global && P <= 0) break;
     if (dense_ok) {
       const int full_w = wn.w + 1, full_h = wn.h + 1;
-      Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, full_w, full_h, swarm_global != 0, exact);
+      Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, full_w, full_h, swarm_global != 0, exact, dynamic_window);
       int cap = dense_entries(full_w, full_h);
       if (dynamic_window && Ld.total > kMaxLds / 2) {
         // shrink the provisioned (square) table until two workgroups fit per CU, else until one does;
@@ -885,7 +895,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         for (int limit : {kMaxLds / 2, kMaxLds}) {
           bool found = false;
           for (int side = (int)std::sqrt((double)(full_w * full_h)); side >= 64; side -= 4) {
-            const Layout Lt = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0, exact);
+            const Layout Lt = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0, exact, dynamic_window);
             if (Lt.total <= limit) {
               Ld = Lt;
               cap = dense_entries(side, side);
@@ -904,7 +914,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         return true;
       }
     }
-    const Layout Lb = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, 0, 0, swarm_global != 0, exact);
+    const Layout Lb = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, 0, 0, swarm_global != 0, exact, dynamic_window);
     if (Lb.total <= kMaxLds) {
       plan->path = bitmap_path;
       plan->L = Lb;

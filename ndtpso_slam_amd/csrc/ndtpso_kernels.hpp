@@ -533,9 +533,7 @@ __device__ __forceinline__ void score_trip_dense(const GridP& g, const DenseP& d
   // the dense table starts at LDS address 0 and records are addressed absolutely: plain shifts, no base add
   typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
   typedef double v2d_t __attribute__((ext_vector_type(2)));
-  typedef float v4f_t __attribute__((ext_vector_type(4)));
   typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
-  typedef const v4f_t __attribute__((address_space(3))) * lds_f4_t;
   (void)lds0;
   unsigned e[U];
 #pragma unroll
@@ -1370,6 +1368,7 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
   double* tcost;  // [S]
   double* pcs;    // [2][S] plain cos, sin of the proposal's heading  } exact mode only: what the fp64 score of a
   double* bcs;    // [2][S] the same for the pbest position            } position takes (exact_tasks), so that the
+  unsigned char* pex;  // [S] exact mode: pbc[j] holds the fp64 score of the pbest position (an arbitration put it there)
   int32_t* raw;   // [max(3(P+1), 6P)] rand() outputs of the current phase   arbitration needs no sincos of its own
   int32_t* raw2;  // [6P] the next iteration's outputs, generated by an idle wave behind the current one's last round
 };
@@ -1377,7 +1376,7 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
 // overlapped generator -- always with the swarm in its HBM workspace, in LDS only for swarms of up to 256 particles (a
 // 512-particle swarm with it no longer fits beside the dense table: 16 266 instead of 26 202 align/s, measured)
 __host__ __device__ inline bool swarm_has_raw2(int P, bool swarm_global) { return swarm_global || P <= 256; }
-__host__ __device__ inline int swarm_doubles(int P, bool exact) { return (exact ? 25 : 21) * (P + 1); }
+__host__ __device__ inline int swarm_doubles(int P, bool exact) { return (exact ? 26 : 21) * (P + 1); }
 __host__ __device__ inline int swarm_raw_ints(int P) { return (6 * P > 3 * (P + 1)) ? 6 * P : 3 * (P + 1); }
 __host__ __device__ inline int swarm_bytes(int P, bool exact, bool raw2) {
   return align16(swarm_doubles(P, exact) * 8) + align16(swarm_raw_ints(P) * 4) + (raw2 ? align16(6 * P * 4) : 0);
@@ -1400,6 +1399,7 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P, bool exact, bool
   sw.tty = d + 20 * S;
   sw.pcs = exact ? d + 21 * S : nullptr;
   sw.bcs = exact ? d + 23 * S : nullptr;
+  sw.pex = exact ? reinterpret_cast<unsigned char*>(d + 25 * S) : nullptr;  // (S bytes of an S-double slot)
   sw.raw = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P, exact) * 8));
   sw.raw2 = raw2 ? reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P, exact) * 8) + align16(swarm_raw_ints(P) * 4)) : nullptr;
   return sw;
@@ -1427,6 +1427,14 @@ struct ExactArgs {
   const double* gcs;   // [2]    of the gbest position's
   double* xgbc;
   int S;
+  // the arbitration's work list and scratch (exact_tasks_wg)
+  unsigned char* pex;      // Swarm::pex
+  unsigned xs_lds;         // LDS byte address of the partial-sum scratch: xs_slots x 64 doubles
+  int xs_slots;            // units (one lane accumulator of one fp64 score each) that can be in flight
+  int gex;                 // the gbest cost in PsoShared::gbc is the fp64 score of the gbest position
+  int n_task;              // tasks of the current arbitration
+  int gb_task;             // ... one of which rescored the gbest position
+  unsigned short task[2 * 16 + 2];  // (item << 2) | kind: 0 proposal -> tcost, 1 pbest -> pbc, 2 gbest -> *xgbc   [kMaxNear = 16]
 };
 // Dense form, fused pairs kernel: the folded translation (DenseItem::TX, TY) of a pose whose transform keeps EVERY point
 // of the list inside the cell table lies in [x_lo, x_hi) x [y_lo, y_hi) -- the points lie within `rho` of the sensor,
@@ -1791,54 +1799,228 @@ __device__ __forceinline__ void verify_item(const ExactArgs* ap, int j, double c
 }
 #endif
 
+// ---- the arbitration's fp64 scores, split for latency (round 3) ----------------------------------------------------
+// One fp64 score used to be one wave's job: 17 chunks in five dependent rounds of gathers (four chunks in flight), 6 us
+// with the records in HBM -- and an alignment of the live sequence arbitrates 4 comparisons (11-15 us each with the
+// barriers around them: 47 us of a 0.5 ms scan).  The score's sum is four independent lane accumulators -- chunk k of a
+// four-chunk trip goes to accumulator k, the chunks behind the last full trip to accumulator 0, then (a0 + a1) + (a2 + a3)
+// and the wave reduction (eval_pose_wave_exact) -- so a UNIT of work is one accumulator of one score: four or five
+// chunks, all in flight at once, summed in the order the one-wave loop adds them.  Units are dealt to the waves; each
+// leaves its 64 lane values in LDS, and after a barrier one wave per score folds the four and reduces: the same bits
+// as before, in one round of gathers instead of five.
+// Which scores are needed is decided first (exact_task_list): the proposals of the noted items always; a pbest or the
+// gbest position only if its stored cost is not already an fp64 score from an earlier arbitration (Swarm::pex,
+// ExactArgs::gex -- in a converged swarm the same particles tie round after round).
+template <bool BYTE, bool POW2>
+__device__ __forceinline__ double exact_partial(const ExactArgs* ap, double c, double s, double tx, double ty, int acc) {
+  const GridP g = ap->g;
+  const int dw = ap->dw, dh = ap->dh, ox = ap->ox, oy = ap->oy;
+  const unsigned null_entry = ap->null_entry;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+  typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
+  const unsigned pts_lds = ap->pts_lds;
+  const double2* __restrict__ xmean = ap->xmean;
+  const double2* __restrict__ xab = ap->xab;
+  const double2* __restrict__ xcd = ap->xcd;
+  const int chunks = round_up(ap->n, kWave) / kWave, in_trips = chunks & ~3;
+  const int lane = lane_id();
+  auto term_of = [&](int k) -> double {  // (eval_pose_wave_exact's, operation for operation)
+    const v2d_t p = *(lds_d2_t)(uintptr_t)(pts_lds + (unsigned)(k * kWave + lane) * 16u);
+    const double qx = (p.x * c - p.y * s) + tx;
+    const double qy = (p.x * s + p.y * c) + ty;
+    const bool inframe = (int)(fabs(qx) < g.hw) & (int)(fabs(qy) < g.hh);
+    int ix, iy;
+    cell_coords<POW2>(g, qx, qy, ix, iy);
+    const bool wrap = (ix == g.W);
+    ix = wrap ? 0 : ix;
+    iy = wrap ? iy + 1 : iy;
+    const unsigned rx = (unsigned)(ix - ox), ry = (unsigned)(iy - oy);
+    const bool inwin = (int)inframe & (int)(rx <= (unsigned)dw) & (int)(ry <= (unsigned)dh);
+    const unsigned lin = inwin ? ry * (unsigned)dense_stride(dw) + rx : 0u;
+    const unsigned e = *(lds_u16_t)(uintptr_t)(lin << 1);
+    const bool hit = e != null_entry;
+    const unsigned slot = hit ? dense_rec_index(BYTE ? e - null_entry : (e - null_entry) << 4) - 1u : 0u;
+    const double2 m = xmean[slot], ab = xab[slot], cd = xcd[slot];
+    const double d0 = qx - m.x, d1 = qy - m.y;
+    const double r0 = d0 * ab.x + d1 * cd.x;
+    const double r1 = d0 * ab.y + d1 * cd.y;
+    const double x = -(r0 * d0 + r1 * d1) / 2.;
+    return exp(hit ? x : -(double)__builtin_inff());
+  };
+  // this accumulator's chunks, in the order the one-wave loop adds them: acc, acc + 4, ... below in_trips, then (acc 0)
+  // the chunks behind the last full trip
+  double a = 0.;
+  int k = acc;
+#pragma unroll 1
+  for (; k + 12 < in_trips; k += 16) {  // four of them in flight
+    const double t0 = term_of(k), t1 = term_of(k + 4), t2 = term_of(k + 8), t3 = term_of(k + 12);
+    a += t0;
+    a += t1;
+    a += t2;
+    a += t3;
+  }
+#pragma unroll 1
+  for (; k < in_trips; k += 4) a += term_of(k);
+  if (acc == 0) {
+#pragma unroll 1
+    for (k = in_trips; k < chunks; ++k) a += term_of(k);
+  }
+  return a;
+}
+
 #ifndef NDTPSO_EXACT_CALL
 #define NDTPSO_EXACT_CALL 1
 #endif
+// unit u = 4 * task + accumulator: computes it and leaves the lane values in scratch slot (u mod xs_slots)
 template <bool BYTE>
-#if NDTPSO_EXACT_CALL
-__device__ __attribute__((noinline, cold)) void exact_tasks(const ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
-#else
-__device__ __forceinline__ void exact_tasks(const ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
-#endif
-#ifdef NDTPSO_X_NOTASKS
-  return;
-#endif
-  const int n_waves = blockDim.x >> 6;
-  const int n_tasks = kind == 0 ? cnt : (kind == 1 ? 2 * cnt + 1 : 1);
+__device__ __forceinline__ void exact_unit_body(const ExactArgs* ap, int u) {
+  const unsigned tk = ap->task[u >> 2];
+  const int j = (int)(tk >> 2), kind = (int)(tk & 3u), acc = u & 3;
+  double x, y, cn, sn;
+  if (kind == 2) {
+    x = ap->gb[0];
+    y = ap->gb[1];
+    cn = ap->gcs[0];
+    sn = ap->gcs[1];
+  } else {
+    const double* src = kind == 1 ? ap->pb : ap->tpos;
+    const double* cs = kind == 1 ? ap->bcs : ap->pcs;
+    x = src[j];
+    y = src[ap->S + j];
+    cn = cs[j];
+    sn = cs[ap->S + j];
+  }
+  const double a = ap->g.cs_pow2 ? exact_partial<BYTE, true>(ap, cn, sn, x, y, acc) : exact_partial<BYTE, false>(ap, cn, sn, x, y, acc);
+  typedef double __attribute__((address_space(3))) * lds_d_t;
+  *(lds_d_t)(uintptr_t)(ap->xs_lds + (unsigned)((u % ap->xs_slots) * kWave + lane_id()) * 8u) = a;
+}
+// this wave's units of a pass: u0, u0 + stride, ... below u_end.  Out of line (and cold) in the one-workgroup kernels,
+// which sit at their register limit: the fp32-score kernels must not carry this code in their hot paths' allocation.
+// The cluster kernels have registers to spare and inline it (INL): a call there costs more than it saves -- callee-saved
+// registers go through scratch memory on every call, and the live sequence arbitrates four comparisons per scan.
+template <bool BYTE>
+__device__ __attribute__((noinline, cold)) void exact_unit_call(const ExactArgs* ap, int u) { exact_unit_body<BYTE>(ap, u); }
+template <bool BYTE, bool INL>
+__device__ __forceinline__ void exact_units(const ExactArgs* ap, int u0, int stride, int u_end) {
 #pragma unroll 1
-  for (int t = wave_id(); t < n_tasks; t += n_waves) {
-    double x, y, cn, sn;
-    double* dst;
-    if (kind == 2 || (kind == 1 && t == 2 * cnt)) {
-      x = ap->gb[0];
-      y = ap->gb[1];
-      cn = ap->gcs[0];
-      sn = ap->gcs[1];
-      dst = ap->xgbc;
-    } else {
-      const int j = list[kind == 0 ? t : (t >> 1)];
-      const bool pbest = kind == 1 && (t & 1);
-      const double* src = pbest ? ap->pb : ap->tpos;
-      const double* cs = pbest ? ap->bcs : ap->pcs;
-      x = src[j];
-      y = src[ap->S + j];
-      cn = cs[j];
-      sn = cs[ap->S + j];
-      dst = pbest ? &ap->pbc[j] : &ap->tcost[j];
-    }
-    const double c = ap->g.cs_pow2 ? eval_pose_wave_exact<BYTE, true>(ap, cn, sn, x, y)
-                                   : eval_pose_wave_exact<BYTE, false>(ap, cn, sn, x, y);
-    if (lane_id() == 0) *dst = c;
+  for (int u = u0; u < u_end; u += stride) {
+    if constexpr (INL || !NDTPSO_EXACT_CALL)
+      exact_unit_body<BYTE>(ap, u);
+    else
+      exact_unit_call<BYTE>(ap, u);
   }
 }
-// Only the waves that have a task make the call (an out-of-line call saves and restores the callee-saved registers it
-// uses in scratch memory: 100 MB of HBM traffic per launch when all eight waves went through it for three tasks);
-// every thread of the workgroup calls this wrapper, which ends with a barrier.
+// the four accumulators of task t (scratch slots of units 4t .. 4t + 3) -> its score, stored where the task says
+__device__ __forceinline__ void exact_combine(const ExactArgs* ap, int t) {
+  typedef const double __attribute__((address_space(3))) * lds_d_t;
+  const unsigned base = ap->xs_lds + (unsigned)(((4 * t) % ap->xs_slots) * kWave + lane_id()) * 8u;
+  const double a0 = *(lds_d_t)(uintptr_t)base, a1 = *(lds_d_t)(uintptr_t)(base + kWave * 8u),
+               a2 = *(lds_d_t)(uintptr_t)(base + 2u * kWave * 8u), a3 = *(lds_d_t)(uintptr_t)(base + 3u * kWave * 8u);
+  const double c = -wave_sum((a0 + a1) + (a2 + a3));
+  if (lane_id() == 0) {
+    const unsigned tk = ap->task[t];
+    const int j = (int)(tk >> 2), kind = (int)(tk & 3u);
+    double* dst = kind == 2 ? ap->xgbc : (kind == 1 ? &ap->pbc[j] : &ap->tcost[j]);
+    *dst = c;
+  }
+}
+// kind 0: the swarm initialisation's candidates (proposal scores of the listed items); 1: a round's noted items
+// (proposal; pbest and gbest unless their costs are fp64 scores already); 2: the gbest position (the returned cost).
+// Every thread of the workgroup calls this; ap is the block in LDS (PsoShared::xa), written by thread 0 only.
+// one whole fp64 score by this wave (the cluster kernels' way, see exact_tasks_wg)
 template <bool BYTE>
-__device__ __forceinline__ void exact_tasks_wg(const ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
-  const int n_tasks = kind == 0 ? cnt : (kind == 1 ? 2 * cnt + 1 : 1);
-  if (wave_id() < n_tasks) exact_tasks<BYTE>(ap, list, cnt, kind);
+__device__ __forceinline__ void exact_task_body(const ExactArgs* ap, unsigned tk) {
+  const int j = (int)(tk >> 2), kd = (int)(tk & 3u);
+  double x, y, cn, sn;
+  if (kd == 2) {
+    x = ap->gb[0];
+    y = ap->gb[1];
+    cn = ap->gcs[0];
+    sn = ap->gcs[1];
+  } else {
+    const double* src = kd == 1 ? ap->pb : ap->tpos;
+    const double* cs = kd == 1 ? ap->bcs : ap->pcs;
+    x = src[j];
+    y = src[ap->S + j];
+    cn = cs[j];
+    sn = cs[ap->S + j];
+  }
+  const double c = ap->g.cs_pow2 ? eval_pose_wave_exact<BYTE, true>(ap, cn, sn, x, y) : eval_pose_wave_exact<BYTE, false>(ap, cn, sn, x, y);
+  if (lane_id() == 0) {
+    double* dst = kd == 2 ? ap->xgbc : (kd == 1 ? &ap->pbc[j] : &ap->tcost[j]);
+    *dst = c;
+  }
+}
+// (out of line and cold here as well: with the fp64 score inlined the cluster kernel's own evaluation loop got slower)
+template <bool BYTE>
+__device__ __attribute__((noinline, cold)) void exact_task_call(const ExactArgs* ap, unsigned tk) { exact_task_body<BYTE>(ap, tk); }
+
+template <bool BYTE, bool INL = false>
+__device__ __forceinline__ void exact_tasks_wg(ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
+  if (INL || ap->xs_slots == 0) {  // (xs_slots: uniform, set once by enable_arbitration)
+    // A cluster's workgroups have four waves (one per SIMD).  A whole score per wave, all of them at once, is as quick
+    // there as the split into units (three scores are twelve units, three per wave), and it needs neither the work list
+    // nor the second barrier: task slot t is fixed -- kind 0: the proposal of item t; kind 1: 2q the proposal and 2q + 1
+    // the pbest of item q, 2 cnt the gbest; kind 2: the gbest -- and a slot whose cost is an fp64 score already is
+    // skipped by its wave.  (Measured on the live sequence, same box: 0.502 ms per scan before the units, 0.514 with
+    // them, 0.52 through an out-of-line call.)
+    const int n_slots = kind == 0 ? cnt : (kind == 1 ? 2 * cnt + 1 : 1), n_waves = (int)(blockDim.x >> 6);
+    if (threadIdx.x == 0) ap->gb_task = (kind != 0 && !ap->gex) ? 1 : 0;  // (read by the callers after their barrier)
+#pragma unroll 1
+    for (int t = wave_id(); t < n_slots; t += n_waves) {
+      const bool gb = kind == 2 || (kind == 1 && t == 2 * cnt);
+      unsigned tk;
+      if (gb) {
+        if (ap->gex) continue;
+        tk = 2u;
+      } else {
+        const unsigned j = list[kind == 0 ? t : (t >> 1)];
+        const bool pbest = kind == 1 && (t & 1);
+        if (pbest && ap->pex[j]) continue;
+        tk = (j << 2) | (pbest ? 1u : 0u);
+      }
+      exact_task_call<BYTE>(ap, tk);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && kind == 1) {
+      for (int q = 0; q < cnt; ++q) ap->pex[list[q]] = 1;
+      ap->gex = 1;
+    }
+    return;
+  }
+  if (threadIdx.x == 0) {
+    int n = 0;
+    ap->gb_task = 0;
+    if (kind != 2)
+      for (int q = 0; q < cnt; ++q) {
+        const unsigned j = list[q];
+        ap->task[n++] = (unsigned short)(j << 2);
+        if (kind == 1 && !ap->pex[j]) ap->task[n++] = (unsigned short)((j << 2) | 1u);
+      }
+    if (kind != 0 && !ap->gex) {
+      ap->task[n++] = 2;
+      ap->gb_task = 1;
+    }
+    ap->n_task = n;
+  }
   __syncthreads();
+  const int n_tasks = ap->n_task, n_waves = (int)(blockDim.x >> 6);
+  const int per_pass = max(1, ap->xs_slots >> 2);  // tasks whose four partial sums fit in the scratch at once
+#pragma unroll 1
+  for (int t0 = 0; t0 < n_tasks; t0 += per_pass) {
+    const int t1 = min(n_tasks, t0 + per_pass);
+    // the pass's units, dealt round robin to the waves; a wave with more than one does them one after the other.  Only
+    // the waves that have a unit go in (see exact_unit_call)
+    if (4 * t0 + wave_id() < 4 * t1) exact_units<BYTE, INL>(ap, 4 * t0 + wave_id(), n_waves, 4 * t1);
+    __syncthreads();
+    for (int t = t0 + wave_id(); t < t1; t += n_waves) exact_combine(ap, t);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && kind == 1) {  // what the scores just stored are from now on
+    for (int q = 0; q < cnt; ++q) ap->pex[list[q]] = 1;
+    ap->gex = 1;
+  }
 }
 
 // One wave per item.  `improver` (optional): the evaluating wave itself records the lowest item index whose
@@ -2084,6 +2266,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       a.gcs = sh->gcs;
       a.xgbc = &sh->xgbc;
       a.S = S;
+      a.pex = sw.pex;
+      a.gex = 0;
     }
   }
   // The device replay of glibc's generator is the work of ONE wave: wave 0 when it is the light wave of the evaluation
@@ -2160,7 +2344,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         return false;
       }
       if (__builtin_expect(cnt > 1, 0)) {  // (cold: the register allocator must not charge the evaluation loops for it)
-        exact_tasks_wg<PATH == 3>(&sh->xa, sh->near_list[0], cnt, 0);
+        exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[0], cnt, 0);
         n_arb += (uint32_t)cnt;
       }
     }
@@ -2191,6 +2375,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     if constexpr (ARB) {
       sw.bcs[j] = sw.pcs[j];
       sw.bcs[S + j] = sw.pcs[S + j];
+      sw.pex[j] = 0;  // (some of these costs are fp64 scores already -- the initial gbest's candidates; not tracked)
     }
   }
   __syncthreads();
@@ -2376,9 +2561,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             }
             // fp64 scores of the undecidable items' proposals and pbest positions and of the gbest position replace
             // the stored costs; the group's first improver is then looked for again (core.cpp:94-104, nested tests)
-            exact_tasks_wg<PATH == 3>(&sh->xa, sh->near_list[slot], cnt, 1);
+            exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[slot], cnt, 1);
             if (tid == 0) {
-              sh->gbc = sh->xgbc;
+              if (sh->xa.gb_task) sh->gbc = sh->xgbc;  // (else it is the fp64 score of the gbest position already)
               int first = P;
               for (int j = lo; j < hi_g; ++j) {
                 const double cj = sw.tcost[j];
@@ -2406,6 +2591,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       }
       ++grp;
       const int last = (js < P) ? js : (hi_g - 1);
+      // exact mode: items of this round whose costs the arbitration replaced by fp64 scores (what a pbest / the gbest
+      // that takes such a cost over inherits: Swarm::pex, ExactArgs::gex)
+      [[maybe_unused]] const int arb_cnt = ARB ? sh->near_cnt[slot] : 0;
+      [[maybe_unused]] const unsigned short* arb_list = sh->near_list[slot];
       for (int j = lo + tid; j <= last; j += blockDim.x) {
         const double cst = sw.tcost[j];
         const bool better = cst < sw.pbc[j];  // core.cpp:94
@@ -2426,6 +2615,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           if (better) {
             sw.bcs[j] = sw.pcs[j];
             sw.bcs[S + j] = sw.pcs[S + j];
+            bool exact_j = false;
+            for (int q = 0; q < arb_cnt; ++q) exact_j |= (int)arb_list[q] == j;
+            sw.pex[j] = exact_j ? 1 : 0;
           }
         }
       }
@@ -2439,6 +2631,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           if constexpr (ARB) {
             sh->gcs[0] = sw.pcs[js];
             sh->gcs[1] = sw.pcs[S + js];
+            bool exact_js = false;
+            for (int q = 0; q < arb_cnt; ++q) exact_js |= (int)arb_list[q] == js;
+            sh->xa.gex = exact_js ? 1 : 0;
           }
         }
         __syncthreads();
@@ -2476,7 +2671,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #ifndef NDTPSO_NO_FINAL_EXACT
   if constexpr (ARB) {
     {  // exact mode: the returned cost is the fp64 score of the returned pose (what the fp64 mode holds)
-      exact_tasks_wg<PATH == 3>(&sh->xa, nullptr, 0, 2);
+      exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, nullptr, 0, 2);
       exact_cost = true;
     }
   }
@@ -2496,7 +2691,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #endif
   if (tid == 0 && writer) {
     for (int k = 0; k < 3; ++k) out_pose[k] = sh->gb[k];  // core.cpp:115
-    if (out_cost) *out_cost = exact_cost ? sh->xgbc : sh->gbc;
+    if (out_cost) *out_cost = (exact_cost && sh->xa.gb_task) ? sh->xgbc : sh->gbc;  // (gbc itself when it already is the fp64 score)
     if (stats) {
       stats->status |= (n_arb < 0xffffu ? n_arb : 0xffffu) << 16;  // exact mode: comparisons arbitrated in fp64
       stats->n_points = (uint32_t)n;
