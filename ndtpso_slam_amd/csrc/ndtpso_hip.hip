@@ -33,6 +33,7 @@ struct Layout {
   int key_off, cellkey_off, cnt_off, bm2_off, plist_off;  // build scratch inside region
   int swarm_global;  // 1: the swarm does not fit in LDS and lives in an HBM workspace (large-swarm configs)
   int xs_off, xs_slots;  // exact mode: partial-sum scratch of the arbitration, xs_slots x 512 bytes (exact_tasks_wg); -1: none
+  int stage_off;         // swarm in HBM, dense form: two staging buffers of the next round's constants (eval_items); -1: none
 };
 
 // fmt: kScoreF32 -> mean+chol, kScoreF64 -> mean+ab+cd, 2 -> everything (table build kernel);
@@ -84,6 +85,11 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
   }
   const int swarm = (P > 0 && !swarm_global) ? swarm_bytes(P, exact, swarm_has_raw2(P, false)) : 0;
   L.total = L.region_off + std::max(scratch, swarm);
+  L.stage_off = -1;
+  if (swarm_global && dense) {
+    L.stage_off = L.total;
+    L.total += 2 * 5 * kStageRow * 8;
+  }
   L.xs_off = -1;
   L.xs_slots = 0;
   if (exact && exact_units) {  // (the fused pairs kernels; a single alignment's kernels score whole tasks per wave)
@@ -154,6 +160,7 @@ __device__ __forceinline__ EvalCtx make_eval_ctx(const GridP& g, const WinP& wn,
   E.lds0 = g_lds;
   E.light = 0;
   E.guard_lds = 0;
+  E.stage_lds = 0;
   return E;
 }
 
@@ -200,6 +207,7 @@ __device__ __forceinline__ EvalCtx make_eval_ctx_global(const GridP& g, const Wi
   E.lds0 = g_lds;
   E.light = 0;
   E.guard_lds = 0;
+  E.stage_lds = 0;
   return E;
 }
 
@@ -443,9 +451,11 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   // Two copies of the PSO, one per home of the swarm, so that in each the compiler knows the address space of the
   // swarm arrays: selecting the base pointer at run time made every swarm access a FLAT instruction (74 of them), and
   // the proposal / commit phases -- one or two waves working, the rest waiting -- are chains of exactly those accesses.
+  E.stage_lds = 0;
   if (L.swarm_global) {
+    if (L.stage_off >= 0) E.stage_lds = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)(g_lds + L.stage_off);
     const Swarm sw = swarm_carve(ws + (size_t)cl.rank * swarm_bytes(ps.P, true, true), ps.P, ARB, true);
-    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
+    pso_run_wg<MODE, PATH, CLUSTER, ARB, false, true>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
                                          out_cost, stats, cl);
   } else {
     const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
@@ -469,7 +479,11 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
 // CLUSTER (small batches: fewer alignments than compute units): cl.K consecutive workgroups share alignment
 // blockIdx.x / K -- each of them ingests both scans and builds the table for itself (identical arithmetic, so the
 // copies agree), then the PSO runs as a cluster (ClusterP).  Never combined with a gate.
-template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false>
+// SWARM: 2 = the kernel carries both copies of the PSO (swarm in LDS / in its HBM workspace, chosen by L.swarm_global);
+// 0 / 1 = only the LDS / only the HBM copy.  The NOCLIP kernels -- the ones the batches of the benchmark run -- exist as
+// 0 and 1: at 128 registers what is inlined beside the hot loop decides its allocation, and the staging of the HBM
+// copy (eval_items) cost the LDS copy ten more spills when both lived in one kernel.
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, int SWARM = 2>
 __global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
@@ -583,16 +597,22 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if constexpr (ARB && !CLUSTER) E.xa = &lds_ctrl(L.ctrl_off)->xa;
 #endif
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
-  if (L.swarm_global) {  // (two copies: see k_align)
-    const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P, ARB, true);
-    pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                                         tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
-                                         out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+  E.stage_lds = 0;
+  if (SWARM == 1 || (SWARM == 2 && L.swarm_global)) {  // (two copies: see k_align)
+    if constexpr (SWARM != 0) {
+      if (L.stage_off >= 0) E.stage_lds = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)(g_lds + L.stage_off);
+      const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P, ARB, true);
+      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, true>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                                           tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
+                                           out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+    }
   } else {
-    const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
-    pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                                         tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
-                                         out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+    if constexpr (SWARM != 1) {
+      const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
+      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+                                           tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
+                                           out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
+    }
   }
   if (threadIdx.x == 0 && writer) {
     stats[b].n_built = hdr->n_built;
@@ -1010,10 +1030,14 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, true, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, true, true>);
-  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, false, true>);
-  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, false, true>);
-  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true, true>);
-  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, false, true, 0>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, false, true, 0>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true, true, 0>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true, true, 0>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, false, true, 1>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, false, true, 1>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true, true, 1>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true, true, 1>);
   if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, false, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, true, true>);
 #define GLOBAL_PATHS(K, ...)                                                   \
@@ -1777,11 +1801,21 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     HIP_TRY(c, c->ximg.reserve(ximg_stride * n_pairs * (size_t)K));
   }
   unsigned char* d_ximg = ximg_stride ? (unsigned char*)c->ximg.p : nullptr;
-#define LAUNCH_PAIRS_CAN(MODE, PATH, CL, ARB, NOCLIP)                                                             \
-  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP>), dim3(n_pairs * (unsigned)K), dim3(waves * 64), plan.L.total, \
+#define LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, SWARM)                                                      \
+  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM>), dim3(n_pairs * (unsigned)K), dim3(waves * 64), plan.L.total, \
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
                      d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
                      cl, dirs, d_ximg, ximg_stride)
+// (the kernels without clipping trips exist per home of the swarm, the others carry both copies of the PSO)
+#define LAUNCH_PAIRS_CAN(MODE, PATH, CL, ARB, NOCLIP)                                    \
+  do {                                                                                   \
+    if constexpr (NOCLIP) {                                                              \
+      if (plan.L.swarm_global) LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, (NOCLIP ? 1 : 2)); \
+      else LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, (NOCLIP ? 0 : 2));             \
+    } else {                                                                             \
+      LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, 2);                                 \
+    }                                                                                    \
+  } while (0)
 // the dense-form kernels on one workgroup per alignment come in a variant without the frame-clipping trips, for grids
 // whose cells do not overhang the frame (DenseP::clip == 0: the usual case) -- less code inlined, better registers:
 // + 3 % in both the fp32 and the exact mode.  (Dropping the copy of the PSO that keeps its swarm in HBM as well took the
@@ -1815,6 +1849,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
 #undef LAUNCH_PAIRS_C
 #undef LAUNCH_PAIRS_CA
 #undef LAUNCH_PAIRS_CAN
+#undef LAUNCH_PAIRS_CANS
   HIP_TRY(c, hipGetLastError());
   return NDTPSO_OK;
 }

@@ -30,16 +30,21 @@ def build():
     print(b.build_variant("budget", verbose=True))
 
 
-def timed_launches(score, launches=12):
+CONFIGS = {"config3": dict(B=512, P=70, I=70, beams=1081, cs=0.5, seed=2024, launches=12, warm=6),
+           "config5": dict(B=256, P=2048, I=200, beams=2048, cs=0.25, seed=21, launches=3, warm=1)}
+
+
+def timed_launches(score, launches=12, config="config3"):
     """(mean ms per launch by events, last stats) through whatever library NDTPSO_LIB selects."""
     import numpy as np
     import torch
     from ndtpso_slam_amd import capi, synth
     dev = torch.device("cuda", 0)
-    B, P, I = 512, 70, 70
-    p = synth.make_pairs(B, seed=2024)
+    cf = CONFIGS[config]
+    B, P, I, launches = cf["B"], cf["P"], cf["I"], cf["launches"]
+    p = synth.make_pairs(B, n_beams=cf["beams"], seed=cf["seed"])
     geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
-    grid, cfg = capi.Grid(60, 60, 0.5), capi.PSOConfig.make(I, P)
+    grid, cfg = capi.Grid(60, 60, cf["cs"]), capi.PSOConfig.make(I, P)
     mode = {"exact": capi.SCORE_EXACT, "f32": capi.SCORE_F32}[score]
     ctx = capi.Context(0)
     stream = torch.cuda.current_stream(dev)
@@ -55,7 +60,7 @@ def timed_launches(score, launches=12):
     def launch():
         ctx.align_pairs_dev(B, d_ref.data_ptr(), d_new.data_ptr(), geom, grid, d_guess.data_ptr(), d_dev.data_ptr(), cfg,
                             d_seeds.data_ptr(), 0, mode, d_pose.data_ptr(), d_cost.data_ptr(), d_stats.data_ptr())
-    for _ in range(6):
+    for _ in range(cf["warm"]):
         launch()
     torch.cuda.synchronize()
     rows, ms, spans = [], [], []
@@ -86,20 +91,21 @@ def main():
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--score", default="exact", choices=["exact", "f32"])
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_phase_budget.json"))
+    ap.add_argument("--config", default="config3", choices=list(CONFIGS))
     ap.add_argument("--plain", action="store_true", help="(internal) time the shipped library and print the mean launch time")
     args = ap.parse_args()
     if args.build:
         build()
         return
     if args.plain:
-        ms, spans, _, _ = timed_launches(args.score)
+        ms, spans, _, _ = timed_launches(args.score, config=args.config)
         print(json.dumps({"ms": ms, "span_us": float(sum(s["span_us"] for s in spans) / len(spans))}))
         return
     import numpy as np
-    plain = json.loads(subprocess.check_output([sys.executable, os.path.abspath(__file__), "--plain", "--score", args.score],
+    plain = json.loads(subprocess.check_output([sys.executable, os.path.abspath(__file__), "--plain", "--score", args.score, "--config", args.config],
                                                env={k: v for k, v in os.environ.items() if k != "NDTPSO_LIB"}).decode().strip().splitlines()[-1])
     os.environ["NDTPSO_LIB"] = BUDGET_LIB
-    ms, spans, rows, st = timed_launches(args.score)
+    ms, spans, rows, st = timed_launches(args.score, config=args.config)
     assert rows is not None, "the library loaded is not a -DNDTPSO_PHASE_BUDGET build"
     ph = rows[:, :, :11]                       # [launch, workgroup, phase]
     wg_total = rows[:, :, 15]
@@ -114,8 +120,10 @@ def main():
     budget = [{"phase": n, "mean_us_per_workgroup": float(v), "share_of_kernel_time": float(v / kernel_us)} for n, v in zip(PHASES, mean_phase)]
     accounted = float(mean_phase.sum()) + offset + tail
     out = {
-        "what": "time budget of one launch of the fused pairs kernel, BASELINE config 3 (512 pairs, 1081 beams, 70 particles x 70 iterations), "
-                "score mode %s; diagnostic build -DNDTPSO_PHASE_BUDGET, %d launches x 512 workgroups averaged" % (args.score, rows.shape[0]),
+        "what": "time budget of one launch of the fused pairs kernel, BASELINE %s (%d pairs, %d beams, %d particles x %d iterations, %.2f m cells), "
+                "score mode %s; diagnostic build -DNDTPSO_PHASE_BUDGET, %d launches x %d workgroups averaged"
+                % (args.config, CONFIGS[args.config]["B"], CONFIGS[args.config]["beams"], CONFIGS[args.config]["P"], CONFIGS[args.config]["I"],
+                   CONFIGS[args.config]["cs"], args.score, rows.shape[0], rows.shape[1]),
         "kernel_ms_by_events_instrumented_build": ms,
         "kernel_ms_by_events_shipped_library": plain["ms"],
         "clock_overhead": ms / plain["ms"] - 1.0,
