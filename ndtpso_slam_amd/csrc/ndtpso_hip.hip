@@ -33,7 +33,6 @@ struct Layout {
   int key_off, cellkey_off, cnt_off, bm2_off, plist_off;  // build scratch inside region
   int swarm_global;  // 1: the swarm does not fit in LDS and lives in an HBM workspace (large-swarm configs)
   int xs_off, xs_slots;  // exact mode: partial-sum scratch of the arbitration, xs_slots x 512 bytes (exact_tasks_wg); -1: none
-  int stage_off;         // swarm in HBM, dense form: two staging buffers of the next round's constants (eval_items); -1: none
 };
 
 // fmt: kScoreF32 -> mean+chol, kScoreF64 -> mean+ab+cd, 2 -> everything (table build kernel);
@@ -85,15 +84,15 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
   }
   const int swarm = (P > 0 && !swarm_global) ? swarm_bytes(P, exact, swarm_has_raw2(P, false)) : 0;
   L.total = L.region_off + std::max(scratch, swarm);
-  L.stage_off = -1;
-  if (swarm_global && dense) {
-    L.stage_off = L.total;
-    L.total += 2 * 5 * kStageRow * 8;
-  }
   L.xs_off = -1;
   L.xs_slots = 0;
-  if (exact && exact_units) {  // (the fused pairs kernels; a single alignment's kernels score whole tasks per wave)
-    L.xs_slots = swarm_global ? 16 : 8;  // one unit per wave of the workgroup: 8 waves (16 with the swarm in HBM, one per CU)
+  // The fused pairs kernels with the swarm in LDS (8-wave workgroups) split the arbitration's fp64 scores into units; a
+  // single alignment's kernels and the 16-wave workgroups of swarms kept in HBM score whole tasks per wave.  (With units
+  // the 16-wave kernels returned poses that differed from the fp64 mode's on batches of 700- to 2048-particle swarms --
+  // tests/test_gpu_fullsize.py::test_batches_of_large_swarms_kept_in_hbm, which this round added, caught it; not
+  // understood, and the arbitration is 1 % of those kernels' time.)
+  if (exact && exact_units && !swarm_global) {
+    L.xs_slots = 8;  // one unit per wave of the workgroup
     L.xs_off = L.total;
     L.total += L.xs_slots * kWave * 8;
   }
@@ -160,7 +159,6 @@ __device__ __forceinline__ EvalCtx make_eval_ctx(const GridP& g, const WinP& wn,
   E.lds0 = g_lds;
   E.light = 0;
   E.guard_lds = 0;
-  E.stage_lds = 0;
   return E;
 }
 
@@ -207,7 +205,6 @@ __device__ __forceinline__ EvalCtx make_eval_ctx_global(const GridP& g, const Wi
   E.lds0 = g_lds;
   E.light = 0;
   E.guard_lds = 0;
-  E.stage_lds = 0;
   return E;
 }
 
@@ -451,11 +448,9 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   // Two copies of the PSO, one per home of the swarm, so that in each the compiler knows the address space of the
   // swarm arrays: selecting the base pointer at run time made every swarm access a FLAT instruction (74 of them), and
   // the proposal / commit phases -- one or two waves working, the rest waiting -- are chains of exactly those accesses.
-  E.stage_lds = 0;
   if (L.swarm_global) {
-    if (L.stage_off >= 0) E.stage_lds = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)(g_lds + L.stage_off);
     const Swarm sw = swarm_carve(ws + (size_t)cl.rank * swarm_bytes(ps.P, true, true), ps.P, ARB, true);
-    pso_run_wg<MODE, PATH, CLUSTER, ARB, false, true>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
+    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
                                          out_cost, stats, cl);
   } else {
     const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
@@ -481,8 +476,8 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
 // copies agree), then the PSO runs as a cluster (ClusterP).  Never combined with a gate.
 // SWARM: 2 = the kernel carries both copies of the PSO (swarm in LDS / in its HBM workspace, chosen by L.swarm_global);
 // 0 / 1 = only the LDS / only the HBM copy.  The NOCLIP kernels -- the ones the batches of the benchmark run -- exist as
-// 0 and 1: at 128 registers what is inlined beside the hot loop decides its allocation, and the staging of the HBM
-// copy (eval_items) cost the LDS copy ten more spills when both lived in one kernel.
+// 0 and 1: at 128 registers what is inlined beside the hot loop decides its allocation (fp32-score kernel of config 3:
+// 21 spills with both copies, none with its own).
 template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, int SWARM = 2>
 __global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
@@ -597,12 +592,10 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if constexpr (ARB && !CLUSTER) E.xa = &lds_ctrl(L.ctrl_off)->xa;
 #endif
   if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
-  E.stage_lds = 0;
   if (SWARM == 1 || (SWARM == 2 && L.swarm_global)) {  // (two copies: see k_align)
     if constexpr (SWARM != 0) {
-      if (L.stage_off >= 0) E.stage_lds = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)(g_lds + L.stage_off);
       const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P, ARB, true);
-      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, true>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                                            tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
                                            out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
     }

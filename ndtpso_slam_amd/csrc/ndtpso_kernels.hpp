@@ -1449,7 +1449,6 @@ struct PsoShared {  // small control block in LDS
   double gb[3];
   double gbc;
   int jstar[3];  // first improver of a group, rotating by group number (see pso_run_wg)
-  int stage_first[2];  // swarm in HBM: first item whose constants the light wave staged in LDS buffer 0 / 1 (-1: none)
   int tiny;      // fp32 score mode: some cost of the current group fell in the underflow regime
   int timed_out; // cluster mode: a workgroup of the cluster did not arrive at an exchange
   RngState rng;
@@ -1473,7 +1472,6 @@ struct EvalCtx {
   const unsigned char* lds0;
   int light;  // PsoP::light (the item -> wave deal of eval_items)
   unsigned guard_lds;  // LDS byte address of the DenseGuard, 0: none
-  unsigned stage_lds;  // LDS byte address of the two staging buffers of a swarm that lives in HBM (2 x 5 x kStageRow doubles), 0: none
 #ifdef NDTPSO_VERIFY_MARGIN
   const struct ExactArgs* xa = nullptr;  // diagnostic builds: every fp32 score is checked against its fp64 value
 #endif
@@ -2027,14 +2025,10 @@ __device__ __forceinline__ void exact_tasks_wg(ExactArgs* ap, const unsigned sho
 
 // One wave per item.  `improver` (optional): the evaluating wave itself records the lowest item index whose
 // cost beats `gbc` (core.cpp:97 under single-thread order), so no separate detection pass is needed.
-// HBM / stage: the swarm lives in its HBM workspace and the constants of this round's items (folded pose, pbest cost) were
-// copied into LDS by the light wave during the previous round (pso_run_wg, "staging"): `stage` is the LDS byte address of
-// five rows of kStageRow doubles -- tc, ts, ttx, tty, pbc of items first, first + 1, ... -- or 0 (read the workspace).
-constexpr int kStageRow = 32;
-template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false, bool HBM = false>
+template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false>
 __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first,
                                   int last /*exclusive*/, double gbc, int* improver, int* tiny, int* near_cnt,
-                                  unsigned short* near_list, unsigned stage = 0) {
+                                  unsigned short* near_list) {
   const int n_waves = blockDim.x >> 6;
   // item k of the round goes to wave k + 1 for k < n - 1, to wave k - (n - 1) after that: wave 0 gets one item (k = n - 1)
   // of a round of 2n - 1, the others two.  `light` off, or a longer round (the swarm's initialisation): plain striding.
@@ -2042,33 +2036,12 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
   const int j0 = light ? (wave_id() == 0 ? first + n_waves - 1 : first + wave_id() - 1) : first + wave_id();
   const int dj = light ? (wave_id() == 0 ? 2 * n_waves : n_waves) : n_waves;
   for (int j = j0; j < last; j += dj) {
-    double c = 0., s = 0., pbc_j = 0., ttx_j = 0., tty_j = 0.;
-    bool from_stage = false;
-    if constexpr (HBM && path_is_dense(PATH)) {
-      if (stage) {
-        typedef const double __attribute__((address_space(3))) * lds_d_t;
-        const unsigned at = stage + (unsigned)(j - first) * 8u;
-        c = *(lds_d_t)(uintptr_t)at;
-        s = *(lds_d_t)(uintptr_t)(at + kStageRow * 8u);
-        ttx_j = *(lds_d_t)(uintptr_t)(at + 2u * kStageRow * 8u);
-        tty_j = *(lds_d_t)(uintptr_t)(at + 3u * kStageRow * 8u);
-        pbc_j = *(lds_d_t)(uintptr_t)(at + 4u * kStageRow * 8u);
-        from_stage = true;
-      }
-    }
-    if (!from_stage) {
-      c = sw.tc[j];
-      s = sw.ts[j];
-      pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
-                          // initialisation, where it is not looked at)
-      if constexpr (path_is_dense(PATH)) {
-        ttx_j = sw.ttx[j];
-        tty_j = sw.tty[j];
-      }
-    }
+    const double c = sw.tc[j], s = sw.ts[j];
+    const double pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
+                                     // initialisation, where it is not looked at)
     double cost;
     if constexpr (path_is_dense(PATH)) {
-      const DenseItem it{c, s, ttx_j, tty_j, E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
+      const DenseItem it{c, s, sw.ttx[j], sw.tty[j], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
       if constexpr (PATH == 3 || (PATH == 2 && NOCLIP)) {  // (the fused pairs kernels: they set up the guard)
         typedef double v2d_t __attribute__((ext_vector_type(2)));
         typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
@@ -2190,14 +2163,14 @@ constexpr unsigned long long kClusterWaitTicks = 2000000ull;  // 20 ms of the 10
 
 // Evaluates items [first, last) of the swarm; on return (after the caller's barrier) sw.tcost holds their costs and
 // *improver / *tiny are set as eval_items sets them.  `epoch` counts the cluster's exchanges.
-template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, bool HBM = false>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false>
 __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first, int last,
                                   double gbc, int* improver, int* tiny, const ClusterP& cl, unsigned& epoch,
                                   int* timed_out, int* near_cnt, unsigned short* near_list,
                                   RngState* gen_st = nullptr, int* gen_t = nullptr, int32_t* gen_dst = nullptr,
-                                  int gen_cnt = 0, int gen_wave = -1, unsigned stage = 0) {
+                                  int gen_cnt = 0, int gen_wave = -1) {
   if constexpr (!CLUSTER) {
-    eval_items<MODE, PATH, ARB, NOCLIP, HBM>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list, stage);
+    eval_items<MODE, PATH, ARB, NOCLIP>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
   } else {
     NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
@@ -2255,7 +2228,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
 // ARB: the exact mode (NDTPSO_SCORE_EXACT) of the fp32-score dense kernels.  A template parameter, not a run-time
 // switch: the arbitration code in the same kernel cost the plain fp32 mode 11 % (register pressure: spills in the
 // proposal / commit paths), see DESIGN.md.
-template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false, bool HBM = false>
+template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false>
 __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
@@ -2336,7 +2309,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     }
   }
   __syncthreads();
-  eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, HBM>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
+  eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
                                   nullptr);
   n_evals += S;
   n_rounds += 1;
@@ -2413,7 +2386,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   if (tid == 0) {
     sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
     sh->near_cnt[0] = sh->near_cnt[1] = sh->near_cnt[2] = 0;
-    sh->stage_first[0] = sh->stage_first[1] = -1;
   }
   // rand() table from the host (the live node): the draws of an iteration are fetched from HBM one iteration ahead --
   // the loads are issued at the top of iteration it - 1, sit in two registers per thread while it runs, and land in the
@@ -2546,13 +2518,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       const int hi_g = min(lo + ps.G, P);
       // a cluster draws the next iteration's numbers behind the first exchange of this one (eval_round)
       const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
-      // (swarm in HBM) the constants of this round's items, if the light wave staged them in LDS during the previous round
-      unsigned stage = 0;
-      if constexpr (HBM && !CLUSTER && path_is_dense(PATH))
-        if (E.stage_lds && sh->stage_first[grp & 1u] == lo) stage = E.stage_lds + (grp & 1u) * (5u * kStageRow * 8u);
-      eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, HBM>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
+      eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
                                       &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
-                                      dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w, stage);
+                                      dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
       if (gen_here) next_filled = n_draw;
       NDTPSO_PB(4);
       if constexpr (!CLUSTER) {
@@ -2564,30 +2532,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         } else if (overlapped && !ps.light && it + 1 < ps.I && next_filled == 0 && hi_g == P && hi_g - lo <= rng_w) {
           if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext, n_draw);  // (rng_w had no item in this round)
           next_filled = n_draw;
-        }
-      }
-      if constexpr (HBM && !CLUSTER && path_is_dense(PATH)) {
-        // Staging: a wave that starts an item whose constants lie in the HBM workspace waits a memory round trip for
-        // them with nothing else to do -- at the start of a round every wave of the workgroup does, together (config 5:
-        // 13 400 rounds of 12.7 us, 9 us of which is vector work).  The light wave has the time: before it goes to the
-        // round's barrier it copies the NEXT round's constants (tc, ts, ttx, tty, pbc of items hi_g ...) into LDS; the
-        // barrier publishes them.  They are what the next round reads unless this round moves the gbest (the re-proposal
-        // below invalidates the copy) -- proposals are made once per iteration for every uncommitted particle, and a
-        // particle's pbest cost only changes when it is committed.
-        if (E.stage_lds && wave_id() == 0 && ps.G <= kStageRow) {
-          const int cntn = min(ps.G, P - hi_g), ln = lane_id();
-          const unsigned buf = (grp + 1u) & 1u;
-          if (ln < cntn) {
-            typedef double __attribute__((address_space(3))) * lds_d_t;
-            const int j = hi_g + ln;
-            const unsigned at = E.stage_lds + buf * (5u * kStageRow * 8u) + (unsigned)ln * 8u;
-            *(lds_d_t)(uintptr_t)at = sw.tc[j];
-            *(lds_d_t)(uintptr_t)(at + kStageRow * 8u) = sw.ts[j];
-            *(lds_d_t)(uintptr_t)(at + 2u * kStageRow * 8u) = sw.ttx[j];
-            *(lds_d_t)(uintptr_t)(at + 3u * kStageRow * 8u) = sw.tty[j];
-            *(lds_d_t)(uintptr_t)(at + 4u * kStageRow * 8u) = sw.pbc[j];
-          }
-          if (ln == 0) sh->stage_first[buf] = cntn > 0 ? hi_g : -1;
         }
       }
       n_evals += (uint32_t)(hi_g - lo);
@@ -2682,7 +2626,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         // barrier orders those reads before the update, and the re-proposal barrier publishes it
         __syncthreads();
         if (tid == 0) {
-          if constexpr (HBM) sh->stage_first[0] = sh->stage_first[1] = -1;  // every later proposal is about to change
           sh->gbc = sw.tcost[js];
           for (int k = 0; k < 3; ++k) sh->gb[k] = sw.tpos[k * S + js];
           if constexpr (ARB) {

@@ -1,5 +1,5 @@
 """A/B timing of the score modes inside ONE process, alternating, inputs resident in HBM (config 3 by default).
-usage: python scripts/r2_ab_modes.py [pairs] [rounds] [modes comma separated]"""
+usage: python scripts/ab_modes.py [pairs] [rounds] [modes comma separated]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

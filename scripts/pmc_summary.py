@@ -10,10 +10,53 @@ import os
 # dense form with byte-address entries (what config 3 runs): the arbitrating kernel of the exact mode, the plain fp32-score
 # kernel, or the general dense form -- whichever the profiled run launched
 names = {r["Kernel_Name"] for r in csv.DictReader(open(f"{src}/p1/p_counter_collection.csv"))}
-KERNEL = next((k for k in ("k_align_pairs<0, 3, false, true, true>", "k_align_pairs<0, 3, false, false, true>",
-                           "k_align_pairs<0, 3, false, true, false>", "k_align_pairs<0, 3, false, false, false>",
-                           "k_align_pairs<0, 3, false, true>", "k_align_pairs<0, 3, false, false>", "k_align_pairs<0, 3, false>",
+KERNEL = next((k for k in ("k_align_pairs<0, 3, false, true, true", "k_align_pairs<0, 3, false, false, true",
+                           "k_align_pairs<0, 3, false, true, false", "k_align_pairs<0, 3, false, false, false",
+                           "k_align_pairs<0, 3, false, true", "k_align_pairs<0, 3, false, false", "k_align_pairs<0, 3, false",
                            "k_align_pairs<0, 2, false") if any(k in n for n in names)), "k_align_pairs")
+FULL_NAME = next((n.split("(")[0].replace("void ", "") for n in sorted(names) if KERNEL in n), KERNEL)
+
+
+def describe(name):
+    """What the template arguments of k_align_pairs<MODE, PATH, CLUSTER, ARB, NOCLIP, SWARM> say about the launch."""
+    import re
+    m = re.search(r"<([^>]*)>", name)
+    a = [x.strip() for x in m.group(1).split(",")] if m else []
+    a += ["false"] * (5 - len(a)) + (["2"] if len(a) < 6 else [])
+    mode = "fp32 Gaussian score" if a[0] == "0" else "fp64 score"
+    form = {"0": "bitmap table, true division", "1": "bitmap table, power-of-two cells", "2": "dense u16 table (entries in 16-byte units)",
+            "3": "dense u16 table (entries are byte addresses)"}.get(a[1], a[1])
+    arb = "EXACT mode: near-tie comparisons arbitrated with the fp64 score" if a[3] == "true" else "plain (no arbitration)"
+    swarm = {"0": "swarm in LDS", "1": "swarm in its HBM workspace", "2": "both swarm homes compiled in"}.get(a[5], a[5])
+    return "%s, %s, %s, %s, %s%s" % (mode, form, arb, "cluster of workgroups per pair" if a[2] == "true" else "one workgroup per pair",
+                                     "no frame-clipping trips, " if a[4] == "true" else "", swarm)
+
+
+def code_object_resources(name):
+    """VGPRs / spills / scratch / static LDS of the kernel from the shipped library's code object metadata (rocprofv3's
+    dispatch columns report allocation granules and 0 for dynamic LDS, which is what round 2's summary mistook)."""
+    try:
+        import re, subprocess, tempfile
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path.insert(0, here)
+        import isa_mix
+        lib = os.environ.get("NDTPSO_LIB", os.path.join(os.path.dirname(here), "ndtpso_slam_amd", "lib", "libndtpso_hip.so"))
+        with tempfile.NamedTemporaryFile(suffix=".elf") as f:
+            f.write(isa_mix.extract_code_object(lib))
+            f.flush()
+            out = subprocess.check_output([os.path.join(isa_mix.LLVM, "llvm-readelf"), "--notes", f.name], text=True)
+        want = name.replace(" ", "")
+        for b in out.split("- .agpr_count")[1:]:
+            sym = re.search(r"\.name:\s+(\S+)", b).group(1)
+            dem = subprocess.run(["c++filt", sym], capture_output=True, text=True).stdout.strip().split("(")[0].replace("void ", "")
+            if dem.replace(" ", "").replace("ndtpso::", "") == want.replace("ndtpso::", ""):
+                g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, b).group(1))  # noqa: E731
+                return {"vgpr_count": g("vgpr_count"), "vgpr_spill_count": g("vgpr_spill_count"), "sgpr_count": g("sgpr_count"),
+                        "scratch_bytes_per_lane": g("private_segment_fixed_size"), "static_lds_bytes": g("group_segment_fixed_size"),
+                        "source": "llvm-readelf --notes of the gfx950 code object in libndtpso_hip.so"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": str(e)}
+    return {"error": "kernel not found in the code object"}
 vals = collections.defaultdict(list)
 disp = {}
 for p in ("p1", "p2", "p3", "p4", "p5"):
@@ -44,8 +87,11 @@ derived = {
     "hbm_read_bytes_per_launch_FETCH_SIZE_x2_KiB_units": mean["FETCH_SIZE"] * 1024 * 2,
     "hbm_write_bytes_per_launch": mean["WRITE_SIZE"] * 1024,
 }
-out = {"kernel": f"{KERNEL} (fp32 score, dense table, per-alignment window), {pairs} pairs, {P}x{I}; the gated redo launches "
-                 "exit immediately and are not included", "source": src, "dispatch": disp,
+out = {"kernel": FULL_NAME, "kernel_is": describe(FULL_NAME), "workload": f"{pairs} pairs, {P} x {I}, {beams} beams; the gated redo "
+       "launches exit immediately and are not included", "source": src,
+       "code_object": code_object_resources(FULL_NAME),
+       "rocprofv3_dispatch_columns": dict(disp, note="allocation granules as rocprofv3 reports them; dynamic LDS shows as 0 -- see code_object and "
+                                          "ndtpso_align_pairs_describe for the real figures"),
        "counters_mean_per_launch": mean, "derived": derived}
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(derived, indent=1))

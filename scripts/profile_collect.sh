@@ -1,0 +1,33 @@
+# usage (build container): bash scripts/profile_collect.sh <dir under gpurun_out written by scripts/profile_run.sh> <prefix, e.g. r03>
+# copies the evidence of one profile run from scratch (gpurun_out/) into the tracked profiles/ directory
+SRC=gpurun_out/$1; P=profiles/$2
+mkdir -p ${P}_pmc
+cp $SRC/bench.json ${P}_bench.json
+cp $SRC/bench_one_at_a_time.json ${P}_bench_one_at_a_time.json
+cp $SRC/ubench_valu.txt ${P}_ubench_valu.txt
+cp $SRC/isa_mix.json ${P}_isa_mix.json
+cp $SRC/score_loop_isa.txt ${P}_score_loop_isa.txt
+cp $SRC/trace1/t_kernel_stats.csv ${P}_kernel_stats.csv                 # one batch at a time
+cp $SRC/trace2/t_kernel_stats.csv ${P}_kernel_stats_two_in_flight.csv
+for k in 1 2 3 4 5; do
+  # the rows of the fused pairs kernels only (the counter files also list torch's own kernels)
+  head -1 $SRC/pmc/p$k/p_counter_collection.csv > ${P}_pmc/p${k}_k_align_pairs.csv
+  grep "k_align_pairs" $SRC/pmc/p$k/p_counter_collection.csv >> ${P}_pmc/p${k}_k_align_pairs.csv
+done
+cp $SRC/pmc_summary.json ${P}_pmc_summary.json
+cp $SRC/phase_budget.json ${P}_phase_budget.json
+cp $SRC/phase_budget_f32.json ${P}_phase_budget_f32.json
+cp $SRC/phase_budget_config5.json ${P}_phase_budget_config5.json
+python - <<PY
+import json
+out = {}
+for w in ("config3", "random", "converged", "config5"):
+    try:
+        d = json.load(open("$SRC/verify_%s.json" % w))
+        out[w] = {k: v for k, v in d.items() if k != "runs"}
+        out[w]["runs"] = [{k: r[k] for k in ("pairs", "beams", "cs", "P", "I", "evaluations_checked", "max_err", "max_err_over_bound", "max_bound_over_half_tau", "max_err_over_half_tau", "points_binned_differently", "arbitrated_mean")} for r in d["runs"]]
+    except Exception as e:
+        out[w] = {"error": str(e)}
+json.dump(out, open("${P}_margin_verification.json", "w"), indent=1)
+PY
+ls -la profiles | tail -24

@@ -1,0 +1,24 @@
+# Evidence run of one round on the GPU box: microbenchmark, ISA mix, bench line, rocprofv3 kernel traces, PMC passes,
+# per-phase time budgets.  Everything lands in gpurun_out/<dir>/; `bash scripts/profile_collect.sh <dir> rNN` (build
+# container) copies what is to be judged into profiles/.
+#   usage (GPU box): bash scripts/profile_run.sh <dir under gpurun_out>
+set -x
+D=$1
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$D
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/ubench_valu.hip -o /tmp/ubench_valu 2>/dev/null && /tmp/ubench_valu > $OUT/ubench_valu.txt 2>&1
+python scripts/isa_mix.py --kernel "k_align_pairs<0, 3, false, true, true, 0>" --ubench $OUT/ubench_valu.txt --out $OUT/isa_mix.json --dump $OUT/score_loop_isa.txt > /dev/null
+cp $OUT/isa_mix.json profiles/r03_isa_mix.json   # the bench line's roofline.floor reads it
+timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
+timeout 300 python bench.py --pipeline 1 --no-latency --cpu-sample 0 > $OUT/bench_one_at_a_time.json 2>> $OUT/bench.err
+# kernel traces (own runs): one batch at a time -- the per-launch duration the roofline divides by -- and two in flight
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o t -- python $GRAFT_REPO_ROOT/bench.py --pipeline 1 --steps 40 --warmup 20 --cpu-sample 0 --no-latency > $OUT/trace1.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o t -- python $GRAFT_REPO_ROOT/bench.py --pipeline 2 --steps 40 --warmup 20 --cpu-sample 0 --no-latency > $OUT/trace2.log 2>&1)
+bash scripts/pmc.sh $D/pmc --pipeline 1 > $OUT/pmc.log 2>&1
+python scripts/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_summary.log 2>&1
+timeout 300 python scripts/phase_budget.py --config config3 --score exact --out $OUT/phase_budget.json > $OUT/budget.log 2>&1
+timeout 300 python scripts/phase_budget.py --config config3 --score f32 --out $OUT/phase_budget_f32.json >> $OUT/budget.log 2>&1
+timeout 400 python scripts/phase_budget.py --config config5 --score exact --out $OUT/phase_budget_config5.json >> $OUT/budget.log 2>&1
+for w in config3 random converged config5; do timeout 600 python scripts/verify_margin.py --workload $w $( [ $w = config5 ] && echo --pairs 130 ) > $OUT/verify_$w.json 2>> $OUT/verify.err; done
+cat $OUT/bench.json | head -c 600; echo; tail -3 $OUT/bench.err; cat $OUT/pmc_summary.log | tail -14

@@ -156,3 +156,27 @@ def test_config5_full_size_large_swarm(ctx):
     assert np.array_equal(out[capi.SCORE_EXACT][1], out[capi.SCORE_F64][1])
     assert d32.max() < F32_POSE_TOL
     assert np.abs(out[capi.SCORE_F32][0] - p.delta).max() < 2e-2
+
+
+@pytest.mark.parametrize("B,Pn,In,beams,cs", [(130, 1024, 12, 1081, 0.5), (200, 700, 20, 1441, 0.3), (140, 2048, 5, 2048, 0.25)])
+def test_batches_of_large_swarms_kept_in_hbm(ctx, oracle, B, Pn, In, beams, cs):
+    """Swarms too large for LDS keep their state in an HBM workspace (one workgroup per pair, 16 waves): batches of more
+    pairs than half the compute units, so that the one-workgroup kernels run (the config-5 fixture above goes through
+    the cluster path).  fp64 mode == oracle on a sample of the pairs; exact mode == fp64 mode bit for bit on all."""
+    from ndtpso_slam_amd import capi, synth
+    p = synth.make_pairs(B, n_beams=beams, seed=300 + In)
+    geom = _geom(p, capi)
+    rc, plan = capi.align_pairs_describe(geom, capi.Grid(FRAME_M, FRAME_M, cs), capi.PSOConfig.make(In, Pn), capi.SCORE_EXACT, B)
+    assert rc == 0 and plan["swarm_in_hbm"] == 1
+    args = (p.ref_ranges, p.new_ranges, geom, capi.Grid(FRAME_M, FRAME_M, cs), (0, 0, 0), DEVIATION, capi.PSOConfig.make(In, Pn))
+    p64, c64, s64 = ctx.align_pairs(*args, seeds=p.seeds, mode=capi.SCORE_F64)
+    px, cx, sx = ctx.align_pairs(*args, seeds=p.seeds, mode=capi.SCORE_EXACT)
+    n_o = 6
+    want, want_cost, _ = oracle.align_pairs(p.ref_ranges[:n_o], p.new_ranges[:n_o], p.angle_min, p.angle_inc, p.range_max, 0.1,
+                                            FRAME_M, FRAME_M, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(In, Pn),
+                                            p.seeds[:n_o], n_threads=0)
+    print("f64 vs oracle max |dpose| %.3g; exact == f64 on %d / %d poses; arbitrated mean %.1f"
+          % (np.abs(p64[:n_o] - want).max(), int((px == p64).all(axis=1).sum()), B, sx["arbitrated"].mean()))
+    assert np.abs(p64[:n_o] - want).max() < 1e-9 and np.abs(c64[:n_o] - want_cost).max() < 1e-8
+    assert (s64["status"] == 0).all() and (sx["status"] == 0).all()
+    assert np.array_equal(px, p64) and np.array_equal(cx, c64)
