@@ -393,7 +393,8 @@ def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms,
     v_exp_f32 is charged as ONE fp32 flop although it issues at a quarter of the fp32 rate (frac_exp_at_quarter_rate
     charges it 4).  `floor` keeps round 2's instruction-level figure: the issue time of the score loop's actual
     instruction mix (scripts/isa_mix.py x scripts/ubench_valu.hip) -- useful for tuning, not a roofline."""
-    mix = _load_json("r03_isa_mix.json") or _load_json("r02_isa_mix.json")
+    mix_name = "r03_isa_mix.json" if _load_json("r03_isa_mix.json") else "r02_isa_mix.json"
+    mix = _load_json(mix_name)
     point_evals = float(stats["n_points"].astype(np.float64).sum()) * evals_nominal
     flops = point_evals * (FLOP_FP64 + FLOP_FP32 + FLOP_EXP)
     t_peak_s = point_evals * (FLOP_FP64 / (VEC_FP64_TFLOPS * 1e12) + (FLOP_FP32 + FLOP_EXP) / (VEC_FP32_TFLOPS * 1e12))
@@ -419,7 +420,7 @@ def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms,
                       "frac_of_kernel_ms": point_evals / issue_peak * 1e3 / kern_ms,
                       "what": "issue time of the score loop's own instruction mix on 1024 SIMDs (a shorter loop lowers it): a tuning "
                               "figure, not the roofline",
-                      "source": "profiles/r02_isa_mix.json (scripts/isa_mix.py), profiles/r02_score_loop_isa.txt, profiles/r02_ubench_valu.txt"}
+                      "source": "profiles/%s (scripts/isa_mix.py: llvm-objdump of the shipped kernel x scripts/ubench_valu.hip on this chip)" % mix_name}
     r["hbm_effective"] = {"achieved": hbm_equiv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_equiv_gbs / HBM_PEAK_GBS,
                           "algorithmic_bytes_per_launch": algo_bytes,
                           "note": "SURVEY 8(d)'s streaming-equivalent accounting: 40 B per point evaluation (16 B point + 24 B cell "
