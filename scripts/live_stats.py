@@ -18,7 +18,7 @@ ctx = capi.Context(0)
 rmap = capi.ResidentMap(ctx, grid, og_cell_size=0.1, pool_bytes=256 << 20)
 scan = capi.ResidentScan(ctx, 4096)
 prev = np.zeros(3); hist = [np.zeros(3), np.zeros(3)]
-arb, flags, evals, ts = [], [], [], []
+arb, flags, evals, ts, rounds = [], [], [], [], []
 for k in range(n):
     t0 = time.perf_counter()
     scan.load_scan(ranges[k], geom, clip=grid)
@@ -26,11 +26,11 @@ for k in range(n):
         dev = np.array((0.1, 0.1, 3.1415e-3)) if k <= 2 else np.abs(2.0 * (hist[-1] - hist[-2]))
         prev, _, st = rmap.align(scan, prev, dev, cfg, rand_table=tables[k], mode=mode)
         hist.append(prev.copy())
-        arb.append(int(st["arbitrated"])); flags.append(int(st["status"]) & 0xffff); evals.append(int(st["cost_evals"]))
+        arb.append(int(st["arbitrated"])); flags.append(int(st["status"]) & 0xffff); evals.append(int(st["cost_evals"])); rounds.append(int(st["rounds"]))
     rmap.insert(scan, prev)
     ts.append(time.perf_counter() - t0)
 ctx.synchronize()
-arb = np.array(arb); ts = np.array(ts[5:])
+arb = np.array(arb); ts = np.array(ts[5:]); print("rounds field mean (arbitration ticks / 100 = us in -DNDTPSO_PROFILE_ARB builds): %.1f" % (np.mean(rounds) / 100.0))
 print("scans %d  ms/scan median %.3f mean %.3f  -> %.0f scans/s" % (n, 1e3 * np.median(ts), 1e3 * ts.mean(), 1 / ts.mean()))
 print("arbitrated per alignment: mean %.2f median %d p90 %d max %d; alignments with status flags %d; evals mean %.0f"
       % (arb.mean(), np.median(arb), np.percentile(arb, 90), arb.max(), int((np.array(flags) != 0).sum()), np.mean(evals)))
