@@ -1512,6 +1512,8 @@ struct AlignSrc {
   const double2* xy;
   uint32_t n;
   const uint32_t* n_ptr;
+  bool want_cost = true;  // false: the caller asked for the pose only (NDTFrame::align does) -- the exact mode then skips
+                          // the fp64 score of the returned pose, which nothing else needs
 };
 
 // How many workgroups share one alignment (cluster mode, see ClusterP).  One item per wave and round: enough waves
@@ -1601,7 +1603,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
                      src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
                      ps, (const double*)c->table.p, (const double*)c->table.p + 3, seed,                           \
                      have_table ? (const int32_t*)((const unsigned char*)c->table.p + kGuessBytes) : nullptr,      \
-                     (unsigned char*)c->ws.p, d_out, d_out + 3, d_stats, cl)
+                     (unsigned char*)c->ws.p, d_out, src.want_cost ? d_out + 3 : nullptr, d_stats, cl)
 #define LAUNCH_ALIGN_C(MODE, PATH, CL) LAUNCH_ALIGN_CA(MODE, PATH, CL, false)
 #define LAUNCH_ALIGN(MODE, PATH) \
   do { if (K > 1) LAUNCH_ALIGN_C(MODE, PATH, true); else LAUNCH_ALIGN_C(MODE, PATH, false); } while (0)
@@ -1674,7 +1676,7 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   double gd[6] = {guess[0], guess[1], guess[2], deviation[0], deviation[1], deviation[2]};
   HIP_TRY(c, c->pinned.upload2(c->table.p, gd, sizeof(gd), kGuessBytes, rand_table, rand_table ? n_draw * 4 : 0, c->stream));
-  const AlignSrc src{(const unsigned char*)c->image.p, c->g, c->wn, (const double2*)c->xy2.p, n, nullptr};
+  const AlignSrc src{(const unsigned char*)c->image.p, c->g, c->wn, (const double2*)c->xy2.p, n, nullptr, out_cost != nullptr};
   return align_finish(c, src, cfg, seed, rand_table != nullptr, mode, out_pose, out_cost, stats);
 }
 

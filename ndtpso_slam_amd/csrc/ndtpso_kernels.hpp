@@ -2670,9 +2670,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   bool exact_cost = false;
 #ifndef NDTPSO_NO_FINAL_EXACT
   if constexpr (ARB) {
-    {  // exact mode: the returned cost is the fp64 score of the returned pose (what the fp64 mode holds)
-      exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, nullptr, 0, 2);
-      exact_cost = true;
+    if (out_cost) {  // exact mode: the returned cost is the fp64 score of the returned pose (what the fp64 mode holds);
+      exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, nullptr, 0, 2);  // a caller that takes the pose only (NDTFrame::align) has
+      exact_cost = true;                                           // passed no cost pointer and is spared the score
     }
   }
 #endif
