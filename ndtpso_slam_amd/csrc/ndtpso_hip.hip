@@ -841,18 +841,22 @@ PsoP make_pso(const ndtpso_pso_config* c, int waves, int mode) {
   PsoP p;
   p.P = c->population;
   p.I = c->iterations;
-  int k = 2;  // particles per evaluation round = k x waves
+  // items per wave and evaluation round.  Two, except for large swarms: a gbest update costs the tail of ONE round in
+  // re-evaluations, which at 2048 particles is nothing (0.1 % with rounds of 61), while every round costs its barrier
+  // and the ramp-down of its last waves -- config 5: 167.7 ms per 256 pairs with two items per wave, 162.6 with four
+  // (158.1 -> 152.2 in the fp32 mode); at 70 particles four items lose 1.5 % (config 3) to 8 % (30 x 50).
+  int k = c->population >= 512 ? 4 : 2;
   if (const char* e = std::getenv("NDTPSO_GROUP")) k = std::max(1, std::atoi(e));  // tuning knob
   p.G = std::min(std::max(waves * k, 1), std::max(c->population, 1));
-  // light wave (PsoP::light): rounds of 2 x waves - 1, wave 0 takes one item and does the commits and the generator
+  // light wave (PsoP::light): rounds of k x (waves - 1) + 1, wave 0 takes one item and does the commits and the generator
   static const bool light = [] {
     const char* e = std::getenv("NDTPSO_LIGHT_WAVE");  // tuning knob: =0 deals every wave two items
     return !(e && e[0] == '0');
   }();
   // (not for the fp64 score: its evaluations are three times as long, the light wave's idle half-round costs more
   // than the commits and the generator it hides -- 7.11 against 6.84 ms per 512 pairs)
-  p.light = (light && k == 2 && waves >= 2 && mode != NDTPSO_SCORE_F64) ? 1 : 0;
-  if (p.light) p.G = std::min(2 * waves - 1, std::max(c->population, 1));
+  p.light = (light && k >= 2 && waves >= 2 && mode != NDTPSO_SCORE_F64) ? k : 0;  // items per wave other than wave 0
+  if (p.light) p.G = std::min(k * (waves - 1) + 1, std::max(c->population, 1));
   p.w = c->w;
   p.c1 = c->c1;
   p.c2 = c->c2;

@@ -53,7 +53,7 @@ struct ScanP {
 struct PsoP {
   int P, I;
   int G;  // particles evaluated per round: 2 x waves - 1 with a light wave (below), else a multiple of the wave count
-  int light;  // 1: wave 0 takes ONE item of a round, every other wave two -- wave 0 is the wave that commits the round
+  int light;  // k >= 2: wave 0 takes ONE item of a round, every other wave k -- wave 0 is the wave that commits the round
               // before and replays glibc's generator, and with a full share it kept the other waves waiting at the
               // round's barrier for exactly that long (one-workgroup kernels; a cluster deals its items differently)
   double w, c1, c2, wdamp;
@@ -2030,12 +2030,15 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
                                   int last /*exclusive*/, double gbc, int* improver, int* tiny, int* near_cnt,
                                   unsigned short* near_list) {
   const int n_waves = blockDim.x >> 6;
-  // item k of the round goes to wave k + 1 for k < n - 1, to wave k - (n - 1) after that: wave 0 gets one item (k = n - 1)
-  // of a round of 2n - 1, the others two.  `light` off, or a longer round (the swarm's initialisation): plain striding.
-  const bool light = E.light && last - first <= 2 * n_waves - 1;
-  const int j0 = light ? (wave_id() == 0 ? first + n_waves - 1 : first + wave_id() - 1) : first + wave_id();
-  const int dj = light ? (wave_id() == 0 ? 2 * n_waves : n_waves) : n_waves;
-  for (int j = j0; j < last; j += dj) {
+  // Light-wave deal (E.light = k >= 2 items per other wave): a round of k (n - 1) + 1 items; wave w >= 1 takes items
+  // w - 1, w - 1 + (n - 1), ... below k (n - 1), wave 0 the one item behind them.  `light` off, or a longer round (the
+  // swarm's initialisation): plain striding.
+  const int heavy_items = E.light * (n_waves - 1);
+  const bool light = E.light && last - first <= heavy_items + 1;
+  const int j0 = light ? (wave_id() == 0 ? first + heavy_items : first + wave_id() - 1) : first + wave_id();
+  const int dj = light ? (n_waves - 1) : n_waves;
+  const int jend = (light && wave_id() != 0) ? min(last, first + heavy_items) : (light ? min(last, j0 + 1) : last);
+  for (int j = j0; j < jend; j += dj) {
     const double c = sw.tc[j], s = sw.ts[j];
     const double pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
                                      // initialisation, where it is not looked at)
