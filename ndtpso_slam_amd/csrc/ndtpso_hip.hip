@@ -450,7 +450,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   // the proposal / commit phases -- one or two waves working, the rest waiting -- are chains of exactly those accesses.
   if (L.swarm_global) {
     const Swarm sw = swarm_carve(ws + (size_t)cl.rank * swarm_bytes(ps.P, true, true), ps.P, ARB, true);
-    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
+    pso_run_wg<MODE, PATH, CLUSTER, ARB, false, true>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
                                          out_cost, stats, cl);
   } else {
     const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
@@ -595,7 +595,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if (SWARM == 1 || (SWARM == 2 && L.swarm_global)) {  // (two copies: see k_align)
     if constexpr (SWARM != 0) {
       const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P, ARB, true);
-      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, true>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                                            tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
                                            out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
     }
@@ -837,7 +837,7 @@ int make_scan(ndtpso_ctx* c, const ndtpso_scan_geom* s, ScanP* p, const double2*
   return beam_directions(c, s, dirs);
 }
 
-PsoP make_pso(const ndtpso_pso_config* c, int waves, int mode) {
+PsoP make_pso(const ndtpso_pso_config* c, int waves, int mode, bool swarm_global = false) {
   PsoP p;
   p.P = c->population;
   p.I = c->iterations;
@@ -845,8 +845,9 @@ PsoP make_pso(const ndtpso_pso_config* c, int waves, int mode) {
   // re-evaluations, which at 2048 particles is nothing (0.1 % with rounds of 61), while every round costs its barrier
   // and the ramp-down of its last waves -- config 5: 167.7 ms per 256 pairs with two items per wave, 162.6 with four
   // (158.1 -> 152.2 in the fp32 mode); at 70 particles four items lose 1.5 % (config 3) to 8 % (30 x 50).
-  int k = c->population >= 512 ? 4 : 2;
+  int k = (swarm_global && c->population >= 512) ? 4 : 2;  // (only the HBM-swarm copies of the PSO deal more than two: KGEN)
   if (const char* e = std::getenv("NDTPSO_GROUP")) k = std::max(1, std::atoi(e));  // tuning knob
+  if (!swarm_global && k > 2) k = 2;
   p.G = std::min(std::max(waves * k, 1), std::max(c->population, 1));
   // light wave (PsoP::light): rounds of k x (waves - 1) + 1, wave 0 takes one item and does the commits and the generator
   static const bool light = [] {
@@ -1593,7 +1594,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   cluster_shape(cfg->population, true, allow_cluster, &K, &cw);
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
-  PsoP ps = make_pso(cfg, waves, mode);
+  PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
   ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
@@ -1780,7 +1781,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (K > 1) K = std::min<int>(K, c->n_cus / (int)std::min<uint32_t>(n_pairs, (uint32_t)c->n_cus));
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   if (K > 1) waves = cw;
-  PsoP ps = make_pso(cfg, waves, mode);
+  PsoP ps = make_pso(cfg, waves, mode, plan.L.swarm_global != 0);
   ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);

@@ -2025,19 +2025,32 @@ __device__ __forceinline__ void exact_tasks_wg(ExactArgs* ap, const unsigned sho
 
 // One wave per item.  `improver` (optional): the evaluating wave itself records the lowest item index whose
 // cost beats `gbc` (core.cpp:97 under single-thread order), so no separate detection pass is needed.
-template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false>
+// KGEN: the light-wave deal for any number k of items per wave (PsoP::light = k); without it k is two.  Only the copies of
+// the PSO that keep their swarm in HBM carry it (large swarms: make_pso) -- in the 70-particle kernels the general
+// deal's few extra instructions cost 2.4 % (exact) / 1 % (fp32) on config 3, same box.
+template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false, bool KGEN = false>
 __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first,
                                   int last /*exclusive*/, double gbc, int* improver, int* tiny, int* near_cnt,
                                   unsigned short* near_list) {
   const int n_waves = blockDim.x >> 6;
-  // Light-wave deal (E.light = k >= 2 items per other wave): a round of k (n - 1) + 1 items; wave w >= 1 takes items
-  // w - 1, w - 1 + (n - 1), ... below k (n - 1), wave 0 the one item behind them.  `light` off, or a longer round (the
-  // swarm's initialisation): plain striding.
-  const int heavy_items = E.light * (n_waves - 1);
-  const bool light = E.light && last - first <= heavy_items + 1;
-  const int j0 = light ? (wave_id() == 0 ? first + heavy_items : first + wave_id() - 1) : first + wave_id();
-  const int dj = light ? (n_waves - 1) : n_waves;
-  const int jend = (light && wave_id() != 0) ? min(last, first + heavy_items) : (light ? min(last, j0 + 1) : last);
+  int j0, dj, jend;
+  if constexpr (KGEN) {
+    // E.light = k >= 2 items per other wave: a round of k (n - 1) + 1 items; wave w >= 1 takes items w - 1, w - 1 + (n - 1),
+    // ... below k (n - 1), wave 0 the one item behind them.  `light` off, or a longer round (the swarm's
+    // initialisation): plain striding.
+    const int heavy_items = E.light * (n_waves - 1);
+    const bool light = E.light && last - first <= heavy_items + 1;
+    j0 = light ? (wave_id() == 0 ? first + heavy_items : first + wave_id() - 1) : first + wave_id();
+    dj = light ? (n_waves - 1) : n_waves;
+    jend = (light && wave_id() != 0) ? min(last, first + heavy_items) : (light ? min(last, j0 + 1) : last);
+  } else {
+    // item k of the round goes to wave k + 1 for k < n - 1, to wave k - (n - 1) after that: wave 0 gets one item (k = n - 1)
+    // of a round of 2n - 1, the others two.  `light` off, or a longer round (the swarm's initialisation): plain striding.
+    const bool light = E.light && last - first <= 2 * n_waves - 1;
+    j0 = light ? (wave_id() == 0 ? first + n_waves - 1 : first + wave_id() - 1) : first + wave_id();
+    dj = light ? (wave_id() == 0 ? 2 * n_waves : n_waves) : n_waves;
+    jend = last;
+  }
   for (int j = j0; j < jend; j += dj) {
     const double c = sw.tc[j], s = sw.ts[j];
     const double pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
@@ -2166,14 +2179,14 @@ constexpr unsigned long long kClusterWaitTicks = 2000000ull;  // 20 ms of the 10
 
 // Evaluates items [first, last) of the swarm; on return (after the caller's barrier) sw.tcost holds their costs and
 // *improver / *tiny are set as eval_items sets them.  `epoch` counts the cluster's exchanges.
-template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, bool KGEN = false>
 __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first, int last,
                                   double gbc, int* improver, int* tiny, const ClusterP& cl, unsigned& epoch,
                                   int* timed_out, int* near_cnt, unsigned short* near_list,
                                   RngState* gen_st = nullptr, int* gen_t = nullptr, int32_t* gen_dst = nullptr,
                                   int gen_cnt = 0, int gen_wave = -1) {
   if constexpr (!CLUSTER) {
-    eval_items<MODE, PATH, ARB, NOCLIP>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
+    eval_items<MODE, PATH, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
   } else {
     NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
@@ -2231,7 +2244,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
 // ARB: the exact mode (NDTPSO_SCORE_EXACT) of the fp32-score dense kernels.  A template parameter, not a run-time
 // switch: the arbitration code in the same kernel cost the plain fp32 mode 11 % (register pressure: spills in the
 // proposal / commit paths), see DESIGN.md.
-template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false>
+template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false, bool KGEN = false>
 __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
@@ -2312,7 +2325,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     }
   }
   __syncthreads();
-  eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
+  eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
                                   nullptr);
   n_evals += S;
   n_rounds += 1;
@@ -2521,7 +2534,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       const int hi_g = min(lo + ps.G, P);
       // a cluster draws the next iteration's numbers behind the first exchange of this one (eval_round)
       const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
-      eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
+      eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
                                       &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
                                       dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
       if (gen_here) next_filled = n_draw;
