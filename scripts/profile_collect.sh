@@ -21,11 +21,11 @@ cp $SRC/phase_budget_config5.json ${P}_phase_budget_config5.json
 python - <<PY
 import json
 out = {}
-for w in ("config3", "random", "converged", "config5"):
+for w in ("config3", "config4", "random", "converged", "config5"):
     try:
         d = json.load(open("$SRC/verify_%s.json" % w))
         out[w] = {k: v for k, v in d.items() if k != "runs"}
-        out[w]["runs"] = [{k: r[k] for k in ("pairs", "beams", "cs", "P", "I", "evaluations_checked", "max_err", "max_err_over_bound", "max_bound_over_half_tau", "max_err_over_half_tau", "points_binned_differently", "arbitrated_mean")} for r in d["runs"]]
+        out[w]["runs"] = [{k: r[k] for k in ("pairs", "beams", "cs", "P", "I", "evaluations_checked", "points_checked", "max_err", "max_err_over_bound", "max_bound_over_half_tau", "max_err_over_half_tau", "points_binned_differently", "arbitrated_mean")} for r in d["runs"]]
     except Exception as e:
         out[w] = {"error": str(e)}
 json.dump(out, open("${P}_margin_verification.json", "w"), indent=1)

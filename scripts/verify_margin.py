@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="config3", choices=["config3", "config5", "random", "converged"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config5", "random", "converged"])
     ap.add_argument("--pairs", type=int, default=0)
     ap.add_argument("--seed", type=int, default=2024)
     args = ap.parse_args()
@@ -37,6 +37,9 @@ def main():
     runs = []
     if args.workload == "config3":
         runs.append(dict(pairs=args.pairs or 512, beams=1081, cs=0.5, P=70, I=70, dev=(0.1, 0.1, 3.1415e-3), seed=2024))
+    elif args.workload == "config4":   # the 4096 pairs of BASELINE config 4, as one device would see them shard by shard
+        for k in range(8):
+            runs.append(dict(pairs=512, beams=1081, cs=0.5, P=70, I=70, dev=(0.1, 0.1, 3.1415e-3), seed=2024, first=512 * k, total=4096))
     elif args.workload == "config5":
         runs.append(dict(pairs=args.pairs or 2, beams=2048, cs=0.25, P=2048, I=200, dev=(0.1, 0.1, 3.1415e-3), seed=21))
     elif args.workload == "converged":   # tight deviations: the swarm converges, near-ties everywhere
@@ -50,7 +53,7 @@ def main():
     out = {"workload": args.workload, "kArbRel": 5e-6, "runs": []}
     worst = np.zeros(16)
     for r in runs:
-        p = synth.make_pairs(r["pairs"], n_beams=r["beams"], seed=r["seed"])
+        p = synth.make_pairs(r["pairs"], n_beams=r["beams"], seed=r["seed"], first_pair=r.get("first", 0), total_pairs=r.get("total"))
         geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
         B = r["pairs"]
         assert L.ndtpso_profile_verify_margin(None, 0, 1) == 0
