@@ -55,7 +55,8 @@ int main(int argc, char** argv) {
   unsigned iter_num = 0;
   const unsigned kSaveEachNumIters = std::getenv("NODE_REPLAY_SAVE_EACH") ? (unsigned)std::max(1, std::atoi(std::getenv("NODE_REPLAY_SAVE_EACH"))) : 10u;
   std::vector<float> ranges((size_t)n_beams);
-  double busy_s = 0.;
+  double busy_s = 0., part_s[4] = {0., 0., 0., 0.};  // loadLaser, align, update, between scans (NODE_REPLAY_TIMING)
+  auto t_prev_end = std::chrono::steady_clock::now();
   const double pace_hz = std::getenv("NODE_REPLAY_PACE_HZ") ? std::atof(std::getenv("NODE_REPLAY_PACE_HZ")) : 0.;
   auto next_scan = std::chrono::steady_clock::now();
   for (int k = 0; k < n_scans; ++k) {
@@ -66,13 +67,23 @@ int main(int argc, char** argv) {
     }
     const auto t0 = std::chrono::steady_clock::now();
     current_frame->loadLaser(ranges, amin, ainc, rmax);                       // :186
+    const auto t1 = std::chrono::steady_clock::now();
     if (first_iteration)
       current_pose = previous_pose;                                            // :188-189
     else
       current_pose = ref_frame->align(previous_pose, current_frame);           // :194
     previous_pose = current_pose;
+    const auto t2 = std::chrono::steady_clock::now();
     ref_frame->update(current_pose, current_frame);                            // :198
-    if (k > 0) busy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const auto t3 = std::chrono::steady_clock::now();
+    if (k > 0) {
+      busy_s += std::chrono::duration<double>(t3 - t0).count();
+      part_s[0] += std::chrono::duration<double>(t1 - t0).count();
+      part_s[1] += std::chrono::duration<double>(t2 - t1).count();
+      part_s[2] += std::chrono::duration<double>(t3 - t2).count();
+      if (k > 1) part_s[3] += std::chrono::duration<double>(t0 - t_prev_end).count();
+    }
+    t_prev_end = t3;
     if (global_map) {                                                          // :200-206
       // the node merges every SAVE_DATA_TO_FILE_EACH_NUM_ITERS-th scan (10, ndtpso_slam_node.hpp:18) into the global
       // map, starting with the first, and records every pose
@@ -86,6 +97,9 @@ int main(int argc, char** argv) {
     first_iteration = false;
   }
   std::fclose(f);
+  if (n_scans > 1 && std::getenv("NODE_REPLAY_TIMING"))
+    std::fprintf(stderr, "per scan (us): loadLaser %.1f  align %.1f  update %.1f  between scans %.1f\n", 1e6 * part_s[0] / (n_scans - 1),
+                 1e6 * part_s[1] / (n_scans - 1), 1e6 * part_s[2] / (n_scans - 1), 1e6 * part_s[3] / (n_scans - 1));
   if (n_scans > 1)  // the node's own metric ("matching rate", ndtpso_slam_node.cpp:239): loadLaser + align + update per scan
     std::fprintf(stderr, "matching rate: %.1f Hz (%.3f ms per scan)\n", (n_scans - 1) / busy_s, 1e3 * busy_s / (n_scans - 1));
   if (dump_prefix) {  // :141-172

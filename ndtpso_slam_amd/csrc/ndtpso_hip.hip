@@ -3,6 +3,7 @@
 #include "ndtpso_kernels.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -431,9 +432,21 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
         const uint32_t* __restrict__ n_ptr, GridP g, WinP wn, Layout L, DenseP dn, PsoP ps,
         const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
         const int32_t* __restrict__ table, unsigned char* __restrict__ ws, double* __restrict__ out_pose,
-        double* __restrict__ out_cost, AlignStats* __restrict__ stats, ClusterP cl) {
+        double* __restrict__ out_cost, AlignStats* __restrict__ stats, ClusterP cl, double* __restrict__ mirror,
+        const int4* __restrict__ table_src, int4* __restrict__ table_dst, int table_vec) {
   cl.rank = (int)blockIdx.x;
   if (CLUSTER && cl.rank == cl.absent) return;
+  // The rand() table in a pinned HOST slot (table_src; ndtpso_map_align): fetched in one sweep into this workgroup's
+  // own copy in HBM, the loads in flight together -- one trip over the host link instead of a copy operation ahead of
+  // the kernel.  (Read in place, an iteration's draws one iteration ahead, the trips were not hidden: the memory counter
+  // retires in order, so every later load waited for them; 66 us per alignment.)  The first reader comes after the
+  // barrier below.
+  const int32_t* draws_table = table;
+  if (table_src) {
+    int4* dst = table_dst + (size_t)cl.rank * (size_t)table_vec;
+    for (int q = (int)threadIdx.x; q < table_vec; q += (int)blockDim.x) dst[q] = table_src[q];
+    draws_table = reinterpret_cast<const int32_t*>(dst);
+  }
   if (threadIdx.x == 0 && cl.rank == 0 && stats) *stats = AlignStats{0, 0, 0, 0, 0, 0, 0, 0};  // only this workgroup writes it
   if (n_ptr) n = min((int)*n_ptr, n);  // the point count lives on the device (resident scan); n is its capacity
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
@@ -450,17 +463,27 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   // the proposal / commit phases -- one or two waves working, the rest waiting -- are chains of exactly those accesses.
   if (L.swarm_global) {
     const Swarm sw = swarm_carve(ws + (size_t)cl.rank * swarm_bytes(ps.P, true, true), ps.P, ARB, true);
-    pso_run_wg<MODE, PATH, CLUSTER, ARB, false, true>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
+    pso_run_wg<MODE, PATH, CLUSTER, ARB, false, true>(E, pts, n, ps, guess, dev, seed, draws_table, sw, lds_ctrl(L.ctrl_off), out_pose,
                                          out_cost, stats, cl);
   } else {
     const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
-    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, table, sw, lds_ctrl(L.ctrl_off), out_pose,
+    pso_run_wg<MODE, PATH, CLUSTER, ARB>(E, pts, n, ps, guess, dev, seed, draws_table, sw, lds_ctrl(L.ctrl_off), out_pose,
                                          out_cost, stats, cl);
   }
   if (threadIdx.x == 0 && stats && cl.rank == 0) {
     const ImageHeader* h = reinterpret_cast<const ImageHeader*>(g_lds + L.hdr_off);
     stats->n_built = h->n_built;
     stats->status = (stats->status & (kStatusNeedsF64 | kStatusClusterTimeout | 0xffff0000u)) | h->status;
+    // the host's copy of {pose, cost, statistics}: written into its pinned slot from here (this thread wrote all of it),
+    // so that no copy operation stands between the end of the kernel and the host's wake-up
+    if (mirror) {
+      static_assert(sizeof(AlignStats) == 32, "result slot layout");
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mirror[k] = out_pose[k];  // [3] is the cost's place (out_cost, when wanted)
+      const double* sd = reinterpret_cast<const double*>(stats);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mirror[4 + k] = sd[k];
+    }
   }
 }
 
@@ -658,10 +681,11 @@ struct PinnedRing {
   hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     return upload2(dst, src, bytes, 0, nullptr, 0, stream);
   }
-  // two host buffers, one transfer: [a | padding up to b_offset | b]
-  hipError_t upload2(void* dst, const void* a, size_t a_bytes, size_t b_offset, const void* b, size_t b_bytes,
-                     hipStream_t stream) {
-    const size_t bytes = b_bytes ? b_offset + b_bytes : a_bytes;
+  // A pinned slot of `bytes` for the caller to fill: the device reads it where it lies (kernels take the slot's address
+  // -- hipHostMalloc memory is mapped into the device's address space -- so a small per-scan input costs no copy
+  // operation between two kernels of the stream, each of which was 4-6 us plus the wait for the copy engine's signal).
+  // fence() after the last operation that reads the slot has been enqueued.
+  hipError_t stage(size_t bytes, void** out, int* slot) {
     const int k = next;
     next = (next + 1) % kSlots;
     hipError_t e = hipSuccess;
@@ -678,16 +702,31 @@ struct PinnedRing {
       if (host[k]) (void)hipHostFree(host[k]);
       host[k] = nullptr;
       cap[k] = 0;
-      e = hipHostMalloc(&host[k], bytes, hipHostMallocDefault);
+      e = hipHostMalloc(&host[k], bytes, hipHostMallocMapped | hipHostMallocCoherent);
       if (e != hipSuccess) return e;
       cap[k] = bytes;
     }
-    std::memcpy(host[k], a, a_bytes);
-    if (b_bytes) std::memcpy((unsigned char*)host[k] + b_offset, b, b_bytes);
-    e = hipMemcpyAsync(dst, host[k], bytes, hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return e;
+    *out = host[k];
+    *slot = k;
+    return hipSuccess;
+  }
+  hipError_t fence(int k, hipStream_t stream) {
     busy[k] = true;
     return hipEventRecord(ev[k], stream);
+  }
+  // two host buffers, one transfer: [a | padding up to b_offset | b]
+  hipError_t upload2(void* dst, const void* a, size_t a_bytes, size_t b_offset, const void* b, size_t b_bytes,
+                     hipStream_t stream) {
+    const size_t bytes = b_bytes ? b_offset + b_bytes : a_bytes;
+    void* h = nullptr;
+    int k = 0;
+    hipError_t e = stage(bytes, &h, &k);
+    if (e != hipSuccess) return e;
+    std::memcpy(h, a, a_bytes);
+    if (b_bytes) std::memcpy((unsigned char*)h + b_offset, b, b_bytes);
+    e = hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return e;
+    return fence(k, stream);
   }
   void release() {
     for (int k = 0; k < kSlots; ++k) {
@@ -742,6 +781,15 @@ struct ndtpso_ctx {
   int pipe_depth = 1;
   unsigned long long pipe_calls = 0;  // pipelined calls issued so far
   hipEvent_t pipe_in = nullptr;       // "inputs of the call are ready on the context's stream"
+  // NDTPSO_HOST_CLOCK=1 (diagnostics): where the host's time goes around single alignments -- mean time between an
+  // alignment's wake-up and the next one's launch (the host's serial path), and from launch to wake-up; printed by
+  // ndtpso_ctx_destroy
+  double clk_host = 0., clk_wait = 0., clk_pre = 0.;
+  unsigned long long clk_n = 0;
+  std::chrono::steady_clock::time_point clk_wake{}, clk_enter{};
+  bool inputs_pinned = false;         // `inputs` is a pinned host slot (the kernel fetches the table from there itself)
+  const void* inputs = nullptr;       // [guess | deviation | pad to kGuessBytes | rand() table] of the alignment about to be launched:
+                                      // `table` (uploaded) or a pinned slot the kernel reads in place (ndtpso_map_align)
   void* result_pinned = nullptr;      // pinned landing slot of one alignment's pose / cost / statistics (align_once)
   hipEvent_t result_event = nullptr;
 };
@@ -1060,6 +1108,9 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
 }
 
 void ndtpso_ctx_destroy(ndtpso_ctx* c) {
+  if (c && c->clk_n)
+    std::fprintf(stderr, "ndtpso: host clock over %llu alignments (us): wake-up to next launch %.1f (of which inside the align call %.1f), launch to wake-up %.1f\n",
+                 c->clk_n, 1e6 * c->clk_host / c->clk_n, 1e6 * c->clk_pre / c->clk_n, 1e6 * c->clk_wait / c->clk_n);
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
@@ -1586,12 +1637,19 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   const Layout& L = plan.L;
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
+  if (!c->result_pinned) {
+    HIP_TRY(c, hipHostMalloc(&c->result_pinned, 256, hipHostMallocMapped | hipHostMallocCoherent));
+    HIP_TRY(c, hipEventCreateWithFlags(&c->result_event, hipEventDisableTiming));
+  }
   int K, cw;
   if (allow_cluster && c->cluster_penalty > 0) {
     --c->cluster_penalty;
     allow_cluster = false;
   }
   cluster_shape(cfg->population, true, allow_cluster, &K, &cw);
+  const bool staged_table = have_table && c->inputs_pinned;
+  const int table_vec = (int)((ndtpso_rand_draws(cfg) * 4 + 15) / 16);
+  if (staged_table) HIP_TRY(c, c->table.reserve(kGuessBytes + (size_t)K * (size_t)table_vec * 16));  // one copy per workgroup of the cluster
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
@@ -1606,9 +1664,12 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
 #define LAUNCH_ALIGN_CA(MODE, PATH, CL, ARB)                                                                       \
   hipLaunchKernelGGL((k_align<MODE, PATH, CL, ARB>), dim3(K), dim3(waves * 64), L.total, c->stream,                \
                      src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
-                     ps, (const double*)c->table.p, (const double*)c->table.p + 3, seed,                           \
-                     have_table ? (const int32_t*)((const unsigned char*)c->table.p + kGuessBytes) : nullptr,      \
-                     (unsigned char*)c->ws.p, d_out, src.want_cost ? d_out + 3 : nullptr, d_stats, cl)
+                     ps, (const double*)c->inputs, (const double*)c->inputs + 3, seed,                             \
+                     have_table && !staged_table ? (const int32_t*)((const unsigned char*)c->inputs + kGuessBytes) : nullptr, \
+                     (unsigned char*)c->ws.p, d_out, src.want_cost ? d_out + 3 : nullptr, d_stats, cl,             \
+                     (double*)c->result_pinned,                                                                    \
+                     staged_table ? (const int4*)((const unsigned char*)c->inputs + kGuessBytes) : nullptr,        \
+                     (int4*)((unsigned char*)c->table.p + kGuessBytes), table_vec)
 #define LAUNCH_ALIGN_C(MODE, PATH, CL) LAUNCH_ALIGN_CA(MODE, PATH, CL, false)
 #define LAUNCH_ALIGN(MODE, PATH) \
   do { if (K > 1) LAUNCH_ALIGN_C(MODE, PATH, true); else LAUNCH_ALIGN_C(MODE, PATH, false); } while (0)
@@ -1639,15 +1700,23 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   // wake-up.  (With a pageable destination the copy call itself blocked until the kernel was done, `after` was
   // enqueued late and then waited for: 30 us per scan on the live path.)
   constexpr size_t kResultBytes = (4 + sizeof(AlignStats) / 8) * sizeof(double);
-  if (!c->result_pinned) {
-    HIP_TRY(c, hipHostMalloc(&c->result_pinned, 256, hipHostMallocDefault));
-    HIP_TRY(c, hipEventCreateWithFlags(&c->result_event, hipEventDisableTiming));
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->result_pinned, c->out.p, kResultBytes, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipEventRecord(c->result_event, c->stream));
+  HIP_TRY(c, hipEventRecord(c->result_event, c->stream));  // (the kernel itself has written the pinned slot)
   if (after.fn)
     if (int rc = after.fn(after.arg)) return rc;
+  static const bool host_clock = std::getenv("NDTPSO_HOST_CLOCK") != nullptr;
+  std::chrono::steady_clock::time_point t_launch;
+  if (host_clock) t_launch = std::chrono::steady_clock::now();
   HIP_TRY(c, hipEventSynchronize(c->result_event));
+  if (host_clock) {
+    const auto now = std::chrono::steady_clock::now();
+    if (c->clk_wake.time_since_epoch().count()) {
+      c->clk_host += std::chrono::duration<double>(t_launch - c->clk_wake).count();
+      c->clk_pre += std::chrono::duration<double>(t_launch - c->clk_enter).count();
+      c->clk_wait += std::chrono::duration<double>(now - t_launch).count();
+      ++c->clk_n;
+    }
+    c->clk_wake = now;
+  }
   std::memcpy(host, c->result_pinned, kResultBytes);
   if (K > 1) {
     AlignStats st;
@@ -1681,6 +1750,8 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   if (n) HIP_TRY(c, hipMemcpyAsync(c->xy2.p, xy, (size_t)n * 16, hipMemcpyHostToDevice, c->stream));
   double gd[6] = {guess[0], guess[1], guess[2], deviation[0], deviation[1], deviation[2]};
   HIP_TRY(c, c->pinned.upload2(c->table.p, gd, sizeof(gd), kGuessBytes, rand_table, rand_table ? n_draw * 4 : 0, c->stream));
+  c->inputs = c->table.p;
+  c->inputs_pinned = false;
   const AlignSrc src{(const unsigned char*)c->image.p, c->g, c->wn, (const double2*)c->xy2.p, n, nullptr, out_cost != nullptr};
   return align_finish(c, src, cfg, seed, rand_table != nullptr, mode, out_pose, out_cost, stats);
 }
