@@ -425,6 +425,13 @@ k_cost_batch(const unsigned char* __restrict__ image, const double2* __restrict_
 }
 
 // ---- K2 --------------------------------------------------------------------------------------
+// the last store of a result a kernel leaves in pinned host memory: everything this thread wrote before it is visible to
+// the host that reads the word
+__device__ __forceinline__ void publish_pinned_word(uint32_t* word, uint32_t value) {
+  __threadfence_system();
+  __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // CLUSTER: gridDim.x workgroups share this one alignment (see ClusterP in ndtpso_kernels.hpp)
 template <int MODE, int PATH, bool CLUSTER, bool ARB = false>
 __global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
@@ -433,7 +440,8 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
         const double* __restrict__ guess, const double* __restrict__ dev, uint32_t seed,
         const int32_t* __restrict__ table, unsigned char* __restrict__ ws, double* __restrict__ out_pose,
         double* __restrict__ out_cost, AlignStats* __restrict__ stats, ClusterP cl, double* __restrict__ mirror,
-        const int4* __restrict__ table_src, int4* __restrict__ table_dst, int table_vec) {
+        const int4* __restrict__ table_src, int4* __restrict__ table_dst, int table_vec,
+        const uint32_t* __restrict__ late_hdr, int late_table_cap, int late_rec_cap, uint32_t seq) {
   cl.rank = (int)blockIdx.x;
   if (CLUSTER && cl.rank == cl.absent) return;
   // The rand() table in a pinned HOST slot (table_src; ndtpso_map_align): fetched in one sweep into this workgroup's
@@ -448,6 +456,32 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
     draws_table = reinterpret_cast<const int32_t*>(dst);
   }
   if (threadIdx.x == 0 && cl.rank == 0 && stats) *stats = AlignStats{0, 0, 0, 0, 0, 0, 0, 0};  // only this workgroup writes it
+  if constexpr (PATH == 2) {
+    if (late_hdr) {  // late window binding (AlignSrc::late_hdr): uniform, and the same in every workgroup of a cluster
+      const int nb = (int)late_hdr[1], x0 = (int)late_hdr[4], x1 = (int)late_hdr[5], y0 = (int)late_hdr[6], y1 = (int)late_hdr[7];
+      wn.x0 = x0;
+      wn.y0 = y0;
+      wn.w = x1 - x0 + 1;
+      wn.h = y1 - y0 + 1;
+      wn.n_words = (int)late_hdr[3];
+      wn.rec_cap = max(nb, 1);
+      dn.dw = wn.w + 1;
+      dn.dh = wn.h + 1;
+      dn.ox = x0 - 1;
+      dn.oy = y0 - 1;
+      dense_set_limits(dn, g.hw, g.hh, g.inv_cs);
+      if (dense_entries(dn.dw, dn.dh) > late_table_cap || wn.rec_cap > late_rec_cap) {
+        if (threadIdx.x == 0 && cl.rank == 0 && stats) {
+          stats->status = kStatusLateOverflow;
+          if (mirror) {
+            reinterpret_cast<AlignStats*>(mirror + 4)->status = kStatusLateOverflow;
+            publish_pinned_word(reinterpret_cast<uint32_t*>(mirror + 8), seq);
+          }
+        }
+        return;
+      }
+    }
+  }
   if (n_ptr) n = min((int)*n_ptr, n);  // the point count lives on the device (resident scan); n is its capacity
   double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
   stage_image<MODE, PATH>(image, g, wn, L, dn);
@@ -483,6 +517,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
       const double* sd = reinterpret_cast<const double*>(stats);
 #pragma unroll
       for (int k = 0; k < 4; ++k) mirror[4 + k] = sd[k];
+      publish_pinned_word(reinterpret_cast<uint32_t*>(mirror + 8), seq);  // the host polls this word (wait_pinned_word)
     }
   }
 }
@@ -677,6 +712,11 @@ struct PinnedRing {
   size_t cap[kSlots] = {0, 0, 0, 0};
   hipEvent_t ev[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   bool busy[kSlots] = {false, false, false, false};
+  // fence_until(): the slot's reader is a kernel of `rs`, and it precedes single alignment number `need` of the context on
+  // that stream -- once the host has seen that alignment's result the slot is free, with no event of its own (an event
+  // recorded between two kernels of the live sequence cost the device 6 us each time)
+  unsigned long long need[kSlots] = {0, 0, 0, 0};
+  hipStream_t rs[kSlots] = {nullptr, nullptr, nullptr, nullptr};
   int next = 0;
   hipError_t upload(void* dst, const void* src, size_t bytes, hipStream_t stream) {
     return upload2(dst, src, bytes, 0, nullptr, 0, stream);
@@ -685,10 +725,17 @@ struct PinnedRing {
   // -- hipHostMalloc memory is mapped into the device's address space -- so a small per-scan input costs no copy
   // operation between two kernels of the stream, each of which was 4-6 us plus the wait for the copy engine's signal).
   // fence() after the last operation that reads the slot has been enqueued.
-  hipError_t stage(size_t bytes, void** out, int* slot) {
+  hipError_t stage(size_t bytes, void** out, int* slot, unsigned long long done_seq = 0) {
     const int k = next;
     next = (next + 1) % kSlots;
     hipError_t e = hipSuccess;
+    if (need[k]) {
+      if (done_seq < need[k]) {  // no alignment has followed the reader (or none has reported yet): wait for the stream
+        e = hipStreamSynchronize(rs[k]);
+        if (e != hipSuccess) return e;
+      }
+      need[k] = 0;
+    }
     if (busy[k]) {
       e = hipEventSynchronize(ev[k]);
       if (e != hipSuccess) return e;
@@ -714,6 +761,19 @@ struct PinnedRing {
     busy[k] = true;
     return hipEventRecord(ev[k], stream);
   }
+  void fence_until(int k, hipStream_t stream, unsigned long long seq) {
+    need[k] = seq;
+    rs[k] = stream;
+  }
+  hipError_t settle() {  // the context is about to change streams: the tickets would no longer mean anything
+    for (int k = 0; k < kSlots; ++k) {
+      if (!need[k]) continue;
+      const hipError_t e = hipStreamSynchronize(rs[k]);
+      if (e != hipSuccess) return e;
+      need[k] = 0;
+    }
+    return hipSuccess;
+  }
   // two host buffers, one transfer: [a | padding up to b_offset | b]
   hipError_t upload2(void* dst, const void* a, size_t a_bytes, size_t b_offset, const void* b, size_t b_bytes,
                      hipStream_t stream) {
@@ -736,6 +796,7 @@ struct PinnedRing {
       host[k] = nullptr;
       cap[k] = 0;
       busy[k] = false;
+      need[k] = 0;
     }
   }
 };
@@ -787,6 +848,8 @@ struct ndtpso_ctx {
   double clk_host = 0., clk_wait = 0., clk_pre = 0.;
   unsigned long long clk_n = 0;
   std::chrono::steady_clock::time_point clk_wake{}, clk_enter{};
+  // single alignments (align_once) are numbered; the kernel writes its number behind its result in the pinned slot
+  unsigned long long align_issued = 0, align_seen = 0;
   bool inputs_pinned = false;         // `inputs` is a pinned host slot (the kernel fetches the table from there itself)
   const void* inputs = nullptr;       // [guess | deviation | pad to kGuessBytes | rand() table] of the alignment about to be launched:
                                       // `table` (uploaded) or a pinned slot the kernel reads in place (ndtpso_map_align)
@@ -1138,7 +1201,9 @@ const char* ndtpso_last_error(const ndtpso_ctx* c) { return c ? c->err.c_str() :
 
 int ndtpso_set_stream(ndtpso_ctx* c, void* s) {
   if (!c) return NDTPSO_E_ARG;
-  c->stream = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  hipStream_t ns = s ? reinterpret_cast<hipStream_t>(s) : c->own_stream;
+  if (ns != c->stream) HIP_TRY(c, c->pinned.settle());
+  c->stream = ns;
   return NDTPSO_OK;
 }
 
@@ -1570,6 +1635,11 @@ struct AlignSrc {
   const uint32_t* n_ptr;
   bool want_cost = true;  // false: the caller asked for the pose only (NDTFrame::align does) -- the exact mode then skips
                           // the fp64 score of the returned pose, which nothing else needs
+  // Late window binding (resident map, dense form): `wn` is an UPPER BOUND the host planned the LDS layout with, and the
+  // kernel takes the table's real window and record count from the map's header on the device -- {n_created, n_built,
+  // status, n_words, x0, x1, y0, y1} -- which the pack kernel ahead of it on the stream has written.  The host then need
+  // not wait for that header before it launches the alignment.
+  const uint32_t* late_hdr = nullptr;
 };
 
 // How many workgroups share one alignment (cluster mode, see ClusterP).  One item per wave and round: enough waves
@@ -1616,6 +1686,24 @@ static int cluster_test_absent() {
 // scripts/small_batch_check.py); forced shapes (NDTPSO_CLUSTER) are taken as given
 static bool cluster_worthwhile(int K, int cw) { return std::getenv("NDTPSO_CLUSTER") != nullptr || K * cw >= 32; }
 
+// The host's side of publish_pinned_word: spin on a word of pinned memory until the kernel has written `want` there.  No
+// event stands behind the kernel for this (the device would spend microseconds on it between two kernels, and the host
+// would hear of the result later); every ~1000 polls the stream is asked whether it is still busy, so that a kernel that
+// died, or ended without reporting, ends the wait with an error.
+static int wait_pinned_word(ndtpso_ctx* c, const uint32_t* word, uint32_t want) {
+  for (unsigned spins = 1;; ++spins) {
+    if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return NDTPSO_OK;
+    __builtin_ia32_pause();
+    if ((spins & 1023u) == 0) {
+      const hipError_t e = hipStreamQuery(c->stream);
+      if (e == hipErrorNotReady) continue;
+      if (e != hipSuccess) return fail(c, NDTPSO_E_HIP, std::string("while waiting for a kernel's result: ") + hipGetErrorString(e));
+      if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return NDTPSO_OK;
+      return fail(c, NDTPSO_E_HIP, "kernel ended without reporting its result");
+    }
+  }
+}
+
 static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
                       int mode, double host[4 + sizeof(AlignStats) / 8], bool allow_cluster = true,
                       AfterLaunch after = AfterLaunch{nullptr, nullptr}) {
@@ -1634,11 +1722,13 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   }
   if (!make_plan(mode, src.g, src.wn, std::max<int>((int)n, 1), cfg->population, &plan, false, true, true, exact != 0))
     return fail(c, NDTPSO_E_CAPACITY, "points + swarm do not fit in LDS");
+  if (src.late_hdr && plan.path != 2) return fail(c, NDTPSO_E_STATE, "late window binding needs the dense form");  // (the caller probes)
   const Layout& L = plan.L;
   double* d_out = (double*)c->out.p;  // [0..2] pose, [3] cost, then stats
   AlignStats* d_stats = reinterpret_cast<AlignStats*>(d_out + 4);
   if (!c->result_pinned) {
     HIP_TRY(c, hipHostMalloc(&c->result_pinned, 256, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->result_pinned, 0, 256);
     HIP_TRY(c, hipEventCreateWithFlags(&c->result_event, hipEventDisableTiming));
   }
   int K, cw;
@@ -1647,6 +1737,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     allow_cluster = false;
   }
   cluster_shape(cfg->population, true, allow_cluster, &K, &cw);
+  const unsigned long long seq = ++c->align_issued;
   const bool staged_table = have_table && c->inputs_pinned;
   const int table_vec = (int)((ndtpso_rand_draws(cfg) * 4 + 15) / 16);
   if (staged_table) HIP_TRY(c, c->table.reserve(kGuessBytes + (size_t)K * (size_t)table_vec * 16));  // one copy per workgroup of the cluster
@@ -1669,7 +1760,9 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
                      (unsigned char*)c->ws.p, d_out, src.want_cost ? d_out + 3 : nullptr, d_stats, cl,             \
                      (double*)c->result_pinned,                                                                    \
                      staged_table ? (const int4*)((const unsigned char*)c->inputs + kGuessBytes) : nullptr,        \
-                     (int4*)((unsigned char*)c->table.p + kGuessBytes), table_vec)
+                     (int4*)((unsigned char*)c->table.p + kGuessBytes), table_vec,                                 \
+                     (plan.path == 2 ? src.late_hdr : nullptr), dense_entries(plan.dn.dw, plan.dn.dh), src.wn.rec_cap,  \
+                     (uint32_t)seq)
 #define LAUNCH_ALIGN_C(MODE, PATH, CL) LAUNCH_ALIGN_CA(MODE, PATH, CL, false)
 #define LAUNCH_ALIGN(MODE, PATH) \
   do { if (K > 1) LAUNCH_ALIGN_C(MODE, PATH, true); else LAUNCH_ALIGN_C(MODE, PATH, false); } while (0)
@@ -1700,13 +1793,13 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   // wake-up.  (With a pageable destination the copy call itself blocked until the kernel was done, `after` was
   // enqueued late and then waited for: 30 us per scan on the live path.)
   constexpr size_t kResultBytes = (4 + sizeof(AlignStats) / 8) * sizeof(double);
-  HIP_TRY(c, hipEventRecord(c->result_event, c->stream));  // (the kernel itself has written the pinned slot)
   if (after.fn)
     if (int rc = after.fn(after.arg)) return rc;
   static const bool host_clock = std::getenv("NDTPSO_HOST_CLOCK") != nullptr;
   std::chrono::steady_clock::time_point t_launch;
   if (host_clock) t_launch = std::chrono::steady_clock::now();
-  HIP_TRY(c, hipEventSynchronize(c->result_event));
+  if (int rc = wait_pinned_word(c, reinterpret_cast<const uint32_t*>(static_cast<const double*>(c->result_pinned) + 8), (uint32_t)seq)) return rc;
+  c->align_seen = seq;
   if (host_clock) {
     const auto now = std::chrono::steady_clock::now();
     if (c->clk_wake.time_since_epoch().count()) {

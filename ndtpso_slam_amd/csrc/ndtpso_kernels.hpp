@@ -2175,6 +2175,7 @@ struct ClusterP {
   double* xc;           // [2][stride] exchanged costs
 };
 constexpr uint32_t kStatusClusterTimeout = 16u;
+constexpr uint32_t kStatusLateOverflow = 32u;  // late window binding: the table outgrew what the host had planned for
 constexpr unsigned long long kClusterWaitTicks = 2000000ull;  // 20 ms of the 100 MHz counter (an exchange takes 1.5 us; round 1 waited 0.2 s)
 
 // Evaluates items [first, last) of the swarm; on return (after the caller's barrier) sw.tcost holds their costs and

@@ -1,6 +1,7 @@
 """The C++ drop-in (host/libndtpso_slam.so): exports on CPU; on the GPU the ROS-free node replay
 (ndtpso_slam_node.cpp:177-244 call sequence, accumulated map with sliding-window cells) against the oracle."""
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -155,6 +156,22 @@ def test_node_replay_matches_oracle(tmp_path, oracle, resident, monkeypatch):
     out_x = subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs),
                                      str(I), str(P), str(seed)], text=True, env=env_default)
     assert out_x == out
+    if resident == "1":
+        # late window binding (ndtpso_map_align): by default the alignment is enqueued before the host has seen the
+        # table's header and binds its window on the device; waiting for the header instead, or a bound the table
+        # exceeds (every alignment flagged by the kernel and redone the usual way), print the same digits
+        exe = [os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs), str(I), str(P), str(seed)]
+        r = subprocess.run(exe, text=True, capture_output=True, check=True, env=dict(env_default, NDTPSO_LOG_LATE="1"))
+        m = re.search(r"late window binding: (\d+) alignments, (\d+) redone", r.stderr)
+        assert m and int(m.group(1)) >= n_scans - 3 and int(m.group(2)) == 0, r.stderr
+        assert r.stdout == out
+        r = subprocess.run(exe, text=True, capture_output=True, check=True, env=dict(env_default, NDTPSO_LOG_LATE="1", NDTPSO_LATE_WINDOW="0"))
+        assert "late window binding" not in r.stderr and r.stdout == out
+        r = subprocess.run(exe, text=True, capture_output=True, check=True,
+                           env=dict(env_default, NDTPSO_LOG_LATE="1", NDTPSO_LATE_TEST_OVERFLOW="1"))
+        m = re.search(r"late window binding: (\d+) alignments, (\d+) redone", r.stderr)
+        assert m and int(m.group(1)) == 0 and int(m.group(2)) >= n_scans - 3, r.stderr
+        assert r.stdout == out
     # like the reference (ndtframe.cpp:257) align() runs 30 x 50 whatever PSO configuration the frame was given
     out_cfg = subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs),
                                        "7", "11", str(seed)], text=True, env=dict(os.environ, NDTPSO_SCORE="f64"))
