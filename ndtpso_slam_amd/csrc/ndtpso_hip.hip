@@ -1686,20 +1686,26 @@ static int cluster_test_absent() {
 // scripts/small_batch_check.py); forced shapes (NDTPSO_CLUSTER) are taken as given
 static bool cluster_worthwhile(int K, int cw) { return std::getenv("NDTPSO_CLUSTER") != nullptr || K * cw >= 32; }
 
-// The host's side of publish_pinned_word: spin on a word of pinned memory until the kernel has written `want` there.  No
-// event stands behind the kernel for this (the device would spend microseconds on it between two kernels, and the host
-// would hear of the result later); every ~1000 polls the stream is asked whether it is still busy, so that a kernel that
-// died, or ended without reporting, ends the wait with an error.
+// The host's side of publish_pinned_word: spin on a word of pinned memory until the kernel has written `want` there.
+// No event stands behind the kernel for this (the device would spend microseconds on it between two
+// kernels, and the host would hear of the result later).  A kernel that died, or ended without reporting, must still end
+// the wait: every 10 ms the stream is asked whether it is still busy -- not more often, because the query itself puts a
+// marker into the queue, and a marker between two kernels of the live sequence costs the device 6 us.
 static int wait_pinned_word(ndtpso_ctx* c, const uint32_t* word, uint32_t want) {
+  std::chrono::steady_clock::time_point last{};
   for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return NDTPSO_OK;
     __builtin_ia32_pause();
-    if ((spins & 1023u) == 0) {
+    if ((spins & 4095u) == 0) {
+      const auto now = std::chrono::steady_clock::now();
+      if (last.time_since_epoch().count() == 0) last = now;
+      if (now - last < std::chrono::milliseconds(10)) continue;
+      last = now;
       const hipError_t e = hipStreamQuery(c->stream);
       if (e == hipErrorNotReady) continue;
-      if (e != hipSuccess) return fail(c, NDTPSO_E_HIP, std::string("while waiting for a kernel's result: ") + hipGetErrorString(e));
+      if (e != hipSuccess) return fail(c, NDTPSO_E_HIP, std::string("while waiting for a kernel's word: ") + hipGetErrorString(e));
       if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return NDTPSO_OK;
-      return fail(c, NDTPSO_E_HIP, "kernel ended without reporting its result");
+      return fail(c, NDTPSO_E_HIP, "kernel ended without reporting");
     }
   }
 }
