@@ -360,6 +360,7 @@ def _live_sequence(ctx, capi, synth, mode, n_scans=60):
             prev, _, _ = rmap.align(scan, prev, dev, cfg, rand_table=tables[k], mode=mode)
             hist.append(prev.copy())
         rmap.insert(scan, prev)
+        rmap.speculate_build()   # what NDTFrame::update of the drop-in does for a frame that is aligned against
     ctx.synchronize()
     dt = (time.perf_counter() - t0) / (n_scans - 1)
     info = rmap.info()

@@ -18,7 +18,8 @@ cp $SRC/pmc_summary.json ${P}_pmc_summary.json
 cp $SRC/phase_budget.json ${P}_phase_budget.json
 cp $SRC/phase_budget_f32.json ${P}_phase_budget_f32.json
 cp $SRC/phase_budget_config5.json ${P}_phase_budget_config5.json
-python - <<PY
+[ -f $SRC/live/live_timeline.json ] && cp $SRC/live/live_timeline.json ${P}_live_timeline.json
+[ -f $SRC/verify_config3.json ] && python - <<PY
 import json
 out = {}
 for w in ("config3", "config4", "random", "converged", "config5"):

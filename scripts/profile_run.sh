@@ -20,5 +20,7 @@ python scripts/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_summary.
 timeout 300 python scripts/phase_budget.py --config config3 --score exact --out $OUT/phase_budget.json > $OUT/budget.log 2>&1
 timeout 300 python scripts/phase_budget.py --config config3 --score f32 --out $OUT/phase_budget_f32.json >> $OUT/budget.log 2>&1
 timeout 400 python scripts/phase_budget.py --config config5 --score exact --out $OUT/phase_budget_config5.json >> $OUT/budget.log 2>&1
-for w in config3 config4 random converged config5; do timeout 600 python scripts/verify_margin.py --workload $w $( [ $w = config5 ] && echo --pairs 130 ) > $OUT/verify_$w.json 2>> $OUT/verify.err; done
+# device timeline of the live sequence (C++ drop-in, node replay): kernel spans folded over the scans
+timeout 300 python scripts/live_timeline.py run $OUT/live 200 > $OUT/live_timeline.log 2>&1; rm -rf $OUT/live/trace
+[ -n "$SKIP_VERIFY" ] || for w in config3 config4 random converged config5; do timeout 600 python scripts/verify_margin.py --workload $w $( [ $w = config5 ] && echo --pairs 130 ) > $OUT/verify_$w.json 2>> $OUT/verify.err; done
 cat $OUT/bench.json | head -c 600; echo; tail -3 $OUT/bench.err; cat $OUT/pmc_summary.log | tail -14
