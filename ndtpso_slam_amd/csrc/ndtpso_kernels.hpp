@@ -796,22 +796,42 @@ __device__ inline void pad_points_wg(double2* pts, int n) {
 // dirs: (cos, sin) of every beam's angle -- index_to_angle (core.h:40-42) in fp32, then ONE glibc sincos() of the
 // widened value -- computed by the host (beam_directions in ndtpso_hip.hip): the device's own sincos is within an ulp
 // of glibc's but not always equal, and laser_to_point (core.h:45-47) must give the reference's points bit for bit.
+// AHEAD: the next pass's range and direction are asked for before this pass's barrier (the resident path reads the ranges
+// from pinned host memory: a second pass of 57 beams otherwise waits for a second trip over the host link).
+template <bool AHEAD = false>
 __device__ inline int scan_to_points_wg(const float* __restrict__ ranges, const ScanP& sp,
                                         const double2* __restrict__ dirs, bool do_trans,
                                         double tc, double ts, double ttx, double tty, double2* out,
                                         int* s_cnt, double clip_hw = 0., double clip_hh = 0.) {
   const int tid = threadIdx.x, lane = lane_id(), wave = wave_id(), n_waves = blockDim.x >> 6;
   int base = 0;
+  [[maybe_unused]] float r_ahead = 0.f;
+  [[maybe_unused]] double2 d_ahead = make_double2(0., 0.);
+  if constexpr (AHEAD) {
+    if (tid < sp.n_beams) {
+      r_ahead = ranges[tid];
+      d_ahead = dirs[tid];
+    }
+  }
   for (int start = 0; start < sp.n_beams; start += blockDim.x) {
     const int i = start + tid;
     bool valid = false;
     double2 p = make_double2(0., 0.);
+    [[maybe_unused]] const float r_now = r_ahead;
+    [[maybe_unused]] const double2 d_now = d_ahead;
+    if constexpr (AHEAD) {
+      const int in = i + (int)blockDim.x;
+      if (in < sp.n_beams) {
+        r_ahead = ranges[in];
+        d_ahead = dirs[in];
+      }
+    }
     if (i < sp.n_beams) {
-      const float r = ranges[i];
+      const float r = AHEAD ? r_now : ranges[i];
       // ndtframe.cpp:165
       valid = ((double)r > 0.) && (r < sp.rmax) && (r > sp.eps);
       if (valid) {
-        const double2 d = dirs[i];     // index_to_angle + the cosine and sine of laser_to_point, from the host
+        const double2 d = AHEAD ? d_now : dirs[i];     // index_to_angle + the cosine and sine of laser_to_point, from the host
         p.x = (double)r * d.x;         // laser_to_point, core.h:45-47
         p.y = (double)r * d.y;
         if (do_trans) {  // transform_point by s_trans, ndtframe.cpp:175-176
