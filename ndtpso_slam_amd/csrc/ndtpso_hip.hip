@@ -850,6 +850,7 @@ struct ndtpso_ctx {
   std::chrono::steady_clock::time_point clk_wake{}, clk_enter{};
   // single alignments (align_once) are numbered; the kernel writes its number behind its result in the pinned slot
   unsigned long long align_issued = 0, align_seen = 0;
+  uint32_t cluster_nonce = 0;
   bool inputs_pinned = false;         // `inputs` is a pinned host slot (the kernel fetches the table from there itself)
   const void* inputs = nullptr;       // [guess | deviation | pad to kGuessBytes | rand() table] of the alignment about to be launched:
                                       // `table` (uploaded) or a pinned slot the kernel reads in place (ndtpso_map_align)
@@ -1658,7 +1659,7 @@ static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw)
 }
 // Arrival counters of the clusters of one launch (64 bytes each) and their exchange buffers.  The counters come from a
 // pre-zeroed ring and are used once, so a launch needs no memset of its own; the ring is re-zeroed when it wraps.
-static int cluster_counters(ndtpso_ctx* c, size_t n_counters, size_t xc_bytes, unsigned** bar, double** xc) {
+static int cluster_counters(ndtpso_ctx* c, size_t n_counters, size_t xc_bytes, unsigned** bar, uint4** xc) {
   constexpr size_t kRing = 4096;  // counters in the ring (256 KiB)
   if (n_counters > kRing) return fail(c, NDTPSO_E_ARG, "too many clusters in one launch");
   if (c->cluster.cap < kRing * 64) {
@@ -1672,8 +1673,14 @@ static int cluster_counters(ndtpso_ctx* c, size_t n_counters, size_t xc_bytes, u
   *bar = (unsigned*)((unsigned char*)c->cluster.p + c->cluster_next * 64);
   c->cluster_next += n_counters;
   HIP_TRY(c, c->cluster_xc.reserve(xc_bytes));
-  *xc = (double*)c->cluster_xc.p;
+  *xc = (uint4*)c->cluster_xc.p;
   return NDTPSO_OK;
+}
+
+// tags of a launch's exchange slots carry this number (ClusterP::nonce): 1 .. 65535, then around
+static uint32_t next_cluster_nonce(ndtpso_ctx* c) {
+  c->cluster_nonce = c->cluster_nonce % 65535u + 1u;
+  return c->cluster_nonce;
 }
 
 // NDTPSO_CLUSTER_TEST_ABSENT=r (tests only): rank r of every cluster leaves immediately, so the others run into the
@@ -1750,13 +1757,14 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr, 0u};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
     cl.stride = round_up(cfg->population + 1, 8);
     unsigned* bar = nullptr;
-    if (int rc = cluster_counters(c, 1, (size_t)2 * cl.stride * 8, &bar, &cl.xc)) return rc;
+    if (int rc = cluster_counters(c, 1, (size_t)2 * cl.stride * sizeof(uint4), &bar, &cl.xc)) return rc;
     cl.bar = bar;
+    cl.nonce = next_cluster_nonce(c);
   }
 #define LAUNCH_ALIGN_CA(MODE, PATH, CL, ARB)                                                                       \
   hipLaunchKernelGGL((k_align<MODE, PATH, CL, ARB>), dim3(K), dim3(waves * 64), L.total, c->stream,                \
@@ -1952,13 +1960,14 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   if (K > 1) waves = cw;
   PsoP ps = make_pso(cfg, waves, mode, plan.L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr, 0u};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);
     cl.stride = round_up(cfg->population + 1, 8);
     unsigned* bar = nullptr;
-    if (int rc = cluster_counters(c, n_pairs, (size_t)n_pairs * 2 * cl.stride * 8, &bar, &cl.xc)) return rc;
+    if (int rc = cluster_counters(c, n_pairs, (size_t)n_pairs * 2 * cl.stride * sizeof(uint4), &bar, &cl.xc)) return rc;
     cl.bar = bar;
+    cl.nonce = next_cluster_nonce(c);
   }
   const size_t stride = ndtpso_rand_draws(cfg);
   const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population, true, true) : 0;

@@ -1575,14 +1575,15 @@ __device__ __forceinline__ double eval_pose_wave_tiny(const EvalCtx& E, const do
 // The PSO consumes a cost only through `cost < best_cost` / `cost < global_best.best_cost` (core.cpp:63,94,97); the
 // value itself survives only as a later comparison's right-hand side and as the returned gbest cost.  The fp32 score
 // is within ~1e-8 relative of the fp64 one (worst case seen 6e-6 absolute on costs of 300..900), so a comparison
-// whose two sides differ by more than kArbRel * |gbest cost| (2e-3 absolute there, 300 times that) comes out the
-// same in either arithmetic.  The few that are closer ("near": ~0.5 per 70 x 70 alignment) are ARBITRATED: the
+// whose two sides differ by more than the margin arb_margin() -- kArbRel * |gbest cost| (2e-3 absolute there, 300 times
+// that), and never less than kArbAbsPerPoint per point of the scan -- comes out the same in either arithmetic.  The few that are closer ("near": ~0.5 per 70 x 70 alignment) are ARBITRATED: the
 // proposal, the particle's pbest position and the gbest position are scored in fp64 exactly as the fp64-score kernels
 // score them (same operation order, same summation order, the bitmap-form table read from its HBM image), the three
 // stored costs are replaced by those values and the comparison is redone.  Every decision is then the fp64 mode's, so
 // the returned pose is the fp64 mode's bit for bit; the returned cost is the fp64 score of that pose, also its.
-// What this rests on: the fp32 score's error staying below kArbRel / 2 -- measured, not proven; and the dense
-// form's binning (gx within 1e-14 cells of the reference's value, see score_trip_dense).
+// What this rests on: the fp32 score's error staying below half the margin -- bounded for any input (below) and checked
+// evaluation by evaluation in the -DNDTPSO_VERIFY_MARGIN build; and the dense form's binning (gx within 1e-14 cells of
+// the reference's value, see score_trip_dense).
 #ifndef NDTPSO_ARB_REL
 #define NDTPSO_ARB_REL 5e-6
 #endif
@@ -2189,11 +2190,31 @@ __device__ unsigned g_budget[kBudgetMaxBlocks * 16];
 #endif
 
 struct ClusterP {
-  int K, rank, stride;  // workgroups, this one's index, doubles per exchange buffer
+  int K, rank, stride;  // workgroups, this one's index, slots per exchange buffer
   int absent;           // test hook: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout
-  unsigned* bar;        // arrival counter, zeroed before the launch
-  double* xc;           // [2][stride] exchanged costs
+  unsigned* bar;        // (arrival counter of the first exchange scheme; unused)
+  uint4* xc;            // [2][stride] exchange slots {cost lo, tag, cost hi, tag}
+  uint32_t nonce;       // upper half of the tags of this launch (the slots keep whatever earlier launches left there)
 };
+
+// One exchanged cost: a 16-byte slot written and read whole, agent scope (sc1: through to memory, past the L2 of the
+// reader's XCD), with the round's tag in two of its words -- a reader takes a slot only when both tags are the round's,
+// so a value is never paired with a stale or half-written neighbour.  No fence on either side: nothing but the slot itself
+// is communicated.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void xslot_store(uint4* slot, double cost, uint32_t tag) {
+  u32x4 v;
+  v.x = (uint32_t)__double2loint(cost);
+  v.y = tag;
+  v.z = (uint32_t)__double2hiint(cost);
+  v.w = tag;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot), "v"(v) : "memory");
+}
+__device__ __forceinline__ u32x4 xslot_load(const uint4* slot) {
+  u32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(slot) : "memory");
+  return v;
+}
 constexpr uint32_t kStatusClusterTimeout = 16u;
 constexpr uint32_t kStatusLateOverflow = 32u;  // late window binding: the table outgrew what the host had planned for
 constexpr unsigned long long kClusterWaitTicks = 2000000ull;  // 20 ms of the 100 MHz counter (an exchange takes 1.5 us; round 1 waited 0.2 s)
@@ -2211,7 +2232,8 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
   } else {
     NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
-    double* buf = cl.xc + (size_t)(epoch & 1u) * cl.stride;
+    uint4* buf = cl.xc + (size_t)(epoch & 1u) * cl.stride;
+    const uint32_t tag = (cl.nonce << 16) | ((epoch + 1u) & 0xffffu);
     for (int j = first + cl.rank * n_waves + wave_id(); j < last; j += total_waves) {
       const double c = sw.tc[j], s = sw.ts[j];
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
@@ -2220,42 +2242,51 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
         cost = eval_pose_wave_dense<false, true, PATH == 3>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
       else
         cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
-      if (lane_id() == 0) __hip_atomic_store(&buf[j], cost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane_id() == 0) xslot_store(&buf[j], cost, tag);
     }
-    __syncthreads();
     NDTPSO_PHASE_MARK(1);
-    // behind the exchange (thread 0 spins on the arrival counter, everybody else would idle): one wave of every
-    // workgroup draws the next iteration's rand() numbers -- 3.4 us that used to stand alone at the iteration's start
+    // behind the exchange (wave 0 polls, everybody else would idle): one wave of every workgroup draws the next
+    // iteration's rand() numbers -- 3.4 us that used to stand alone at the iteration's start
     if (gen_cnt > 0 && wave_id() == gen_wave) rng_fill_wave0(gen_st, gen_t, gen_dst, gen_cnt);
-    if (threadIdx.x == 0) {
-      __threadfence();
-      atomicAdd(cl.bar, 1u);
-      const unsigned want = (unsigned)cl.K * (epoch + 1u);
+    // Wave 0 of every workgroup reads the round's slots until all of them carry the round's tag (its own workgroup's
+    // among them), a lane per item, and does the round's detection on what it read.  One trip of the cost to memory and
+    // one back: the first scheme -- costs, a fence, an arrival counter, a poll, a fence, the costs read back -- was four,
+    // with the L2 written back and invalidated twice per round (3.4 us a round of the live sequence's 60).
+    if (wave_id() == 0) {
       const unsigned long long t0 = wall_clock64();
-      while (__hip_atomic_load(cl.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-        if (wall_clock64() - t0 > kClusterWaitTicks) {
-          *timed_out = 1;
-          break;
+      for (int j0 = first; j0 < last; j0 += kWave) {
+        const int j = j0 + lane_id();
+        const bool mine = j < last;
+        double cost = 0.;
+        for (;;) {
+          bool ok = true;
+          if (mine) {
+            const u32x4 v = xslot_load(&buf[j]);
+            ok = v.y == tag && v.w == tag;
+            cost = __hiloint2double((int)v.z, (int)v.x);
+          }
+          if (__all(ok)) break;
+          if (wall_clock64() - t0 > kClusterWaitTicks) {
+            *timed_out = 1;
+            break;
+          }
+        }
+        if (mine) {
+          sw.tcost[j] = cost;
+          if (MODE == kScoreF32 && (cost != cost || (cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))))
+            *tiny = 1;
+          else if (improver && cost < gbc && cost < sw.pbc[j])  // nested tests of core.cpp:94-104, see eval_items
+            atomicMin(improver, j);
+          if constexpr (ARB) {  // exact mode, as in eval_items: every workgroup of the cluster notes the same items
+            if (improver) {
+              const double tau = arb_margin(gbc, n);
+              if (near_tie(cost, sw.pbc[j], tau) || near_tie(cost, gbc, tau)) near_note(near_cnt, near_list, j);
+            }
+          }
         }
       }
-      __threadfence();
     }
-    __syncthreads();
     NDTPSO_PHASE_MARK(2);
-    for (int j = first + (int)threadIdx.x; j < last; j += blockDim.x) {
-      const double cost = __hip_atomic_load(&buf[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sw.tcost[j] = cost;
-      if (MODE == kScoreF32 && (cost != cost || (cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))))
-        *tiny = 1;
-      else if (improver && cost < gbc && cost < sw.pbc[j])  // nested tests of core.cpp:94-104, see eval_items
-        atomicMin(improver, j);
-      if constexpr (ARB) {  // exact mode, as in eval_items: every workgroup of the cluster notes the same items
-        if (improver) {
-          const double tau = kArbRel * fabs(gbc);
-          if (near_tie(cost, sw.pbc[j], tau) || near_tie(cost, gbc, tau)) near_note(near_cnt, near_list, j);
-        }
-      }
-    }
     ++epoch;
     NDTPSO_PHASE_MARK(3);
   }
