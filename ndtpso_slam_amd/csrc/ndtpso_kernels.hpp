@@ -2671,18 +2671,31 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             fabs(cst - sh->gbc) <= NDTPSO_COUNT_AMBIG * fabs(sh->gbc))
           atomicAdd(&sh->timed_out, 1);
 #endif
+        // (everything read before anything is written: the swarm's arrays may alias as far as the compiler knows, and a
+        // load placed behind a store waited for its own data before the next pair could start -- seven round trips to
+        // the swarm's memory in a row where one does)
+        double np[3], nv[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          const double np = sw.tpos[k * S + j];
-          sw.pos[k * S + j] = np;
-          sw.vel[k * S + j] = sw.tvel[k * S + j];
-          if (better) sw.pb[k * S + j] = np;
+          np[k] = sw.tpos[k * S + j];
+          nv[k] = sw.tvel[k * S + j];
+        }
+        [[maybe_unused]] double hc = 0., hs = 0.;
+        if constexpr (ARB) {
+          hc = sw.pcs[j];
+          hs = sw.pcs[S + j];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          sw.pos[k * S + j] = np[k];
+          sw.vel[k * S + j] = nv[k];
+          if (better) sw.pb[k * S + j] = np[k];
         }
         if (better) sw.pbc[j] = cst;
         if constexpr (ARB) {
           if (better) {
-            sw.bcs[j] = sw.pcs[j];
-            sw.bcs[S + j] = sw.pcs[S + j];
+            sw.bcs[j] = hc;
+            sw.bcs[S + j] = hs;
             bool exact_j = false;
             for (int q = 0; q < arb_cnt; ++q) exact_j |= (int)arb_list[q] == j;
             sw.pex[j] = exact_j ? 1 : 0;
