@@ -547,7 +547,6 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   const size_t b = CLUSTER ? blockIdx.x / (unsigned)cl.K : blockIdx.x;
   if constexpr (CLUSTER) {
     cl.rank = (int)(blockIdx.x % (unsigned)cl.K);
-    cl.bar += b * 16;
     cl.xc += b * 2 * (size_t)cl.stride;
   }
   const bool writer = !CLUSTER || cl.rank == 0;
@@ -818,11 +817,10 @@ struct ndtpso_ctx {
   WinP wn{};
   uint32_t n_rows = 0;
   int n_cus = 256;  // compute units of the device (multiProcessorCount)
-  size_t cluster_next = 0;  // next unused arrival counter of the ring in `cluster`
   // A cluster whose workgroups were not scheduled together gave up (bounded wait) and its alignment was redone on one
   // workgroup: the device is shared with other work.  The next `cluster_penalty` single alignments do not try again.
   int cluster_penalty = 0;
-  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster, cluster_xc, ximg;
+  DevBuf image, rows, xy, xy2, ranges, ranges2, poses, costs, dump, small, table, out, seeds, ws, gate, cluster_xc, ximg;
   PinnedRing pinned;
   BeamDirs beam_dirs[4];  // cached beam directions of the scan geometries in use (beam_directions)
   unsigned beam_dirs_next = 0;
@@ -1179,7 +1177,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (DevBuf* b : {&c->image, &c->rows, &c->xy, &c->xy2, &c->ranges, &c->ranges2, &c->poses, &c->costs, &c->dump,
-                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate, &c->cluster, &c->cluster_xc, &c->ximg})
+                    &c->small, &c->table, &c->out, &c->seeds, &c->ws, &c->gate, &c->cluster_xc, &c->ximg})
     b->release();
   for (BeamDirs& b : c->beam_dirs) b.buf.release();
   c->pinned.release();
@@ -1657,21 +1655,9 @@ static void cluster_shape(int P, bool swarm_in_lds, bool allow, int* K, int* cw)
   if (const char* e = std::getenv("NDTPSO_CLUSTER")) k = std::min(128, std::max(0, std::atoi(e)));
   if (allow && swarm_in_lds && k >= 2) *K = k;
 }
-// Arrival counters of the clusters of one launch (64 bytes each) and their exchange buffers.  The counters come from a
-// pre-zeroed ring and are used once, so a launch needs no memset of its own; the ring is re-zeroed when it wraps.
-static int cluster_counters(ndtpso_ctx* c, size_t n_counters, size_t xc_bytes, unsigned** bar, uint4** xc) {
-  constexpr size_t kRing = 4096;  // counters in the ring (256 KiB)
-  if (n_counters > kRing) return fail(c, NDTPSO_E_ARG, "too many clusters in one launch");
-  if (c->cluster.cap < kRing * 64) {
-    HIP_TRY(c, c->cluster.reserve(kRing * 64));
-    c->cluster_next = kRing;  // forces the zeroing below
-  }
-  if (c->cluster_next + n_counters > kRing) {
-    HIP_TRY(c, hipMemsetAsync(c->cluster.p, 0, kRing * 64, c->stream));
-    c->cluster_next = 0;
-  }
-  *bar = (unsigned*)((unsigned char*)c->cluster.p + c->cluster_next * 64);
-  c->cluster_next += n_counters;
+// Exchange slots of the clusters of one launch (ClusterP::xc).  They need no zeroing: a slot counts only when it carries
+// the launch's nonce and the round's number.
+static int cluster_slots(ndtpso_ctx* c, size_t xc_bytes, uint4** xc) {
   HIP_TRY(c, c->cluster_xc.reserve(xc_bytes));
   *xc = (uint4*)c->cluster_xc.p;
   return NDTPSO_OK;
@@ -1757,13 +1743,11 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr, 0u};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
     cl.stride = round_up(cfg->population + 1, 8);
-    unsigned* bar = nullptr;
-    if (int rc = cluster_counters(c, 1, (size_t)2 * cl.stride * sizeof(uint4), &bar, &cl.xc)) return rc;
-    cl.bar = bar;
+    if (int rc = cluster_slots(c, (size_t)2 * cl.stride * sizeof(uint4), &cl.xc)) return rc;
     cl.nonce = next_cluster_nonce(c);
   }
 #define LAUNCH_ALIGN_CA(MODE, PATH, CL, ARB)                                                                       \
@@ -1960,13 +1944,11 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   if (K > 1) waves = cw;
   PsoP ps = make_pso(cfg, waves, mode, plan.L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, nullptr, 0u};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);
     cl.stride = round_up(cfg->population + 1, 8);
-    unsigned* bar = nullptr;
-    if (int rc = cluster_counters(c, n_pairs, (size_t)n_pairs * 2 * cl.stride * sizeof(uint4), &bar, &cl.xc)) return rc;
-    cl.bar = bar;
+    if (int rc = cluster_slots(c, (size_t)n_pairs * 2 * cl.stride * sizeof(uint4), &cl.xc)) return rc;
     cl.nonce = next_cluster_nonce(c);
   }
   const size_t stride = ndtpso_rand_draws(cfg);

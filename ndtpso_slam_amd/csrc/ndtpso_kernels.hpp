@@ -2140,12 +2140,11 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
 // A lone alignment (the live node, BASELINE config 2) is bounded by the VALU of the one CU its workgroup runs on.
 // K workgroups can share it: every one of them holds the table, the points and the WHOLE swarm and runs the
 // identical control flow (proposals, commits, replays -- deterministic, so the K copies never diverge); only the
-// cost evaluations of a round are divided, one item per wave across all K x waves waves.  After evaluating, the
-// workgroups publish their costs (agent-scope stores into xc[round parity][item]), meet at a counter barrier and
-// read all costs of the round back; first-improver / underflow detection then runs locally on identical data.
-// Per-item arithmetic is the single-workgroup kernel's, so the results are bit-identical to it.
-// Measured price of one exchange on MI355X (scripts/ubench_cluster_barrier.hip): 1.4-1.7 us for K = 4..16.
-// The wait is bounded by the real-time counter: a workgroup that never arrives (cluster not co-resident) raises
+// cost evaluations of a round are divided, one item per wave across all K x waves waves.  After evaluating, every
+// wave publishes its cost in a tagged 16-byte slot (xc[round parity][item], xslot_store) and wave 0 of every workgroup
+// reads the round's slots until all carry the round's tag (eval_round); first-improver / underflow detection then runs
+// locally on identical data.  Per-item arithmetic is the single-workgroup kernel's, so the results are bit-identical
+// to it.  The wait is bounded by the real-time counter: a workgroup that never arrives (cluster not co-resident) raises
 // kStatusClusterTimeout and the host reruns the alignment on one workgroup.
 // NDTPSO_PROFILE_PHASES (diagnostic builds only): thread 0 of rank 0 accumulates the real-time-counter ticks between
 // the marks of a cluster round and prints them at the end: [other -> 0] control, [0 -> 1] evaluation, [1 -> 2]
@@ -2192,7 +2191,6 @@ __device__ unsigned g_budget[kBudgetMaxBlocks * 16];
 struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, slots per exchange buffer
   int absent;           // test hook: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout
-  unsigned* bar;        // (arrival counter of the first exchange scheme; unused)
   uint4* xc;            // [2][stride] exchange slots {cost lo, tag, cost hi, tag}
   uint32_t nonce;       // upper half of the tags of this launch (the slots keep whatever earlier launches left there)
 };
@@ -2301,7 +2299,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
                                   PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats,
-                                  const ClusterP& cl = ClusterP{1, 0, 0, -1, nullptr, nullptr}) {
+                                  const ClusterP& cl = ClusterP{1, 0, 0, -1, nullptr, 0u}) {
   unsigned epoch = 0;
   const bool writer = !CLUSTER || cl.rank == 0;  // the workgroup that reports the result
   const int tid = threadIdx.x;
