@@ -336,7 +336,15 @@ int ndtpso_align_pairs_describe(const ndtpso_scan_geom *geom, const ndtpso_grid 
  * every device holds the poses of the whole batch; device 0's copy is returned.  Results are those of
  * ndtpso_align_pairs on the same arguments, bit for bit, whatever the number of devices.
  * RCCL is loaded at run time: ndtpso_shard_group_create returns NDTPSO_E_HIP when it (or a listed device) is absent.
- * A group is used by one host thread at a time; buffers are host memory (the scatter is part of the call). */
+ * A group is used by one host thread at a time.  Every device has a host thread of its own inside the group: the uploads
+ * of device d (blocking staged copies when the caller's memory is pageable), its launch and the copy of its statistics are
+ * issued by that thread, all devices at once; the calling thread joins the ENQUEUES, issues the collective, and only then
+ * waits for the devices.  Two flavours: host buffers (the scatter is part of the call) and `_dev` (each device's shard
+ * already resident: per-device arrays of device pointers, entry d = the slice [first_d, last_d) on device d, complete
+ * before the call).  ndtpso_shard_last_timing reports, for the last call, per device {start after the call's entry, uploads,
+ * launches} and per call {until every device's work was enqueued, the collective's enqueue, total} in microseconds of
+ * host time; ndtpso_shard_gathered(group, d) is device d's copy of the gathered batch, G blocks of [pose (M x 3) |
+ * cost (M)] doubles with M = ceil(n_pairs / G), valid until the group's next call. */
 typedef struct ndtpso_shard_group ndtpso_shard_group;
 int ndtpso_shard_group_create(const int *devices, int n_devices, ndtpso_shard_group **out);
 void ndtpso_shard_group_destroy(ndtpso_shard_group *group);
@@ -349,6 +357,16 @@ int ndtpso_align_pairs_sharded(ndtpso_shard_group *group, uint32_t n_pairs, cons
                                const double *guess, const double *deviation, const ndtpso_pso_config *cfg,
                                const uint32_t *seeds, const int32_t *rand_tables, int score_mode, double *out_pose,
                                double *out_cost, ndtpso_align_stats *stats);
+int ndtpso_align_pairs_sharded_dev(ndtpso_shard_group *group, uint32_t n_pairs, const float *const *d_ref_ranges,
+                                   const float *const *d_new_ranges, const ndtpso_scan_geom *geom,
+                                   const ndtpso_grid *grid, const double *const *d_guess,
+                                   const double *const *d_deviation, const ndtpso_pso_config *cfg,
+                                   const uint32_t *const *d_seeds, const int32_t *const *d_rand_tables, int score_mode,
+                                   double *out_pose /* may be NULL: results stay on the devices */, double *out_cost,
+                                   ndtpso_align_stats *stats);
+int ndtpso_shard_last_timing(const ndtpso_shard_group *group, double *per_device /* [G][3] or NULL */,
+                             double *call /* [3] or NULL */);
+const double *ndtpso_shard_gathered(const ndtpso_shard_group *group, int index);
 
 #ifdef __cplusplus
 }

@@ -107,7 +107,8 @@ EXPORTS = [
     "ndtpso_map_build", "ndtpso_map_speculate_build", "ndtpso_map_align", "ndtpso_map_cost", "ndtpso_map_get_info", "ndtpso_map_get_cells", "ndtpso_map_get_points",
     "ndtpso_map_get_occupancy",
     "ndtpso_shard_group_create", "ndtpso_shard_group_destroy", "ndtpso_shard_group_size", "ndtpso_shard_last_error",
-    "ndtpso_shard_range", "ndtpso_align_pairs_sharded",
+    "ndtpso_shard_range", "ndtpso_align_pairs_sharded", "ndtpso_align_pairs_sharded_dev", "ndtpso_shard_last_timing",
+    "ndtpso_shard_gathered",
 ]
 
 _lib = None
@@ -193,10 +194,17 @@ def load(build_if_missing: bool = True):
     L.ndtpso_shard_range.restype = None
     L.ndtpso_align_pairs_sharded.argtypes = [vp, C.c_uint32, fp, fp, C.POINTER(ScanGeom), C.POINTER(Grid), dp, dp,
                                              C.POINTER(PSOConfig), up, ip, C.c_int, dp, dp, vp]
+    pp = C.POINTER(C.c_void_p)
+    L.ndtpso_align_pairs_sharded_dev.argtypes = [vp, C.c_uint32, pp, pp, C.POINTER(ScanGeom), C.POINTER(Grid), pp, pp,
+                                                 C.POINTER(PSOConfig), pp, pp, C.c_int, dp, dp, vp]
+    L.ndtpso_shard_last_timing.argtypes = [vp, dp, dp]
+    L.ndtpso_shard_gathered.argtypes = [vp, C.c_int]
+    L.ndtpso_shard_gathered.restype = C.c_void_p
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_rand_draws", "ndtpso_points_destroy",
-                        "ndtpso_map_destroy", "ndtpso_shard_group_destroy", "ndtpso_shard_last_error", "ndtpso_shard_range"):
+                        "ndtpso_map_destroy", "ndtpso_shard_group_destroy", "ndtpso_shard_last_error", "ndtpso_shard_range",
+                        "ndtpso_shard_gathered"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -433,6 +441,39 @@ class ShardGroup:
         if rc != OK:
             raise NdtpsoError(rc, self._lib.ndtpso_shard_last_error(self._h).decode())
         return pose, cost, stats
+
+    def align_pairs_dev(self, n_pairs, d_ref, d_new, geom: ScanGeom, grid: Grid, d_guess, d_dev, cfg: PSOConfig, d_seeds=None,
+                        d_tables=None, mode=SCORE_EXACT, fetch=True):
+        """ndtpso_align_pairs_sharded_dev: every argument a list of G device pointers (ints), entry d = shard d's slice
+        resident on device d and complete.  fetch=False leaves the results on the devices (gathered())."""
+        G = self.size()
+
+        def arr(ptrs):
+            if ptrs is None:
+                return None
+            assert len(ptrs) == G
+            return (C.c_void_p * G)(*[C.c_void_p(int(x)) if x else None for x in ptrs])
+
+        B = int(n_pairs)
+        pose, cost, stats = np.empty((B, 3)), np.empty(B), np.zeros(B, dtype=STATS_DTYPE)
+        rc = self._lib.ndtpso_align_pairs_sharded_dev(
+            self._h, B, arr(d_ref), arr(d_new), C.byref(geom), C.byref(grid), arr(d_guess), arr(d_dev), C.byref(cfg),
+            arr(d_seeds), arr(d_tables), mode, _p(pose, C.c_double) if fetch else None, _p(cost, C.c_double) if fetch else None,
+            stats.ctypes.data_as(C.c_void_p))
+        if rc != OK:
+            raise NdtpsoError(rc, self._lib.ndtpso_shard_last_error(self._h).decode())
+        return (pose, cost, stats) if fetch else (None, None, stats)
+
+    def gathered(self, index: int) -> int:
+        """Device pointer of device `index`'s copy of the gathered batch (G blocks of [pose M x 3 | cost M])."""
+        return int(self._lib.ndtpso_shard_gathered(self._h, int(index)) or 0)
+
+    def last_timing(self):
+        """Host-side microseconds of the last call: ({device: (start, uploads, launches)}, (enqueued, collective, total))."""
+        G = self.size()
+        per, call = np.zeros((G, 3)), np.zeros(3)
+        self._lib.ndtpso_shard_last_timing(self._h, _p(per, C.c_double), _p(call, C.c_double))
+        return per, call
 
 
 def shard_range(n_pairs: int, rank: int, n_devices: int):

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/ndtpso_hip.h"
@@ -1686,11 +1687,21 @@ static bool cluster_worthwhile(int K, int cw) { return std::getenv("NDTPSO_CLUST
 // kernels, and the host would hear of the result later).  A kernel that died, or ended without reporting, must still end
 // the wait: every 10 ms the stream is asked whether it is still busy -- not more often, because the query itself puts a
 // marker into the queue, and a marker between two kernels of the live sequence costs the device 6 us.
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  __asm__ __volatile__("yield");
+#else
+  std::this_thread::yield();
+#endif
+}
+
 static int wait_pinned_word(ndtpso_ctx* c, const uint32_t* word, uint32_t want) {
   std::chrono::steady_clock::time_point last{};
   for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return NDTPSO_OK;
-    __builtin_ia32_pause();
+    cpu_relax();
     if ((spins & 4095u) == 0) {
       const auto now = std::chrono::steady_clock::now();
       if (last.time_since_epoch().count() == 0) last = now;
@@ -2149,6 +2160,9 @@ int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges,
                                         rand_tables ? (const int32_t*)c->table.p : nullptr, mode, d_pose, d_cost,
                                         d_stats);
   if (rc != NDTPSO_OK) return rc;
+  // with batches in flight (ndtpso_set_pipeline_depth) the launch went to a lane's stream: the copies below and the
+  // next call's uploads into the same staging buffers must come behind it
+  if (int frc = ndtpso_pipeline_flush(c, 0)) return frc;
   HIP_TRY(c, hipMemcpyAsync(out_pose, d_pose, B * 24, hipMemcpyDeviceToHost, c->stream));
   if (out_cost) HIP_TRY(c, hipMemcpyAsync(out_cost, d_cost, B * 8, hipMemcpyDeviceToHost, c->stream));
   if (stats) HIP_TRY(c, hipMemcpyAsync(stats, d_stats, B * sizeof(AlignStats), hipMemcpyDeviceToHost, c->stream));

@@ -96,3 +96,29 @@ def test_flush_orders_outputs_on_the_context_stream():
     for c in copies:
         assert torch.equal(c, want)
     ctx.close()
+
+
+def test_host_buffer_batches_at_depth_two_equal_depth_one():
+    """ndtpso_align_pairs (host buffers in and out, synchronous) with batches in flight switched on: its launch goes to a
+    lane's stream, so the call has to flush the lanes before it copies the results out and before the next call's uploads
+    reuse the staging buffers.  Consecutive calls on different inputs must return what they return at depth 1."""
+    from ndtpso_slam_amd import capi, synth
+    B, P, I = 160, 30, 20     # more pairs than half the compute units: the pipelined path, not the cluster path
+    batches = [synth.make_pairs(B, seed=140 + k) for k in range(4)]
+    p0 = batches[0]
+    geom = capi.ScanGeom(p0.n_beams, float(p0.angle_min), float(p0.angle_inc), float(p0.range_max), 0.1)
+    grid, cfg, dev = capi.Grid(60, 60, 0.5), capi.PSOConfig.make(I, P), (0.1, 0.1, 3.1415e-3)
+    ctx = capi.Context(0)
+
+    def run(depth):
+        ctx.set_pipeline_depth(depth)
+        return [ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+                for p in batches]
+
+    serial, piped = run(1), run(2)
+    for (p1, c1, s1), (p2, c2, s2) in zip(serial, piped):
+        assert np.isfinite(p2).all() and (c2 < 0).all()          # not the memset's zeros
+        assert np.array_equal(p1, p2) and np.array_equal(c1, c2)
+        assert np.array_equal(s1["status"], s2["status"]) and np.array_equal(s1["cost_evals"], s2["cost_evals"])
+    ctx.set_pipeline_depth(1)
+    ctx.close()

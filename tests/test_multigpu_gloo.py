@@ -226,6 +226,57 @@ def test_sharded_entry_point_equals_align_pairs(ctx, n_pairs):
 
 
 @pytest.mark.gpu
+def test_sharded_resident_flavour_and_timing(ctx):
+    """ndtpso_align_pairs_sharded_dev: every device's shard already resident (per-device arrays of device pointers).  Same
+    poses as the host flavour; the gathered batch can stay on the devices; the call reports where its host time went."""
+    import torch
+    from ndtpso_slam_amd import capi, synth
+    B = 301
+    p = synth.make_pairs(B, seed=33)
+    geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+    grid, cfg = capi.Grid(60, 60, 0.5), capi.PSOConfig.make(12, 20)
+    dev = (0.1, 0.1, 3.1415e-3)
+    want, wcost, wst = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+    devices = list(range(torch.cuda.device_count()))
+    G = len(devices)
+    g = capi.ShardGroup(devices)
+    keep, ptrs = [], {k: [] for k in ("ref", "new", "guess", "dev", "seeds")}
+    for r, d in enumerate(devices):
+        a, b = capi.shard_range(B, r, G)
+        td = torch.device("cuda", d)
+        t = {"ref": torch.from_numpy(p.ref_ranges[a:b]).to(td), "new": torch.from_numpy(p.new_ranges[a:b]).to(td),
+             "guess": torch.zeros(b - a, 3, dtype=torch.float64, device=td),
+             "dev": torch.tensor(dev, dtype=torch.float64, device=td).repeat(b - a, 1).contiguous(),
+             "seeds": torch.from_numpy(p.seeds[a:b].astype(np.int64)).to(td).to(torch.int32)}
+        keep.append(t)
+        for k in ptrs:
+            ptrs[k].append(t[k].data_ptr())
+        torch.cuda.synchronize(td)
+    got, cost, st = g.align_pairs_dev(B, ptrs["ref"], ptrs["new"], geom, grid, ptrs["guess"], ptrs["dev"], cfg, d_seeds=ptrs["seeds"])
+    assert np.array_equal(got, want) and np.array_equal(cost, wcost) and np.array_equal(st["cost_evals"], wst["cost_evals"])
+    per, call = g.last_timing()
+    assert per.shape == (G, 3) and (per[:, 1] == 0).all() and (per[:, 2] > 0).all()      # nothing uploaded, something launched
+    assert 0 < call[0] <= call[2] and call[1] > 0
+    # results left on the devices: device 0's copy of the gathered batch, block r = shard r as [pose (M x 3) | cost (M)]
+    _, _, st2 = g.align_pairs_dev(B, ptrs["ref"], ptrs["new"], geom, grid, ptrs["guess"], ptrs["dev"], cfg, d_seeds=ptrs["seeds"], fetch=False)
+    M = -(-B // G)
+    import ctypes
+    raw = np.empty(4 * M * G)
+    assert g.gathered(0) != 0
+    hip = ctypes.CDLL("libamdhip64.so")      # the HIP runtime torch has already loaded: one plain device-to-host copy
+    assert hip.hipMemcpy(ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(g.gathered(0)), ctypes.c_size_t(raw.nbytes), 2) == 0
+    for r in range(G):
+        a, b = capi.shard_range(B, r, G)
+        assert np.array_equal(raw[4 * M * r:4 * M * r + 3 * (b - a)].reshape(b - a, 3), want[a:b])
+        assert np.array_equal(raw[4 * M * r + 3 * M:4 * M * r + 3 * M + (b - a)], wcost[a:b])
+    # the host flavour reports its uploads
+    g.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+    per, call = g.last_timing()
+    assert (per[:, 1] > 0).all()
+    g.close()
+
+
+@pytest.mark.gpu
 def test_cpp_batch_driver_on_all_devices(tmp_path, ctx):
     """host/replay/batch_sharded (C++, the C-ABI only) on a batch file: same poses as the Python binding."""
     from ndtpso_slam_amd import capi, synth
