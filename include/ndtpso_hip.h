@@ -94,7 +94,8 @@ typedef struct {
 typedef struct {
   uint32_t n_points;      /* new-scan points that entered the PSO */
   uint32_t n_built;       /* built reference cells */
-  uint32_t cost_evals;    /* particle evaluations incl. replays */
+  uint32_t cost_evals;    /* particle evaluations incl. those thrown away behind a gbest update (the one-workgroup kernels deal an
+                             iteration's items by ticket: how many were in flight then depends on timing -- poses and costs do not) */
   uint32_t rounds;        /* evaluation rounds (iterations + replays) */
   uint32_t gbest_updates; /* in-iteration gbest improvements */
   uint32_t status;        /* 0 ok; bit0: a reference point fell outside the staging window; bit1: more built cells

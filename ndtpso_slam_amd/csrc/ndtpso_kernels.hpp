@@ -352,6 +352,9 @@ __device__ __forceinline__ void cell_coords_rt(const GridP& g, double qx, double
 #ifndef NDTPSO_ALTERNATE_PRIO
 #define NDTPSO_ALTERNATE_PRIO 1
 #endif
+#ifndef NDTPSO_STREAM
+#define NDTPSO_STREAM 1  // one-workgroup kernels: an iteration's items dealt by ticket, one barrier per phase (eval_stream); 0: rounds
+#endif
 
 // ---- K1: NDT score of one candidate pose, one wave --------------------------
 //
@@ -1471,6 +1474,9 @@ struct PsoShared {  // small control block in LDS
   int jstar[3];  // first improver of a group, rotating by group number (see pso_run_wg)
   int tiny;      // fp32 score mode: some cost of the current group fell in the underflow regime
   int timed_out; // cluster mode: a workgroup of the cluster did not arrive at an exchange
+  int ticket;    // NDTPSO_STREAM: the next item of the phase (eval_stream)
+  int jmax;      //                the highest item evaluated in it
+  int spare[32]; //                where the lanes that take no ticket add their zeros (take_ticket)
   RngState rng;
   // arbitration (exact mode): items of a group whose fp32 cost is too close to their pbest's or the gbest's to decide
   // the comparison; rotating by group number like jstar
@@ -2135,6 +2141,95 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
   }
 }
 
+// ---- items of a whole iteration dealt by ticket (round 4) -------------------------------------------------------------
+//
+// NDTPSO_STREAM (the one-workgroup kernels; a cluster keeps its rounds): the evaluation rounds of an iteration -- 15 items,
+// a barrier, 15 items, a barrier ... -- cost a two-item wave a fifth of its time waiting for the round's slowest wave
+// (profiles/r03_phase_budget.json), and 70 particles in rounds of 15 are ten item-times per iteration where 70 / 8 is
+// 8.75.  Here a PHASE covers every particle not yet committed: the waves take items in index order from a ticket counter
+// in LDS, as fast as each gets through them, and meet once at the end.  The exact-order semantics are the rounds': all
+// items of a phase carry proposals against the same gbest; the lowest item that beats it (core.cpp:94-104, nested
+// tests; atomicMin into *improver by the evaluating wave) ends the phase's useful part -- items up to it are committed,
+// everything behind it is proposed again.  What a round bounded by its size a phase bounds by looking: before it takes
+// an item a wave reads *improver, and leaves when its ticket lies behind it (so do all later tickets: *improver only
+// falls).  Every item below the final first improver has been evaluated -- a ticket is only ever dropped behind an
+// improver that was already known --, the evaluated items are [lo, *jmax], and what is thrown away per gbest update
+// is what was in flight: about as much as the tail of a round.
+//
+// The ticket: lane 0 adds one to the counter, every other lane adds zero to one of 32 spare words -- no branch and no two
+// lanes on the counter.  (All 64 lanes adding to one address serialise in the LDS unit, an LDS atomic round trip in front
+// of every item of a 15-item round lost 12 % in round 1, and the `if (lane == 0) atomicAdd` + readfirstlane spelling
+// produced a loop that never ended with that round's compiler, NOTEBOOK 5.1; a one-lane exec mask in inline assembly
+// crashed this compiler's register allocator.)
+__device__ __forceinline__ int take_ticket(int* counter, int* spare /* 32 words */) {
+  typedef int __attribute__((address_space(3))) * lds_int_t;
+  const int lane = lane_id();
+  lds_int_t a = lane == 0 ? (lds_int_t)counter : (lds_int_t)spare + (lane & 31);
+  const int v = __hip_atomic_fetch_add(a, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __builtin_amdgcn_readfirstlane(v);
+}
+
+template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false>
+__device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int P, double gbc,
+                                   int* ticket, int* spare, int* improver, int* jmax, int* tiny, int* near_cnt,
+                                   unsigned short* near_list) {
+  int last_done = -1;
+  for (;;) {
+    const int seen = *(volatile int*)improver;  // (in flight together with the ticket)
+    const int j = take_ticket(ticket, spare);
+    if (j >= P || j > seen) break;
+#if NDTPSO_ALTERNATE_PRIO
+    // the two workgroups of a compute unit take turns holding the higher priority (see pso_run_wg)
+    if ((((unsigned)(wall_clock64() >> 9) & 15u) < (unsigned)NDTPSO_PRIO_SHARE) == (blockIdx.x >= (gridDim.x >> 1)))
+      __builtin_amdgcn_s_setprio(1);
+    else
+      __builtin_amdgcn_s_setprio(0);
+#endif
+    const double c = sw.tc[j], s = sw.ts[j];
+    const double pbc_j = sw.pbc[j];
+    double cost;
+    if constexpr (path_is_dense(PATH)) {
+      const DenseItem it{c, s, sw.ttx[j], sw.tty[j], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
+      if constexpr (PATH == 3 || (PATH == 2 && NOCLIP)) {  // (the fused pairs kernels: they set up the guard)
+        typedef double v2d_t __attribute__((ext_vector_type(2)));
+        typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+        const v2d_t gx = *(lds_d2_t)(uintptr_t)E.guard_lds, gy = *(lds_d2_t)(uintptr_t)(E.guard_lds + 16u);  // DenseGuard
+        if (it.TX >= gx.x && it.TX < gx.y && it.TY >= gy.x && it.TY < gy.y)
+          cost = eval_item_wave_dense<false, PATH == 3, true, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
+        else
+          cost = eval_item_wave_dense<false, PATH == 3, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
+      } else {
+        cost = eval_item_wave_dense<false, PATH == 3, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
+      }
+    } else {
+      const double tx = sw.tpos[j], ty = sw.tpos[S + j];
+      cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+    }
+#ifdef NDTPSO_VERIFY_MARGIN
+    if constexpr (ARB && (PATH == 2 || PATH == 3))
+      if (E.xa) verify_item<PATH == 3>(E.xa, j, cost, gbc);
+#endif
+    last_done = j;
+    if (lane_id() == 0) {  // (as eval_items, with an improver to look for)
+      sw.tcost[j] = cost;
+      bool ordinary = true;
+      if (MODE == kScoreF32 && !(cost <= -kTinyCost)) {  // NaN, or the underflow regime
+        if (cost != cost || pbc_j > -kTinyCost) {
+          *tiny = 1;
+          ordinary = false;
+        }
+      }
+      if (ordinary && cost < gbc)
+        if (cost < pbc_j) atomicMin(improver, j);
+      if constexpr (ARB) {
+        const double tau = arb_margin(gbc, n);
+        if (near_tie(cost, pbc_j, tau) || near_tie(cost, gbc, tau)) near_note(near_cnt, near_list, j);
+      }
+    }
+  }
+  if (lane_id() == 0 && last_done >= 0) atomicMax(jmax, last_done);
+}
+
 // ---- one alignment on several compute units ("cluster") --------------------------------------------------------
 //
 // A lone alignment (the live node, BASELINE config 2) is bounded by the VALU of the one CU its workgroup runs on.
@@ -2301,6 +2396,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats,
                                   const ClusterP& cl = ClusterP{1, 0, 0, -1, nullptr, 0u}) {
   unsigned epoch = 0;
+  constexpr bool kStream = NDTPSO_STREAM && !CLUSTER;  // phases dealt by ticket (eval_stream) instead of rounds
   const bool writer = !CLUSTER || cl.rank == 0;  // the workgroup that reports the result
   const int tid = threadIdx.x;
   const int P = ps.P, S = P + 1;
@@ -2530,6 +2626,12 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     int lo = 0;
     bool need_propose = true;
     while (lo < P) {
+      [[maybe_unused]] const bool proposed_now = need_propose;
+      if constexpr (kStream)
+        if (tid == 0) {  // the phase's ticket counter (published by the barrier that follows)
+          sh->ticket = lo;
+          sh->jmax = lo - 1;
+        }
       if (need_propose) {
         // core.cpp:83-90 for every particle not yet committed, against the current gbest
         // one thread per (particle, coordinate): the three coordinates of a particle are independent (core.cpp:83-90),
@@ -2565,87 +2667,157 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         NDTPSO_PSO_MARK(1);
         NDTPSO_PB(3);
       }
-#if NDTPSO_ALTERNATE_PRIO
-      // Two workgroups share a CU.  VALU issue is arbitrated by priority, then age, so the earlier-dispatched
-      // partner otherwise starves the other, finishes ~25 % early and leaves the CU half empty (measured with
-      // per-workgroup timestamps: residency 0.84 -> 0.95, +6 % throughput with this).  The partners (blocks b and
-      // b + grid/2 by dispatch order -- an assumption that only affects speed) take turns holding the higher
-      // priority; the turn comes from the shared 100 MHz real-time counter (5 us slices), so the two are
-      // complementary at all times, and the later-dispatched one gets 9 of 16 slices, which is what equalises
-      // their finishing times.
-      if constexpr (!CLUSTER) {
-        if ((((unsigned)(wall_clock64() >> 9) & 15u) < (unsigned)NDTPSO_PRIO_SHARE) == (blockIdx.x >= (gridDim.x >> 1)))
-          __builtin_amdgcn_s_setprio(1);
-        else
-          __builtin_amdgcn_s_setprio(0);
-      }
-#endif
-      const int slot = (int)(grp % 3u);
-      const int hi_g = min(lo + ps.G, P);
-      // a cluster draws the next iteration's numbers behind the first exchange of this one (eval_round)
-      const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
-      eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
-                                      &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
-                                      dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
-      if (gen_here) next_filled = n_draw;
-      NDTPSO_PB(4);
-      if constexpr (!CLUSTER) {
-        // the light wave's other job: a slice of the next iteration's draws (published by the barriers that follow)
-        if (sliced && it + 1 < ps.I && next_filled < n_draw) {
-          const int cnt = min(slice, n_draw - next_filled);
-          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext + next_filled, cnt);
-          next_filled += cnt;
-        } else if (overlapped && !ps.light && it + 1 < ps.I && next_filled == 0 && hi_g == P && hi_g - lo <= rng_w) {
-          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext, n_draw);  // (rng_w had no item in this round)
+      int slot = (int)(grp % 3u), hi_g = P;
+      if constexpr (kStream) {
+        // ---- a phase: every particle not yet committed, dealt by ticket (eval_stream) ----
+        // (ticket / jmax were set by thread 0 at the top of this trip; jstar[slot] = P and near_cnt[slot] = 0 two phases ago)
+        if (!proposed_now) __syncthreads();  // (the proposal step's barrier publishes them otherwise)
+        const double gbc_phase = sh->gbc;
+        // the wave that replays glibc's generator draws the next iteration's numbers first, then joins the others: that is
+        // about one item's time (3.4 us for 70 particles), and the ticket counter gives it one item less for it
+        if (overlapped && it + 1 < ps.I && next_filled < n_draw) {
+          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext + next_filled, n_draw - next_filled);
           next_filled = n_draw;
         }
-      }
-      n_evals += (uint32_t)(hi_g - lo);
-      n_rounds += 1;
-      NDTPSO_PB(5);
-      __syncthreads();
-      NDTPSO_PSO_MARK(2);
-      NDTPSO_PB(6);
-      if (CLUSTER && sh->timed_out) {
-        if (tid == 0 && stats && writer) stats->status |= kStatusClusterTimeout;
-        return false;
-      }
-      if (MODE == kScoreF32 && sh->tiny) {
-        if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
-        return false;
-      }
-      if constexpr (ARB) {
-        {
-          const int cnt = sh->near_cnt[slot];  // uniform: written before the barrier above
-          if (__builtin_expect(cnt != 0, 0)) {  // cold, see above
-#ifdef NDTPSO_PROFILE_ARB
-            const unsigned long long arb_t0 = wall_clock64();
-#endif
+        NDTPSO_PB(5);
+        eval_stream<MODE, PATH, ARB, NOCLIP>(E, pts, n, sw, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny,
+                                             &sh->near_cnt[slot], sh->near_list[slot]);
+        NDTPSO_PB(4);
+        __syncthreads();
+        NDTPSO_PSO_MARK(2);
+        NDTPSO_PB(6);
+        if (MODE == kScoreF32 && sh->tiny) {
+          if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+          return false;
+        }
+        n_evals += (uint32_t)(sh->jmax - lo + 1);
+        n_rounds += 1;
+        // items [lo, hi_g) are what the phase has established: everything up to the first improver (all of them evaluated,
+        // see eval_stream); behind it lie items evaluated for nothing, or not at all
+        hi_g = min(sh->jstar[slot], P - 1) + 1;
+        if constexpr (ARB) {
+          // near_cnt[slot] != 0: some evaluated item lies within the margin of its pbest's or the gbest's cost (the
+          // evaluating waves only raise the flag: which items they were is read off the stored costs, in [lo, hi_g), so
+          // that the list does not depend on who evaluated what when)
+          if (__builtin_expect(sh->near_cnt[slot] != 0, 0)) {  // cold
+            __syncthreads();  // (everybody has read the flag)
+            if (tid == 0) sh->near_cnt[slot] = 0;
+            __syncthreads();
+            {
+              const double gbc0 = sh->gbc, tau = arb_margin(gbc0, n);
+              for (int j = lo + tid; j < hi_g; j += blockDim.x) {
+                const double cj = sw.tcost[j], pj = sw.pbc[j];
+                if (near_tie(cj, pj, tau) || near_tie(cj, gbc0, tau)) near_note(&sh->near_cnt[slot], sh->near_list[slot], j);
+              }
+            }
+            __syncthreads();
+            const int cnt = sh->near_cnt[slot];
             if (__builtin_expect(cnt > kMaxNear, 0)) {  // (a converged swarm: nearly every comparison is a near-tie)
               if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
               return false;
             }
-            // fp64 scores of the undecidable items' proposals and pbest positions and of the gbest position replace
-            // the stored costs; the group's first improver is then looked for again (core.cpp:94-104, nested tests)
-            exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[slot], cnt, 1);
-            if (tid == 0) {
-              if (sh->xa.gb_task) sh->gbc = sh->xgbc;  // (else it is the fp64 score of the gbest position already)
-              int first = P;
-              for (int j = lo; j < hi_g; ++j) {
-                const double cj = sw.tcost[j];
-                if (cj < sh->gbc && cj < sw.pbc[j]) {
-                  first = j;
-                  break;
+            if (cnt != 0) {
+              exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[slot], cnt, 1);
+              if (tid == 0) {
+                if (sh->xa.gb_task) sh->gbc = sh->xgbc;  // (else it is the fp64 score of the gbest position already)
+                int first = P;
+                for (int j = lo; j < hi_g; ++j) {
+                  const double cj = sw.tcost[j];
+                  if (cj < sh->gbc && cj < sw.pbc[j]) {
+                    first = j;
+                    break;
+                  }
                 }
+                sh->jstar[slot] = first;  // P: no improver among the established items -- the phase goes on behind them
               }
-              sh->jstar[slot] = first;
+              __syncthreads();
+              n_arb += (uint32_t)cnt;
             }
-            __syncthreads();
-            n_arb += (uint32_t)cnt;
-#ifdef NDTPSO_PROFILE_ARB
-            n_rounds += 1000000u * 0u;
-            arb_ticks += (uint32_t)(wall_clock64() - arb_t0);
+          }
+        }
+      } else {
+#if NDTPSO_ALTERNATE_PRIO
+        // Two workgroups share a CU.  VALU issue is arbitrated by priority, then age, so the earlier-dispatched
+        // partner otherwise starves the other, finishes ~25 % early and leaves the CU half empty (measured with
+        // per-workgroup timestamps: residency 0.84 -> 0.95, +6 % throughput with this).  The partners (blocks b and
+        // b + grid/2 by dispatch order -- an assumption that only affects speed) take turns holding the higher
+        // priority; the turn comes from the shared 100 MHz real-time counter (5 us slices), so the two are
+        // complementary at all times, and the later-dispatched one gets 9 of 16 slices, which is what equalises
+        // their finishing times.
+        if constexpr (!CLUSTER) {
+          if ((((unsigned)(wall_clock64() >> 9) & 15u) < (unsigned)NDTPSO_PRIO_SHARE) == (blockIdx.x >= (gridDim.x >> 1)))
+            __builtin_amdgcn_s_setprio(1);
+          else
+            __builtin_amdgcn_s_setprio(0);
+        }
 #endif
+        slot = (int)(grp % 3u);
+        hi_g = min(lo + ps.G, P);
+        // a cluster draws the next iteration's numbers behind the first exchange of this one (eval_round)
+        const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
+        eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
+                                        &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
+                                        dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
+        if (gen_here) next_filled = n_draw;
+        NDTPSO_PB(4);
+        if constexpr (!CLUSTER) {
+          // the light wave's other job: a slice of the next iteration's draws (published by the barriers that follow)
+          if (sliced && it + 1 < ps.I && next_filled < n_draw) {
+            const int cnt = min(slice, n_draw - next_filled);
+            if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext + next_filled, cnt);
+            next_filled += cnt;
+          } else if (overlapped && !ps.light && it + 1 < ps.I && next_filled == 0 && hi_g == P && hi_g - lo <= rng_w) {
+            if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext, n_draw);  // (rng_w had no item in this round)
+            next_filled = n_draw;
+          }
+        }
+        n_evals += (uint32_t)(hi_g - lo);
+        n_rounds += 1;
+        NDTPSO_PB(5);
+        __syncthreads();
+        NDTPSO_PSO_MARK(2);
+        NDTPSO_PB(6);
+        if (CLUSTER && sh->timed_out) {
+          if (tid == 0 && stats && writer) stats->status |= kStatusClusterTimeout;
+          return false;
+        }
+        if (MODE == kScoreF32 && sh->tiny) {
+          if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+          return false;
+        }
+        if constexpr (ARB) {
+          {
+            const int cnt = sh->near_cnt[slot];  // uniform: written before the barrier above
+            if (__builtin_expect(cnt != 0, 0)) {  // cold, see above
+#ifdef NDTPSO_PROFILE_ARB
+              const unsigned long long arb_t0 = wall_clock64();
+#endif
+              if (__builtin_expect(cnt > kMaxNear, 0)) {  // (a converged swarm: nearly every comparison is a near-tie)
+                if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+                return false;
+              }
+              // fp64 scores of the undecidable items' proposals and pbest positions and of the gbest position replace
+              // the stored costs; the group's first improver is then looked for again (core.cpp:94-104, nested tests)
+              exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[slot], cnt, 1);
+              if (tid == 0) {
+                if (sh->xa.gb_task) sh->gbc = sh->xgbc;  // (else it is the fp64 score of the gbest position already)
+                int first = P;
+                for (int j = lo; j < hi_g; ++j) {
+                  const double cj = sw.tcost[j];
+                  if (cj < sh->gbc && cj < sw.pbc[j]) {
+                    first = j;
+                    break;
+                  }
+                }
+                sh->jstar[slot] = first;
+              }
+              __syncthreads();
+              n_arb += (uint32_t)cnt;
+#ifdef NDTPSO_PROFILE_ARB
+              n_rounds += 1000000u * 0u;
+              arb_ticks += (uint32_t)(wall_clock64() - arb_t0);
+#endif
+            }
           }
         }
       }
@@ -2656,7 +2828,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         sh->near_cnt[(grp + 2u) % 3u] = 0;
       }
       ++grp;
-      const int last = (js < P) ? js : (hi_g - 1);
+      const int last = (js < hi_g) ? js : (hi_g - 1);  // (js >= hi_g: P, no improver)
       // exact mode: items of this round whose costs the arbitration replaced by fp64 scores (what a pbest / the gbest
       // that takes such a cost over inherits: Swarm::pex, ExactArgs::gex)
       [[maybe_unused]] const int arb_cnt = ARB ? sh->near_cnt[slot] : 0;
@@ -2720,7 +2892,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         lo = js + 1;
         need_propose = true;
       } else {
-        lo = hi_g;
+        lo = hi_g;  // (a phase whose arbitration found no improver among the established items goes on behind them)
       }
       NDTPSO_PSO_MARK(3);
       NDTPSO_PB(8);

@@ -70,16 +70,29 @@ int refh_cells(const float* ranges, uint32_t n, float amin, float ainc, float rm
     if (c.built) {
       mean[2 * k] = c.mean.x();
       mean[2 * k + 1] = c.mean.y();
-      // q(d) = d' S d; steps of a fifth of the cell keep q of order one for the covariances a cell can hold
-      const double h = cell_side / 5.;
+      // q(d) = d' S d = -2 ln normalDistribution(mean + d).  Per axis the step is shrunk (or grown) until q is of order
+      // one -- a thin cell's S reaches 1e6 / m^2, exp(-q/2) would underflow with a fixed step --, and d is what the
+      // library itself will subtract: (mean + h) - mean, not h.
       auto q = [&](double dx, double dy) {
         Vector2d p(c.mean.x() + dx, c.mean.y() + dy);
         return -2. * std::log(c.normalDistribution(p));
       };
-      const double qx = q(h, 0.), qy = q(0., h), qxy = q(h, h);
-      icov3[3 * k] = qx / (h * h);
-      icov3[3 * k + 2] = qy / (h * h);
-      icov3[3 * k + 1] = (qxy - qx - qy) / (h * h);
+      auto axis_step = [&](bool along_x) {
+        double h = cell_side / 5.;
+        for (int it = 0; it < 60; ++it) {
+          const double v = along_x ? q(h, 0.) : q(0., h);
+          if (!(v < 8.)) h /= 4.;
+          else if (v < 0.25 && h < 64. * cell_side) h *= 2.;
+          else break;
+        }
+        return h;
+      };
+      const double hx = axis_step(true), hy = axis_step(false);
+      const double dx = (c.mean.x() + hx) - c.mean.x(), dy = (c.mean.y() + hy) - c.mean.y();
+      const double qx = q(hx, 0.), qy = q(0., hy), qxy = q(hx, hy);
+      icov3[3 * k] = qx / (dx * dx);
+      icov3[3 * k + 2] = qy / (dy * dy);
+      icov3[3 * k + 1] = (qxy - qx - qy) / (dx * dy);
     }
     ++k;
   }

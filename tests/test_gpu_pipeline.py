@@ -50,7 +50,7 @@ def test_two_batches_in_flight_equal_one_at_a_time(mode_name):
     piped = run(2)
     for (p1, c1, s1), (p2, c2, s2) in zip(serial, piped):
         assert np.array_equal(p1, p2) and np.array_equal(c1, c2)
-        assert np.array_equal(s1["status"], s2["status"]) and np.array_equal(s1["cost_evals"], s2["cost_evals"])
+        assert np.array_equal(s1["status"], s2["status"]) and np.array_equal(s1["gbest_updates"], s2["gbest_updates"])
         assert (s2["status"] & 0xffff == 0).all()
     ctx.set_pipeline_depth(1)
     ctx.close()
@@ -119,6 +119,6 @@ def test_host_buffer_batches_at_depth_two_equal_depth_one():
     for (p1, c1, s1), (p2, c2, s2) in zip(serial, piped):
         assert np.isfinite(p2).all() and (c2 < 0).all()          # not the memset's zeros
         assert np.array_equal(p1, p2) and np.array_equal(c1, c2)
-        assert np.array_equal(s1["status"], s2["status"]) and np.array_equal(s1["cost_evals"], s2["cost_evals"])
+        assert np.array_equal(s1["status"], s2["status"]) and np.array_equal(s1["gbest_updates"], s2["gbest_updates"])
     ctx.set_pipeline_depth(1)
     ctx.close()

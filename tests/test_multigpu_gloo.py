@@ -221,7 +221,7 @@ def test_sharded_entry_point_equals_align_pairs(ctx, n_pairs):
         for _ in range(2):   # a group is reusable
             got, cost, st = g.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
             assert np.array_equal(got, want) and np.array_equal(cost, wcost)
-            assert np.array_equal(st["status"], wst["status"]) and np.array_equal(st["cost_evals"], wst["cost_evals"])
+            assert np.array_equal(st["status"], wst["status"]) and np.array_equal(st["gbest_updates"], wst["gbest_updates"])
         g.close()
 
 
@@ -253,7 +253,7 @@ def test_sharded_resident_flavour_and_timing(ctx):
             ptrs[k].append(t[k].data_ptr())
         torch.cuda.synchronize(td)
     got, cost, st = g.align_pairs_dev(B, ptrs["ref"], ptrs["new"], geom, grid, ptrs["guess"], ptrs["dev"], cfg, d_seeds=ptrs["seeds"])
-    assert np.array_equal(got, want) and np.array_equal(cost, wcost) and np.array_equal(st["cost_evals"], wst["cost_evals"])
+    assert np.array_equal(got, want) and np.array_equal(cost, wcost) and np.array_equal(st["gbest_updates"], wst["gbest_updates"])
     per, call = g.last_timing()
     assert per.shape == (G, 3) and (per[:, 1] == 0).all() and (per[:, 2] > 0).all()      # nothing uploaded, something launched
     assert 0 < call[0] <= call[2] and call[1] > 0
