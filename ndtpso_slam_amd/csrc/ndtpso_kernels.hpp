@@ -2173,9 +2173,11 @@ template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false>
 __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int P, double gbc,
                                    int* ticket, int* spare, int* improver, int* jmax, int* tiny, int* near_cnt,
                                    unsigned short* near_list) {
+  typedef int __attribute__((address_space(3))) * lds_int_t;
   int last_done = -1;
   for (;;) {
-    const int seen = *(volatile int*)improver;  // (in flight together with the ticket)
+    // (an LDS read in flight together with the ticket; through a generic pointer it was a flat load with system scope)
+    const int seen = __hip_atomic_load((lds_int_t)improver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     const int j = take_ticket(ticket, spare);
     if (j >= P || j > seen) break;
 #if NDTPSO_ALTERNATE_PRIO
@@ -2220,14 +2222,15 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
         }
       }
       if (ordinary && cost < gbc)
-        if (cost < pbc_j) atomicMin(improver, j);
+        if (cost < pbc_j) __hip_atomic_fetch_min((lds_int_t)improver, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if constexpr (ARB) {
         const double tau = arb_margin(gbc, n);
-        if (near_tie(cost, pbc_j, tau) || near_tie(cost, gbc, tau)) near_note(near_cnt, near_list, j);
+        // (a flag is all the phase needs: pso_run_wg reads the list off the stored costs)
+        if (near_tie(cost, pbc_j, tau) || near_tie(cost, gbc, tau)) *(lds_int_t)near_cnt = 1;
       }
     }
   }
-  if (lane_id() == 0 && last_done >= 0) atomicMax(jmax, last_done);
+  if (lane_id() == 0 && last_done >= 0) __hip_atomic_fetch_max((lds_int_t)jmax, last_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // ---- one alignment on several compute units ("cluster") --------------------------------------------------------
@@ -2627,11 +2630,13 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     bool need_propose = true;
     while (lo < P) {
       [[maybe_unused]] const bool proposed_now = need_propose;
+#if NDTPSO_STREAM
       if constexpr (kStream)
         if (tid == 0) {  // the phase's ticket counter (published by the barrier that follows)
           sh->ticket = lo;
           sh->jmax = lo - 1;
         }
+#endif
       if (need_propose) {
         // core.cpp:83-90 for every particle not yet committed, against the current gbest
         // one thread per (particle, coordinate): the three coordinates of a particle are independent (core.cpp:83-90),
@@ -2668,6 +2673,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         NDTPSO_PB(3);
       }
       int slot = (int)(grp % 3u), hi_g = P;
+#if NDTPSO_STREAM
       if constexpr (kStream) {
         // ---- a phase: every particle not yet committed, dealt by ticket (eval_stream) ----
         // (ticket / jmax were set by thread 0 at the top of this trip; jstar[slot] = P and near_cnt[slot] = 0 two phases ago)
@@ -2720,22 +2726,25 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
               exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[slot], cnt, 1);
               if (tid == 0) {
                 if (sh->xa.gb_task) sh->gbc = sh->xgbc;  // (else it is the fp64 score of the gbest position already)
-                int first = P;
-                for (int j = lo; j < hi_g; ++j) {
+                sh->jstar[slot] = P;  // (stays P: no improver among the established items -- the phase goes on behind them)
+              }
+              __syncthreads();
+              {  // the first improver again, by every thread (a phase of a 2048-particle swarm kept in HBM is 2048 items:
+                 // one thread walking them cost 180 us per arbitration, 10 ms of a config-5 alignment)
+                const double gbc1 = sh->gbc;
+                for (int j = lo + tid; j < hi_g; j += blockDim.x) {
                   const double cj = sw.tcost[j];
-                  if (cj < sh->gbc && cj < sw.pbc[j]) {
-                    first = j;
-                    break;
-                  }
+                  if (cj < gbc1 && cj < sw.pbc[j]) atomicMin(&sh->jstar[slot], j);
                 }
-                sh->jstar[slot] = first;  // P: no improver among the established items -- the phase goes on behind them
               }
               __syncthreads();
               n_arb += (uint32_t)cnt;
             }
           }
         }
-      } else {
+      } else
+#endif
+      {
 #if NDTPSO_ALTERNATE_PRIO
         // Two workgroups share a CU.  VALU issue is arbitrated by priority, then age, so the earlier-dispatched
         // partner otherwise starves the other, finishes ~25 % early and leaves the CU half empty (measured with

@@ -22,6 +22,7 @@ import pytest
 from conftest import DEVIATION, FRAME_M
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 P, I, CS = 70, 70, 0.5
 F32_POSE_TOL = 5e-3   # plain fp32 score mode vs the oracle, worst pair (a flipped near-tie: another PSO trajectory)
@@ -180,3 +181,44 @@ def test_batches_of_large_swarms_kept_in_hbm(ctx, oracle, B, Pn, In, beams, cs):
     assert np.abs(p64[:n_o] - want).max() < 1e-9 and np.abs(c64[:n_o] - want_cost).max() < 1e-8
     assert (s64["status"] == 0).all() and (sx["status"] == 0).all()
     assert np.array_equal(px, p64) and np.array_equal(cx, c64)
+
+
+_UNITS_SCRIPT = r"""
+import sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+from ndtpso_slam_amd import capi, synth
+out = []
+ctx = capi.Context(0)
+for (B, Pn, In, beams, cs) in [(130, 1024, 12, 1081, 0.5), (140, 2048, 5, 2048, 0.25)]:
+    p = synth.make_pairs(B, n_beams=beams, seed=300 + In)
+    geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+    args = (p.ref_ranges, p.new_ranges, geom, capi.Grid(60, 60, cs), (0, 0, 0), (0.1, 0.1, 3.1415e-3), capi.PSOConfig.make(In, Pn))
+    p64, c64, s64 = ctx.align_pairs(*args, seeds=p.seeds, mode=capi.SCORE_F64)
+    px, cx, sx = ctx.align_pairs(*args, seeds=p.seeds, mode=capi.SCORE_EXACT)
+    out.append(dict(equal=int((px == p64).all(axis=1).sum()), pairs=B, costs_equal=bool(np.array_equal(cx, c64)),
+                    arbitrated=float(sx["arbitrated"].mean()), flagged=int((sx["status"] != 0).sum())))
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("waves", ["", "8"])
+def test_unit_form_on_swarms_kept_in_hbm(waves):
+    """The arbitration's unit form (fp64 scores split into accumulator units across the waves) on the kernels that keep the
+    swarm in HBM.  They ship with whole tasks per wave: round 3 saw the unit form return wrong poses there (24 of 130
+    pairs in that binary, on any workgroup size, while every build of the round-4 sources passes; NOTEBOOK).  This test
+    switches the units on (NDTPSO_UNITS_HBM, read once per process, hence the subprocess) and holds them to the fp64
+    mode bit for bit, so that a build in which they go wrong again is seen -- the same check the full-size tests apply to
+    the LDS-swarm kernels' unit form, which shares the code."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, NDTPSO_UNITS_HBM="16")
+    if waves:
+        env["NDTPSO_WAVES"] = waves
+    r = subprocess.run([sys.executable, "-c", _UNITS_SCRIPT % {"root": ROOT}], env=env, capture_output=True, text=True, timeout=500)
+    assert r.returncode == 0, r.stdout + r.stderr
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    for d in res:
+        assert d["equal"] == d["pairs"] and d["costs_equal"] and d["flagged"] == 0, res
+    assert res[0]["arbitrated"] > 0 and res[1]["arbitrated"] > 0, res     # (a pass that arbitrated nothing proves nothing)

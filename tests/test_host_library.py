@@ -452,8 +452,10 @@ def run_host_operation_sequence(oracle, workdir, seed, frame_w, frame_h, cs, ogc
     n_aligns = n_exact32 = 0
     for resident in ("1", "0"):
         for score in ("f64", "f32", "exact"):
-            out = subprocess.check_output([os.path.join(HOST, "replay", "frame_fuzz"), path], text=True,
-                                          env=dict(os.environ, NDTPSO_RESIDENT=resident, NDTPSO_SCORE=score))
+            r = subprocess.run([os.path.join(HOST, "replay", "frame_fuzz"), path], text=True, capture_output=True,
+                               env=dict(os.environ, NDTPSO_RESIDENT=resident, NDTPSO_SCORE=score))
+            assert r.returncode == 0, (seed, resident, score, r.returncode, r.stderr[-2000:], r.stdout[-500:])
+            out = r.stdout
             lines = [l.split() for l in out.splitlines()]
             assert len(lines) == len(expect), (resident, score, len(lines), len(expect))
             for k, (got, want) in enumerate(zip(lines, expect)):
