@@ -429,7 +429,7 @@ def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms,
     v_exp_f32 is charged as ONE fp32 flop although it issues at a quarter of the fp32 rate (frac_exp_at_quarter_rate
     charges it 4).  `floor` keeps round 2's instruction-level figure: the issue time of the score loop's actual
     instruction mix (scripts/isa_mix.py x scripts/ubench_valu.hip) -- useful for tuning, not a roofline."""
-    mix_name = "r03_isa_mix.json" if _load_json("r03_isa_mix.json") else "r02_isa_mix.json"
+    mix_name = "r04_isa_mix.json" if _load_json("r04_isa_mix.json") else "r02_isa_mix.json"
     mix = _load_json(mix_name)
     point_evals = float(stats["n_points"].astype(np.float64).sum()) * evals_nominal
     flops = point_evals * (FLOP_FP64 + FLOP_FP32 + FLOP_EXP)

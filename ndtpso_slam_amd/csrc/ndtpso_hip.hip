@@ -23,7 +23,7 @@ static_assert(sizeof(AlignStats) == sizeof(ndtpso_align_stats), "stats ABI");
 namespace {
 
 constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
-constexpr int kCtrlBytes = 1120;     // control block (PsoShared + compaction counters)
+constexpr int kCtrlBytes = 1440;     // control block (PsoShared + compaction counters)
 
 // LDS layout shared by every kernel.
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
@@ -2188,6 +2188,21 @@ int ndtpso_profile_verify_margin(double* out, uint32_t n_blocks, int reset) {
   if (reset) {
     void* p = nullptr;
     if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_verify)) != hipSuccess || hipMemset(p, 0, sizeof(double) * 16 * kVerifyMaxBlocks) != hipSuccess)
+      return NDTPSO_E_HIP;
+  }
+  return NDTPSO_OK;
+}
+#endif
+
+#ifdef NDTPSO_TRACE_ARB
+// diagnostic builds only (scripts/units_hbm_diag.py): the arbitration trace of the first n_blocks workgroups; reset: clear it
+int ndtpso_profile_arb_trace(double* out, uint32_t n_blocks, int reset) {
+  if (n_blocks > kTraceBlocks) return NDTPSO_E_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return NDTPSO_E_HIP;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_arbtrace), (size_t)n_blocks * kTraceDoubles * sizeof(double)) != hipSuccess) return NDTPSO_E_HIP;
+  if (reset) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_arbtrace)) != hipSuccess || hipMemset(p, 0, sizeof(double) * kTraceDoubles * kTraceBlocks) != hipSuccess)
       return NDTPSO_E_HIP;
   }
   return NDTPSO_OK;

@@ -1291,8 +1291,13 @@ __device__ inline void dense_from_image_wg(const GridP& g, const WinP& wn, const
 // lane stores is what another lane of the same wave loads afterwards; the wave barriers between steps keep the compiler
 // from moving accesses across them.  (The ring used to be `volatile`, which serialised the eleven loads of a step:
 // 8 us per PSO iteration with only this wave running -- a fifth of a workgroup's time; now about 1 us.)
+// History of glibc's additive generator r[i] = r[i-31] + r[i-3] (mod 2^32), as a ring of 64 words kept TWICE (word i at
+// [i & 63] and at [(i & 63) + 64]): every word a step reads then lies at a fixed distance below (i & 63) + 64, so the
+// step's eleven loads are one address and eleven immediate offsets (with a single ring each of them cost an add, a mask
+// and a shift of its own: 33 of a step's 55 vector instructions, and the generator was a ninth of everything a
+// 70-particle alignment issues outside its score loop).
 struct RngState {
-  uint32_t hist[64];
+  uint32_t hist[128];
 };
 
 __device__ inline void rng_seed_wave0(RngState* st, uint32_t seed) {
@@ -1308,6 +1313,7 @@ __device__ inline void rng_seed_wave0(RngState* st, uint32_t seed) {
     }
     for (int i = 31; i < 34; ++i) st->hist[i] = st->hist[i - 31];
     for (int i = 34; i < 64; ++i) st->hist[i] = st->hist[i - 31] + st->hist[i - 3];
+    for (int i = 0; i < 64; ++i) st->hist[i + 64] = st->hist[i];
   }
 }
 
@@ -1316,18 +1322,21 @@ __device__ inline uint32_t rng_step_wave0(RngState* st, int t, int cnt) {
   const int lane = lane_id();
   uint32_t v = 0;
   __builtin_amdgcn_wave_barrier();
+  const uint32_t* h = st->hist + ((t + lane) & 63) + 64;  // word i of the upper copy: i - 61 .. i - 30 lie below it in one piece
   if (lane < cnt) {
-    const int i = t + lane;
-    uint32_t h[11];
-    h[0] = st->hist[(i - 30) & 63];
+    uint32_t w[11];
+    w[0] = h[-30];
 #pragma unroll
-    for (int m = 0; m < 10; ++m) h[m + 1] = st->hist[(i - 31 - 3 * m) & 63];  // eleven independent loads in flight
-    v = h[0];
+    for (int m = 0; m < 10; ++m) w[m + 1] = h[-31 - 3 * m];  // eleven independent loads in flight
+    v = w[0];
 #pragma unroll
-    for (int m = 0; m < 10; ++m) v += h[m + 1];  // same order of additions (mod 2^32: any order gives the same sum)
+    for (int m = 0; m < 10; ++m) v += w[m + 1];  // (mod 2^32: any order gives the same sum)
   }
   __builtin_amdgcn_wave_barrier();
-  if (lane < cnt) st->hist[(t + lane) & 63] = v;
+  if (lane < cnt) {
+    const_cast<uint32_t*>(h)[0] = v;
+    const_cast<uint32_t*>(h)[-64] = v;
+  }
   __builtin_amdgcn_wave_barrier();
   return v;
 }
@@ -1485,6 +1494,12 @@ struct PsoShared {  // small control block in LDS
   double xgbc;  // fp64 score of the gbest position (arbitration scratch)
   double gcs[2];  // cos, sin of the gbest position's heading
   DenseGuard guard;  // (fused pairs kernel, dense form)
+  // What the proposal step needs besides the swarm: kept HERE, not in registers.  As kernel arguments and loop-carried
+  // values they were seven register pairs live through the whole PSO; the arbitrating kernel had no room for them beside
+  // its calls, spilled them, and every proposal step -- where one wave works and seven wait -- began with a round trip to
+  // scratch memory (proposals 145 us per alignment against 105 us in the plain fp32 kernel, profiles/r04_phase_budget*).
+  double k_w, k_c1, k_c2;             // inertia weight of the current iteration (core.cpp:108), c1, c2
+  double k_hw, k_hh, k_inv, k_ox, k_oy;  // dense form: the fold of a position into a DenseItem (dense_item)
   ExactArgs xa;
 };
 
@@ -1896,6 +1911,24 @@ __device__ __forceinline__ double exact_partial(const ExactArgs* ap, double c, d
   return a;
 }
 
+#ifdef NDTPSO_TRACE_ARB  // diagnostic builds (scripts/units_hbm_diag.py): what every arbitration decided, per workgroup
+constexpr unsigned kTraceBlocks = 256, kTraceDoubles = 2048;
+__device__ double g_arbtrace[kTraceBlocks * kTraceDoubles];
+__device__ __forceinline__ void arb_trace(double v) {  // thread 0 only
+  if (blockIdx.x < kTraceBlocks) {
+    double* t = g_arbtrace + (size_t)blockIdx.x * kTraceDoubles;
+    const unsigned n = (unsigned)t[0];
+    if (n + 2 < kTraceDoubles) {
+      t[n + 1] = v;
+      t[0] = (double)(n + 1);
+    }
+  }
+}
+#define NDTPSO_ARB_TRACE(v) arb_trace((double)(v))
+#else
+#define NDTPSO_ARB_TRACE(v) do { } while (0)
+#endif
+
 #ifndef NDTPSO_EXACT_CALL
 #define NDTPSO_EXACT_CALL 1
 #endif
@@ -2044,6 +2077,18 @@ __device__ __forceinline__ void exact_tasks_wg(ExactArgs* ap, const unsigned sho
     for (int t = t0 + wave_id(); t < t1; t += n_waves) exact_combine(ap, t);
     __syncthreads();
   }
+#ifdef NDTPSO_TRACE_ARB
+  if (threadIdx.x == 0) {
+    NDTPSO_ARB_TRACE(-1000 - kind);
+    NDTPSO_ARB_TRACE(n_tasks);
+    for (int t = 0; t < n_tasks; ++t) {
+      const unsigned tk = ap->task[t];
+      const int j = (int)(tk >> 2), kd = (int)(tk & 3u);
+      NDTPSO_ARB_TRACE(tk);
+      NDTPSO_ARB_TRACE(kd == 2 ? *ap->xgbc : (kd == 1 ? ap->pbc[j] : ap->tcost[j]));
+    }
+  }
+#endif
   if (threadIdx.x == 0 && kind == 1) {  // what the scores just stored are from now on
     for (int q = 0; q < cnt; ++q) ap->pex[list[q]] = 1;
     ap->gex = 1;
@@ -2175,6 +2220,9 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
                                    unsigned short* near_list) {
   typedef int __attribute__((address_space(3))) * lds_int_t;
   int last_done = -1;
+#if NDTPSO_ALTERNATE_PRIO
+  const unsigned late = __builtin_amdgcn_readfirstlane(blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u);
+#endif
   for (;;) {
     // (an LDS read in flight together with the ticket; through a generic pointer it was a flat load with system scope)
     const int seen = __hip_atomic_load((lds_int_t)improver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -2182,7 +2230,8 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
     if (j >= P || j > seen) break;
 #if NDTPSO_ALTERNATE_PRIO
     // the two workgroups of a compute unit take turns holding the higher priority (see pso_run_wg)
-    if ((((unsigned)(wall_clock64() >> 9) & 15u) < (unsigned)NDTPSO_PRIO_SHARE) == (blockIdx.x >= (gridDim.x >> 1)))
+    // (all of it on the scalar unit: as a comparison of two booleans it was a 64-bit vector compare and two selects per item)
+    if (((((unsigned)wall_clock64() >> 9) & 15u) < (unsigned)NDTPSO_PRIO_SHARE ? 1u : 0u) == late)
       __builtin_amdgcn_s_setprio(1);
     else
       __builtin_amdgcn_s_setprio(0);
@@ -2413,7 +2462,17 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 
   NDTPSO_PB_DECL;
   // ---- swarm initialisation: core.cpp:58-69 ----
-  if (tid == 0) sh->tiny = sh->timed_out = 0;
+  if (tid == 0) {
+    sh->tiny = sh->timed_out = 0;
+    sh->k_w = ps.w;
+    sh->k_c1 = ps.c1;
+    sh->k_c2 = ps.c2;
+    sh->k_hw = E.g.hw;
+    sh->k_hh = E.g.hh;
+    sh->k_inv = E.g.inv_cs;
+    sh->k_ox = (double)E.dn.ox;
+    sh->k_oy = (double)E.dn.oy;
+  }
   if constexpr (ARB) {
     // exact mode: the rest of exact_tasks' parameter block (the kernel has stored the grid, the window and the table
     // views of the fp64 image into sh->xa already)
@@ -2463,10 +2522,11 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         sw.pcs[S + slot] = sn;
       }
       if constexpr (path_is_dense(PATH) && !CLUSTER) {  // DenseItem of this pose (dense_item), kept with it
-        sw.tc[slot] = cn * E.g.inv_cs;
-        sw.ts[slot] = sn * E.g.inv_cs;
-        sw.ttx[slot] = (sw.tpos[slot] + E.g.hw) * E.g.inv_cs - (double)E.dn.ox;
-        sw.tty[slot] = (sw.tpos[S + slot] + E.g.hh) * E.g.inv_cs - (double)E.dn.oy;
+        const double inv = sh->k_inv;
+        sw.tc[slot] = cn * inv;
+        sw.ts[slot] = sn * inv;
+        sw.ttx[slot] = (sw.tpos[slot] + sh->k_hw) * inv - sh->k_ox;
+        sw.tty[slot] = (sw.tpos[S + slot] + sh->k_hh) * inv - sh->k_oy;
       } else {
         sw.tc[slot] = cn;
         sw.ts[slot] = sn;
@@ -2546,7 +2606,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   __syncthreads();
 
   // ---- iterations: core.cpp:78-109 ----
-  double w = ps.w;
   unsigned grp = 0;
   if (tid == 0) {
     sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
@@ -2556,7 +2615,9 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // the loads are issued at the top of iteration it - 1, sit in two registers per thread while it runs, and land in the
   // LDS buffer the device generator would otherwise fill -- so the proposal step, where most waves wait for one or
   // two, starts from LDS instead of paying an HBM round trip every time
-  const bool prefetch = !gen && ps.I > 0 && 6 * P <= 2 * (int)blockDim.x;
+  // (a cluster's kernels only -- the live node's: two more registers live through every iteration are two more spilled
+  // in the batch kernels)
+  const bool prefetch = CLUSTER && !gen && ps.I > 0 && 6 * P <= 2 * (int)blockDim.x;
   int32_t pre0 = 0, pre1 = 0;
   if (prefetch) {
     const int32_t* first = table + 3 * S;
@@ -2584,8 +2645,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // iteration's last round when that round has fewer items than the workgroup has waves (70 particles in rounds of 16:
   // 6 items for 8 waves; that alone took config 3 from 212 to 219 k align/s).  What is still missing when the
   // iteration ends is drawn then.  (A cluster draws at the start of the iteration.)
-  int32_t* dcur = sw.raw;
-  int32_t* dnext = sw.raw2;
   int next_filled = 0;  // draws of the next iteration already in dnext (the same in every thread)
   const bool overlapped = gen && sw.raw2 != nullptr, sliced = overlapped && !CLUSTER && ps.light;
   const int n_draw = 6 * P;
@@ -2594,15 +2653,17 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   for (int it = 0; it < ps.I; ++it) {
     NDTPSO_PSO_MARK(4);
     NDTPSO_PB(9);
+    // (the two draw buffers by the iteration's parity, not as a pair of pointers swapped every iteration: those lived in
+    // scratch memory in the arbitrating kernel)
+    const bool odd = overlapped && (it & 1);
+    int32_t* const dcur = odd ? sw.raw2 : sw.raw;
+    int32_t* const dnext = odd ? sw.raw : sw.raw2;
     if (gen) {
       if (overlapped && it > 0) {  // what the previous iteration's rounds left time for, and the rest now
         if (next_filled < n_draw) {
-          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dnext + next_filled, n_draw - next_filled);
+          if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dcur + next_filled, n_draw - next_filled);
           __syncthreads();
         }
-        int32_t* t = dcur;
-        dcur = dnext;
-        dnext = t;
         next_filled = 0;
       } else {
         if (wave_id() == rng_w) rng_fill_wave0(&sh->rng, &rng_t, dcur, n_draw);
@@ -2642,25 +2703,29 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         // one thread per (particle, coordinate): the three coordinates of a particle are independent (core.cpp:83-90),
         // and each costs two fp64 divisions (Eigen's Random()) -- a chain three times shorter than one thread per
         // particle; the heading lanes then take the sine and cosine
-        for (int q = 3 * lo + tid; q < 3 * P; q += blockDim.x) {
-          const int j = q / 3, k = q - 3 * j;
+        // (the headings first, then the x / y pairs: the sine and cosine -- two thirds of this step's instructions -- are
+        // then issued by the waves that hold heading lanes only, two of the four that 70 particles occupy, instead of by
+        // every wave because every third lane needed them)
+        const int n_prop = P - lo;
+        for (int q = tid; q < 3 * n_prop; q += blockDim.x) {
+          const int j = lo + (q < n_prop ? q : (q - n_prop) >> 1), k = q < n_prop ? 2 : ((q - n_prop) & 1);
           const double r1 = fabs(uniform_pm1(draws[6 * j + 2 * k]));
           const double r2 = fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
           const double p = sw.pos[k * S + j];
-          const double v = w * sw.vel[k * S + j] + ps.c1 * r1 * (sw.pb[k * S + j] - p) + ps.c2 * r2 * (sh->gb[k] - p);
+          const double v = sh->k_w * sw.vel[k * S + j] + sh->k_c1 * r1 * (sw.pb[k * S + j] - p) + sh->k_c2 * r2 * (sh->gb[k] - p);
           const double np = p + v;
           sw.tvel[k * S + j] = v;
           sw.tpos[k * S + j] = np;
           constexpr bool fold = path_is_dense(PATH) && !CLUSTER;
           if constexpr (fold) {  // each coordinate's share of the proposal's DenseItem (dense_item)
-            if (k == 0) sw.ttx[j] = (np + E.g.hw) * E.g.inv_cs - (double)E.dn.ox;
-            if (k == 1) sw.tty[j] = (np + E.g.hh) * E.g.inv_cs - (double)E.dn.oy;
+            if (k == 0) sw.ttx[j] = (np + sh->k_hw) * sh->k_inv - sh->k_ox;
+            if (k == 1) sw.tty[j] = (np + sh->k_hh) * sh->k_inv - sh->k_oy;
           }
           if (k == 2) {
             double sn, cn;
             sincos(np, &sn, &cn);
-            sw.tc[j] = fold ? cn * E.g.inv_cs : cn;
-            sw.ts[j] = fold ? sn * E.g.inv_cs : sn;
+            sw.tc[j] = fold ? cn * sh->k_inv : cn;
+            sw.ts[j] = fold ? sn * sh->k_inv : sn;
             if constexpr (ARB) {
               sw.pcs[j] = cn;
               sw.pcs[S + j] = sn;
@@ -2887,6 +2952,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         __syncthreads();
         if (tid == 0) {
           sh->gbc = sw.tcost[js];
+          NDTPSO_ARB_TRACE(-2000);
+          NDTPSO_ARB_TRACE(it);
+          NDTPSO_ARB_TRACE(js);
+          NDTPSO_ARB_TRACE(sh->gbc);
           for (int k = 0; k < 3; ++k) sh->gb[k] = sw.tpos[k * S + js];
           if constexpr (ARB) {
             sh->gcs[0] = sw.pcs[js];
@@ -2910,8 +2979,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       if (tid < 6 * P) sw.raw[tid] = pre0;
       if (tid + (int)blockDim.x < 6 * P) sw.raw[tid + blockDim.x] = pre1;
     }
+    if (tid == 0) sh->k_w *= ps.wdamp;  // core.cpp:108 (every proposal of this iteration has read it: barriers above)
     __syncthreads();  // all commits of this iteration done before the next draws/proposals
-    w *= ps.wdamp;  // core.cpp:108
   }
 
 #ifdef NDTPSO_PROFILE_PSO

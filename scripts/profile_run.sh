@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/ubench_valu.hip -o /tmp/ubench_valu 2>/dev/null && /tmp/ubench_valu > $OUT/ubench_valu.txt 2>&1
 python scripts/isa_mix.py --kernel "k_align_pairs<0, 3, false, true, true, 0>" --ubench $OUT/ubench_valu.txt --out $OUT/isa_mix.json --dump $OUT/score_loop_isa.txt > /dev/null
-cp $OUT/isa_mix.json profiles/r03_isa_mix.json   # the bench line's roofline.floor reads it
+cp $OUT/isa_mix.json profiles/r04_isa_mix.json   # the bench line's roofline.floor reads it
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --pipeline 1 --no-latency --cpu-sample 0 > $OUT/bench_one_at_a_time.json 2>> $OUT/bench.err
 # kernel traces (own runs): one batch at a time -- the per-launch duration the roofline divides by -- and two in flight
