@@ -23,7 +23,7 @@ static_assert(sizeof(AlignStats) == sizeof(ndtpso_align_stats), "stats ABI");
 namespace {
 
 constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
-constexpr int kCtrlBytes = 1440;     // control block (PsoShared + compaction counters)
+constexpr int kCtrlBytes = 1456;     // control block (PsoShared + compaction counters)
 
 // LDS layout shared by every kernel.
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
@@ -89,15 +89,13 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
   L.xs_off = -1;
   L.xs_slots = 0;
   // The fused pairs kernels with the swarm in LDS split the arbitration's fp64 scores into units; a single alignment's
-  // kernels and the kernels of swarms kept in HBM score whole tasks per wave.  Round 3 saw the unit form return wrong poses
-  // from the HBM-swarm kernels and put it down to 16-wave workgroups.  Round 4 (NOTEBOOK, "The unit form on swarms kept in
-  // HBM"): that binary fails the same way on 4-, 8-, 12- and 16-wave workgroups (NDTPSO_WAVES), deterministically, on 24
-  // of 130 pairs; the callee is byte-identical to the one in builds that pass, the caller differs in register assignment
-  // only, and every build of the round-4 sources -- rounds or phases, old or new LDS layout, 8 or 16 scratch slots --
-  // passes with the units switched on.  Not a property of the workgroup size, then, but of one compilation; the cause
-  // inside it was not found.  The HBM-swarm kernels therefore keep whole tasks (the arbitration is 1 % of their time), and
-  // tests/test_gpu_fullsize.py::test_unit_form_on_swarms_kept_in_hbm runs them WITH units (NDTPSO_UNITS_HBM=<slots>) against
-  // the fp64 mode in every build, as the 8-wave kernels' unit form is checked by the full-size tests.
+  // kernels and the kernels of swarms kept in HBM score whole tasks per wave (the arbitration is 1 % of their time).
+  // The unit form on the HBM-swarm kernels is what rounds 3 and 4 saw return wrong poses in some builds: not a matter of
+  // the workgroup size (round 3's reading) but of the callers' code around the two out-of-line scoring functions under
+  // interprocedural register allocation -- six builds made with it fail identically, the same sources without it pass
+  // (NOTEBOOK, "The unit form on swarms kept in HBM") -- and the library is built without IPRA since (build.py).
+  // tests/test_gpu_fullsize.py::test_unit_form_on_swarms_kept_in_hbm keeps running those kernels WITH units
+  // (NDTPSO_UNITS_HBM=<slots>, tests only) against the fp64 mode in every build.
   static const int units_hbm = [] {  // tests only: scratch slots of the unit form for swarms kept in HBM (0: whole tasks)
     const char* e = std::getenv("NDTPSO_UNITS_HBM");
     return e ? std::atoi(e) : 0;
