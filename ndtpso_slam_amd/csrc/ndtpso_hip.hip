@@ -23,7 +23,7 @@ static_assert(sizeof(AlignStats) == sizeof(ndtpso_align_stats), "stats ABI");
 namespace {
 
 constexpr int kMaxLds = 160 * 1024;  // gfx950: 160 KiB per workgroup
-constexpr int kCtrlBytes = 1456;     // control block (PsoShared + compaction counters)
+constexpr int kCtrlBytes = 1440;     // control block (PsoShared + compaction counters)
 
 // LDS layout shared by every kernel.
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]

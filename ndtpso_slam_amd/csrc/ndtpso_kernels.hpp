@@ -1390,8 +1390,7 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
   double* pos;    // [3][S] committed position
   double* vel;    // [3][S]
   double* pb;     // [3][S] best_position
-  double* pbc;    // [S]    best_cost: the copy the iterations with an even number start from,
-  double* pbc2;   // [S]    and the one the odd ones do (the first proposal step of an iteration fills the other: pso_run_wg)
+  double* pbc;    // [S]    best_cost
   double* tpos;   // [3][S] proposed position
   double* tvel;   // [3][S]
   double* tc;     // [S] cos(theta) of the proposal -- dense form: the folded transform constants C, S, TX, TY of the
@@ -1409,7 +1408,7 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
 // overlapped generator -- always with the swarm in its HBM workspace, in LDS only for swarms of up to 256 particles (a
 // 512-particle swarm with it no longer fits beside the dense table: 16 266 instead of 26 202 align/s, measured)
 __host__ __device__ inline bool swarm_has_raw2(int P, bool swarm_global) { return swarm_global || P <= 256; }
-__host__ __device__ inline int swarm_doubles(int P, bool exact) { return (exact ? 27 : 22) * (P + 1); }
+__host__ __device__ inline int swarm_doubles(int P, bool exact) { return (exact ? 26 : 21) * (P + 1); }
 __host__ __device__ inline int swarm_raw_ints(int P) { return (6 * P > 3 * (P + 1)) ? 6 * P : 3 * (P + 1); }
 __host__ __device__ inline int swarm_bytes(int P, bool exact, bool raw2) {
   return align16(swarm_doubles(P, exact) * 8) + align16(swarm_raw_ints(P) * 4) + (raw2 ? align16(6 * P * 4) : 0);
@@ -1430,10 +1429,9 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P, bool exact, bool
   sw.tcost = d + 18 * S;
   sw.ttx = d + 19 * S;
   sw.tty = d + 20 * S;
-  sw.pbc2 = d + 21 * S;
-  sw.pcs = exact ? d + 22 * S : nullptr;
-  sw.bcs = exact ? d + 24 * S : nullptr;
-  sw.pex = exact ? reinterpret_cast<unsigned char*>(d + 26 * S) : nullptr;  // (S bytes of an S-double slot)
+  sw.pcs = exact ? d + 21 * S : nullptr;
+  sw.bcs = exact ? d + 23 * S : nullptr;
+  sw.pex = exact ? reinterpret_cast<unsigned char*>(d + 25 * S) : nullptr;  // (S bytes of an S-double slot)
   sw.raw = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P, exact) * 8));
   sw.raw2 = raw2 ? reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P, exact) * 8) + align16(swarm_raw_ints(P) * 4)) : nullptr;
   return sw;
@@ -1500,7 +1498,7 @@ struct PsoShared {  // small control block in LDS
   // values they were seven register pairs live through the whole PSO; the arbitrating kernel had no room for them beside
   // its calls, spilled them, and every proposal step -- where one wave works and seven wait -- began with a round trip to
   // scratch memory (proposals 145 us per alignment against 105 us in the plain fp32 kernel, profiles/r04_phase_budget*).
-  double k_wv[2], k_c1, k_c2;         // inertia weight (core.cpp:108) of the even / the odd iterations, c1, c2
+  double k_w, k_c1, k_c2;             // inertia weight of the current iteration (core.cpp:108), c1, c2
   double k_hw, k_hh, k_inv, k_ox, k_oy;  // dense form: the fold of a position into a DenseItem (dense_item)
   ExactArgs xa;
 };
@@ -2466,7 +2464,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // ---- swarm initialisation: core.cpp:58-69 ----
   if (tid == 0) {
     sh->tiny = sh->timed_out = 0;
-    sh->k_wv[0] = ps.w;
+    sh->k_w = ps.w;
     sh->k_c1 = ps.c1;
     sh->k_c2 = ps.c2;
     sh->k_hw = E.g.hw;
@@ -2609,7 +2607,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 
   // ---- iterations: core.cpp:78-109 ----
   unsigned grp = 0;
-  int pend_lo = P, pend_slot = 0;  // the commit the previous iteration owes: particles pend_lo .. P - 1 of the phase that used near_list[pend_slot]
   if (tid == 0) {
     sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
     sh->near_cnt[0] = sh->near_cnt[1] = sh->near_cnt[2] = 0;
@@ -2661,11 +2658,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     const bool odd = overlapped && (it & 1);
     int32_t* const dcur = odd ? sw.raw2 : sw.raw;
     int32_t* const dnext = odd ? sw.raw : sw.raw2;
-    // pbest costs: the iteration starts from one copy and its first proposal step fills the other (see there)
-    double* const pbc_old = (it & 1) ? sw.pbc2 : sw.pbc;
-    double* const pbc_cur = (it & 1) ? sw.pbc : sw.pbc2;
-    Swarm swc = sw;
-    swc.pbc = pbc_cur;
     if (gen) {
       if (overlapped && it > 0) {  // what the previous iteration's rounds left time for, and the rest now
         if (next_filled < n_draw) {
@@ -2714,58 +2706,13 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         // (the headings first, then the x / y pairs: the sine and cosine -- two thirds of this step's instructions -- are
         // then issued by the waves that hold heading lanes only, two of the four that 70 particles occupy, instead of by
         // every wave because every third lane needed them)
-        // The iteration's FIRST proposal step (lo == 0) also does what the previous iteration left undone.  An iteration
-        // that ends without a gbest move owes the commit of its last phase -- particles pend_lo .. P - 1: position,
-        // velocity, pbest (core.cpp:94-96) -- and used to pay it as a step of its own: a pass over the swarm by one or two
-        // waves, and a barrier before the next iteration could read what it wrote.  The thread that proposes coordinate k of
-        // particle j now commits it on the way (the same values into the same places), and the heading's thread the
-        // pbest cost -- into the OTHER copy of the array, which every particle's cost is carried over to, because the
-        // particle's two other threads compare against the old one at the same time.  One barrier and one serial step less
-        // per iteration (config 3: commits + end of iteration were 120 of a workgroup's 2000 us; a cluster's round of the
-        // live sequence spent 1.0 of its 5 us there).
-        const bool first_step = lo == 0;
-        if (first_step && tid == 0) {
-          sh->k_wv[(it + 1) & 1] = sh->k_wv[it & 1] * ps.wdamp;  // core.cpp:108, for the next iteration
-          if constexpr (ARB) sh->xa.pbc = pbc_cur;
-        }
-        const double w_it = sh->k_wv[it & 1];
-        [[maybe_unused]] const int pend_cnt = ARB ? sh->near_cnt[pend_slot] : 0;
-        [[maybe_unused]] const unsigned short* pend_list = sh->near_list[pend_slot];
         const int n_prop = P - lo;
         for (int q = tid; q < 3 * n_prop; q += blockDim.x) {
           const int j = lo + (q < n_prop ? q : (q - n_prop) >> 1), k = q < n_prop ? 2 : ((q - n_prop) & 1);
           const double r1 = fabs(uniform_pm1(draws[6 * j + 2 * k]));
           const double r2 = fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
-          double p, vel0, pbk;
-          bool took = false;  // the owed commit found a new pbest
-          if (first_step && j >= pend_lo) {
-            const double cst = sw.tcost[j];
-            took = cst < pbc_old[j];  // core.cpp:94
-            p = sw.tpos[k * S + j];
-            vel0 = sw.tvel[k * S + j];
-            pbk = took ? p : sw.pb[k * S + j];
-            sw.pos[k * S + j] = p;
-            sw.vel[k * S + j] = vel0;
-            if (took) sw.pb[k * S + j] = p;
-            if (k == 2) {
-              pbc_cur[j] = took ? cst : pbc_old[j];
-              if constexpr (ARB) {
-                if (took) {
-                  sw.bcs[j] = sw.pcs[j];
-                  sw.bcs[S + j] = sw.pcs[S + j];
-                  bool exact_j = false;
-                  for (int t = 0; t < pend_cnt; ++t) exact_j |= (int)pend_list[t] == j;
-                  sw.pex[j] = exact_j ? 1 : 0;
-                }
-              }
-            }
-          } else {
-            p = sw.pos[k * S + j];
-            vel0 = sw.vel[k * S + j];
-            pbk = sw.pb[k * S + j];
-            if (first_step && k == 2) pbc_cur[j] = pbc_old[j];
-          }
-          const double v = w_it * vel0 + sh->k_c1 * r1 * (pbk - p) + sh->k_c2 * r2 * (sh->gb[k] - p);
+          const double p = sw.pos[k * S + j];
+          const double v = sh->k_w * sw.vel[k * S + j] + sh->k_c1 * r1 * (sw.pb[k * S + j] - p) + sh->k_c2 * r2 * (sh->gb[k] - p);
           const double np = p + v;
           sw.tvel[k * S + j] = v;
           sw.tpos[k * S + j] = np;
@@ -2785,7 +2732,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             }
           }
         }
-        if (first_step) pend_lo = P;
         need_propose = false;
         __syncthreads();  // proposals (and the commits before them) visible to every wave
         NDTPSO_PSO_MARK(1);
@@ -2805,7 +2751,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           next_filled = n_draw;
         }
         NDTPSO_PB(5);
-        eval_stream<MODE, PATH, ARB, NOCLIP>(E, pts, n, swc, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny,
+        eval_stream<MODE, PATH, ARB, NOCLIP>(E, pts, n, sw, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny,
                                              &sh->near_cnt[slot], sh->near_list[slot]);
         NDTPSO_PB(4);
         __syncthreads();
@@ -2831,7 +2777,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             {
               const double gbc0 = sh->gbc, tau = arb_margin(gbc0, n);
               for (int j = lo + tid; j < hi_g; j += blockDim.x) {
-                const double cj = sw.tcost[j], pj = pbc_cur[j];
+                const double cj = sw.tcost[j], pj = sw.pbc[j];
                 if (near_tie(cj, pj, tau) || near_tie(cj, gbc0, tau)) near_note(&sh->near_cnt[slot], sh->near_list[slot], j);
               }
             }
@@ -2853,7 +2799,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
                 const double gbc1 = sh->gbc;
                 for (int j = lo + tid; j < hi_g; j += blockDim.x) {
                   const double cj = sw.tcost[j];
-                  if (cj < gbc1 && cj < pbc_cur[j]) atomicMin(&sh->jstar[slot], j);
+                  if (cj < gbc1 && cj < sw.pbc[j]) atomicMin(&sh->jstar[slot], j);
                 }
               }
               __syncthreads();
@@ -2883,7 +2829,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         hi_g = min(lo + ps.G, P);
         // a cluster draws the next iteration's numbers behind the first exchange of this one (eval_round)
         const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
-        eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, swc, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
+        eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
                                         &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
                                         dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
         if (gen_here) next_filled = n_draw;
@@ -2932,7 +2878,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
                 int first = P;
                 for (int j = lo; j < hi_g; ++j) {
                   const double cj = sw.tcost[j];
-                  if (cj < sh->gbc && cj < pbc_cur[j]) {
+                  if (cj < sh->gbc && cj < sw.pbc[j]) {
                     first = j;
                     break;
                   }
@@ -2961,18 +2907,11 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       // that takes such a cost over inherits: Swarm::pex, ExactArgs::gex)
       [[maybe_unused]] const int arb_cnt = ARB ? sh->near_cnt[slot] : 0;
       [[maybe_unused]] const unsigned short* arb_list = sh->near_list[slot];
-      // An iteration's last phase without a gbest move is not committed here: the next iteration's first proposal step
-      // does it on its way (see there); after the last iteration nobody needs it.
-      const bool owe = js >= P && hi_g == P;
-      if (owe) {
-        pend_lo = lo;
-        pend_slot = slot;
-      }
-      for (int j = lo + tid; j <= (owe ? lo - 1 : last); j += blockDim.x) {
+      for (int j = lo + tid; j <= last; j += blockDim.x) {
         const double cst = sw.tcost[j];
-        const bool better = cst < pbc_cur[j];  // core.cpp:94
+        const bool better = cst < sw.pbc[j];  // core.cpp:94
 #ifdef NDTPSO_COUNT_AMBIG  // diagnostic builds: comparisons closer than a relative NDTPSO_COUNT_AMBIG (one-workgroup kernels)
-        if (fabs(cst - pbc_cur[j]) <= NDTPSO_COUNT_AMBIG * fabs(pbc_cur[j]) ||
+        if (fabs(cst - sw.pbc[j]) <= NDTPSO_COUNT_AMBIG * fabs(sw.pbc[j]) ||
             fabs(cst - sh->gbc) <= NDTPSO_COUNT_AMBIG * fabs(sh->gbc))
           atomicAdd(&sh->timed_out, 1);
 #endif
@@ -2996,7 +2935,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           sw.vel[k * S + j] = nv[k];
           if (better) sw.pb[k * S + j] = np[k];
         }
-        if (better) pbc_cur[j] = cst;
+        if (better) sw.pbc[j] = cst;
         if constexpr (ARB) {
           if (better) {
             sw.bcs[j] = hc;
@@ -3040,10 +2979,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       if (tid < 6 * P) sw.raw[tid] = pre0;
       if (tid + (int)blockDim.x < 6 * P) sw.raw[tid + blockDim.x] = pre1;
     }
-    // (No barrier here for the one-workgroup kernels: a commit made above lies behind the gbest move's barriers, the one
-    // owed is the next proposal step's own, and the generator's buffers are the other pair.  A cluster keeps it for the
-    // draws it has just stored.)
-    if constexpr (CLUSTER) __syncthreads();
+    if (tid == 0) sh->k_w *= ps.wdamp;  // core.cpp:108 (every proposal of this iteration has read it: barriers above)
+    __syncthreads();  // all commits of this iteration done before the next draws/proposals
   }
 
 #ifdef NDTPSO_PROFILE_PSO
