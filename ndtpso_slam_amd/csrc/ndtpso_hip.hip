@@ -450,7 +450,12 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
         double* __restrict__ out_cost, AlignStats* __restrict__ stats, ClusterP cl, double* __restrict__ mirror,
         const int4* __restrict__ table_src, int4* __restrict__ table_dst, int table_vec,
         const uint32_t* __restrict__ late_hdr, int late_table_cap, int late_rec_cap, uint32_t seq) {
-  cl.rank = (int)blockIdx.x;
+  if constexpr (CLUSTER) {
+    size_t c0;
+    if (!cluster_place(cl, &c0, &cl.rank)) return;  // (one cluster; the seven in eight workgroups that only place it leave here)
+  } else {
+    cl.rank = 0;
+  }
   if (CLUSTER && cl.rank == cl.absent) return;
   // The rand() table in a pinned HOST slot (table_src; ndtpso_map_align): fetched in one sweep into this workgroup's
   // own copy in HBM, the loads in flight together -- one trip over the host link instead of a copy operation ahead of
@@ -552,9 +557,9 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
               size_t table_stride, unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
               double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl,
               const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride) {
-  const size_t b = CLUSTER ? blockIdx.x / (unsigned)cl.K : blockIdx.x;
+  size_t b = blockIdx.x;
   if constexpr (CLUSTER) {
-    cl.rank = (int)(blockIdx.x % (unsigned)cl.K);
+    if (!cluster_place(cl, &b, &cl.rank)) return;
     cl.xc += b * 2 * (size_t)cl.stride;
   }
   const bool writer = !CLUSTER || cl.rank == 0;
@@ -622,7 +627,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   TableOut xout{nullptr, nullptr, nullptr, nullptr, nullptr};
   if constexpr (ARB) {
     {
-      my_ximg = ximg + (CLUSTER ? (size_t)blockIdx.x : b) * ximg_stride;
+      my_ximg = ximg + (CLUSTER ? b * (size_t)cl.K + (size_t)cl.rank : b) * ximg_stride;
       xout.mean = reinterpret_cast<double2*>(my_ximg + image_mean_offset(wn.n_words));
       xout.ab = reinterpret_cast<double2*>(my_ximg + image_ab_offset(wn.n_words, wn.rec_cap));
       xout.cd = reinterpret_cast<double2*>(my_ximg + image_cd_offset(wn.n_words, wn.rec_cap));
@@ -1677,6 +1682,12 @@ static uint32_t next_cluster_nonce(ndtpso_ctx* c) {
   return c->cluster_nonce;
 }
 
+// NDTPSO_CLUSTER_SPREAD=1: a cluster's workgroups where the dispatcher puts consecutive ones (all eight XCDs) instead of on
+// one XCD (ClusterP::one_xcd) -- for comparison; the results do not depend on it
+static int cluster_one_xcd() {
+  const char* e = std::getenv("NDTPSO_CLUSTER_SPREAD");
+  return (e && e[0] == '1') ? 0 : 1;
+}
 // NDTPSO_CLUSTER_TEST_ABSENT=r (tests only): rank r of every cluster leaves immediately, so the others run into the
 // bounded wait and the one-workgroup rerun is exercised
 static int cluster_test_absent() {
@@ -1763,7 +1774,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), 1};
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
     cl.stride = round_up(cfg->population + 1, 8);
@@ -1771,7 +1782,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     cl.nonce = next_cluster_nonce(c);
   }
 #define LAUNCH_ALIGN_CA(MODE, PATH, CL, ARB)                                                                       \
-  hipLaunchKernelGGL((k_align<MODE, PATH, CL, ARB>), dim3(K), dim3(waves * 64), L.total, c->stream,                \
+  hipLaunchKernelGGL((k_align<MODE, PATH, CL, ARB>), dim3(CL ? cluster_grid(cl) : 1u), dim3(waves * 64), L.total, c->stream, \
                      src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
                      ps, (const double*)c->inputs, (const double*)c->inputs + 3, seed,                             \
                      have_table && !staged_table ? (const int32_t*)((const unsigned char*)c->inputs + kGuessBytes) : nullptr, \
@@ -1964,7 +1975,10 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   if (K > 1) waves = cw;
   PsoP ps = make_pso(cfg, waves, mode, plan.L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), (int)n_pairs};
+  // (one XCD per cluster only while an XCD's share of the clusters finds a compute unit per workgroup there; a batch that
+  // fills the device is spread as the dispatcher spreads it)
+  if (((int)n_pairs + 7) / 8 * K > std::max(1, c->n_cus / 8)) cl.one_xcd = 0;
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);
     cl.stride = round_up(cfg->population + 1, 8);
@@ -1983,7 +1997,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   }
   unsigned char* d_ximg = ximg_stride ? (unsigned char*)c->ximg.p : nullptr;
 #define LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, SWARM)                                                      \
-  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM>), dim3(n_pairs * (unsigned)K), dim3(waves * 64), plan.L.total, \
+  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM>), dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), plan.L.total, \
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
                      d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
                      cl, dirs, d_ximg, ximg_stride)

@@ -2340,7 +2340,30 @@ struct ClusterP {
   int absent;           // test hook: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout
   uint4* xc;            // [2][stride] exchange slots {cost lo, tag, cost hi, tag}
   uint32_t nonce;       // upper half of the tags of this launch (the slots keep whatever earlier launches left there)
+  // A cluster on ONE XCD.  Workgroups go to the eight XCDs in turn (workgroup i to XCD i mod 8: HW_REG_XCC_ID read back by
+  // scripts/ubench_xcd_exchange.hip), and the same 16-byte `sc1` store and loads cost 0.50 us per exchange between eight
+  // workgroups of one XCD against 0.93 us between eight consecutive ones (1.27 -> 0.76 us for sixteen): the slots are served
+  // by the XCD's own L2 instead of the fabric.  So cluster c of a launch is the workgroups whose index is c mod 8 modulo 8
+  // -- rank r of cluster c is workgroup ((c / 8) K + r) 8 + c mod 8 -- and a lone cluster launches 8 K workgroups of which
+  // seven in eight leave on their first instruction.  Placement only: the exchange is correct wherever the workgroups land.
+  int one_xcd;          // 1: that mapping; 0: K consecutive workgroups per cluster (NDTPSO_CLUSTER_SPREAD=1, for comparison)
+  int n;                // clusters in this launch
 };
+// (cluster, rank) of this workgroup; false: it has no part in the launch
+__device__ __forceinline__ bool cluster_place(const ClusterP& cl, size_t* c, int* rank) {
+  if (cl.one_xcd) {
+    const unsigned x = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    *rank = (int)(q % (unsigned)cl.K);
+    *c = (size_t)(q / (unsigned)cl.K) * 8u + x;
+  } else {
+    *rank = (int)(blockIdx.x % (unsigned)cl.K);
+    *c = blockIdx.x / (unsigned)cl.K;
+  }
+  return *c < (size_t)cl.n;
+}
+__host__ inline unsigned cluster_grid(const ClusterP& cl) {
+  return cl.one_xcd ? (unsigned)((cl.n + 7) / 8) * 8u * (unsigned)cl.K : (unsigned)cl.n * (unsigned)cl.K;
+}
 
 // One exchanged cost: a 16-byte slot written and read whole, agent scope (sc1: through to memory, past the L2 of the
 // reader's XCD), with the round's tag in two of its words -- a reader takes a slot only when both tags are the round's,
@@ -2446,7 +2469,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
                                   PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats,
-                                  const ClusterP& cl = ClusterP{1, 0, 0, -1, nullptr, 0u}) {
+                                  const ClusterP& cl = ClusterP{1, 0, 0, -1, nullptr, 0u, 0, 1}) {
   unsigned epoch = 0;
   constexpr bool kStream = NDTPSO_STREAM && !CLUSTER;  // phases dealt by ticket (eval_stream) instead of rounds
   const bool writer = !CLUSTER || cl.rank == 0;  // the workgroup that reports the result

@@ -480,14 +480,19 @@ def test_cluster_of_workgroups_matches_one_workgroup(ctx, oracle, pairs8, monkey
             for kw in (dict(rand_table=table), dict(seed=int(p.seeds[b]))):     # host table / device replay of rand()
                 monkeypatch.setenv("NDTPSO_CLUSTER", "0")
                 want = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, mode=mode, **kw)
-                for shape in (None, ("2", "1"), ("5", "3"), ("32", "4"), ("7", "16")):
+                # (the last shape with the cluster's workgroups where consecutive ones land, on all eight XCDs, instead of
+                # on one XCD: ClusterP::one_xcd is placement only)
+                for shape in (None, ("2", "1"), ("5", "3"), ("32", "4"), ("7", "16"), ("9", "4", "spread")):
                     if shape is None:
                         monkeypatch.delenv("NDTPSO_CLUSTER")
                         monkeypatch.delenv("NDTPSO_CLUSTER_WAVES", raising=False)
                     else:
                         monkeypatch.setenv("NDTPSO_CLUSTER", shape[0])
                         monkeypatch.setenv("NDTPSO_CLUSTER_WAVES", shape[1])
+                        if len(shape) > 2:
+                            monkeypatch.setenv("NDTPSO_CLUSTER_SPREAD", "1")
                     got = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, mode=mode, **kw)
+                    monkeypatch.delenv("NDTPSO_CLUSTER_SPREAD", raising=False)
                     assert np.array_equal(got[0], want[0]) and got[1] == want[1], (P, I, mode, shape)
                     assert got[2]["gbest_updates"] == want[2]["gbest_updates"] and got[2]["status"] == want[2]["status"]
                 monkeypatch.delenv("NDTPSO_CLUSTER_WAVES", raising=False)
