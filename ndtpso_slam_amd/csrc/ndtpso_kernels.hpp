@@ -1393,11 +1393,12 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
   double* pbc;    // [S]    best_cost
   double* tpos;   // [3][S] proposed position
   double* tvel;   // [3][S]
-  double* tc;     // [S] cos(theta) of the proposal -- dense form: the folded transform constants C, S, TX, TY of the
-  double* ts;     // [S] proposal (DenseItem), computed once where the proposal is made instead of by every wave
-  double* ttx;    // [S] that evaluates it (dense form only)
-  double* tty;    // [S]
+  double* it;     // [S][4] per proposal {cos, sin, -, -} of its heading -- dense form: the folded transform constants
+                  //        {C, S, TX, TY} (DenseItem), computed once where the proposal is made instead of by every wave
+                  //        that evaluates it; one record, so that an evaluation fetches it with two 16-byte reads off one address
   double* tcost;  // [S]
+  unsigned char* tgd;  // [S][2] fused pairs kernels: TX / TY of the proposal lie inside the DenseGuard (set with them; the
+                       //        evaluating wave reads the pair as one 16-bit word instead of comparing four doubles)
   double* pcs;    // [2][S] plain cos, sin of the proposal's heading  } exact mode only: what the fp64 score of a
   double* bcs;    // [2][S] the same for the pbest position            } position takes (exact_tasks), so that the
   unsigned char* pex;  // [S] exact mode: pbc[j] holds the fp64 score of the pbest position (an arbitration put it there)
@@ -1408,7 +1409,7 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
 // overlapped generator -- always with the swarm in its HBM workspace, in LDS only for swarms of up to 256 particles (a
 // 512-particle swarm with it no longer fits beside the dense table: 16 266 instead of 26 202 align/s, measured)
 __host__ __device__ inline bool swarm_has_raw2(int P, bool swarm_global) { return swarm_global || P <= 256; }
-__host__ __device__ inline int swarm_doubles(int P, bool exact) { return (exact ? 26 : 21) * (P + 1); }
+__host__ __device__ inline int swarm_doubles(int P, bool exact) { return (exact ? 27 : 22) * (P + 1); }
 __host__ __device__ inline int swarm_raw_ints(int P) { return (6 * P > 3 * (P + 1)) ? 6 * P : 3 * (P + 1); }
 __host__ __device__ inline int swarm_bytes(int P, bool exact, bool raw2) {
   return align16(swarm_doubles(P, exact) * 8) + align16(swarm_raw_ints(P) * 4) + (raw2 ? align16(6 * P * 4) : 0);
@@ -1424,14 +1425,12 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P, bool exact, bool
   sw.pbc = d + 9 * S;
   sw.tpos = d + 10 * S;
   sw.tvel = d + 13 * S;
-  sw.tc = d + 16 * S;
-  sw.ts = d + 17 * S;
-  sw.tcost = d + 18 * S;
-  sw.ttx = d + 19 * S;
-  sw.tty = d + 20 * S;
-  sw.pcs = exact ? d + 21 * S : nullptr;
-  sw.bcs = exact ? d + 23 * S : nullptr;
-  sw.pex = exact ? reinterpret_cast<unsigned char*>(d + 25 * S) : nullptr;  // (S bytes of an S-double slot)
+  sw.it = d + 16 * S;
+  sw.tcost = d + 20 * S;
+  sw.tgd = reinterpret_cast<unsigned char*>(d + 21 * S);  // (2 S bytes of an S-double slot)
+  sw.pcs = exact ? d + 22 * S : nullptr;
+  sw.bcs = exact ? d + 24 * S : nullptr;
+  sw.pex = exact ? reinterpret_cast<unsigned char*>(d + 26 * S) : nullptr;  // (S bytes of an S-double slot)
   sw.raw = reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P, exact) * 8));
   sw.raw2 = raw2 ? reinterpret_cast<int32_t*>(base + align16(swarm_doubles(P, exact) * 8) + align16(swarm_raw_ints(P) * 4)) : nullptr;
   return sw;
@@ -2124,18 +2123,14 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
     jend = last;
   }
   for (int j = j0; j < jend; j += dj) {
-    const double c = sw.tc[j], s = sw.ts[j];
+    const double c = sw.it[4 * j], s = sw.it[4 * j + 1];
     const double pbc_j = sw.pbc[j];  // fetched with the pose, not after the evaluation (garbage during the swarm's
                                      // initialisation, where it is not looked at)
     double cost;
     if constexpr (path_is_dense(PATH)) {
-      const DenseItem it{c, s, sw.ttx[j], sw.tty[j], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
+      const DenseItem it{c, s, sw.it[4 * j + 2], sw.it[4 * j + 3], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
       if constexpr (PATH == 3 || (PATH == 2 && NOCLIP)) {  // (the fused pairs kernels: they set up the guard)
-        typedef double v2d_t __attribute__((ext_vector_type(2)));
-        typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
-        const v2d_t gx = *(lds_d2_t)(uintptr_t)E.guard_lds, gy = *(lds_d2_t)(uintptr_t)(E.guard_lds + 16u);  // DenseGuard
-        // (NaN translations fail the tests and take the clamped loop)
-        if (it.TX >= gx.x && it.TX < gx.y && it.TY >= gy.x && it.TY < gy.y)
+        if (*reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)  // inside the guard both ways (proposal step)
         {
 #ifdef NDTPSO_COUNT_NOCLAMP  // diagnostic builds: evaluations through the no-clamp loop, reported as `gbest_updates`
           if (lane_id() == 0) atomicAdd(tiny + 1, 1);  // PsoShared::timed_out (unused by a single workgroup)
@@ -2221,7 +2216,13 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
   typedef int __attribute__((address_space(3))) * lds_int_t;
   int last_done = -1;
 #if NDTPSO_ALTERNATE_PRIO
-  const unsigned late = __builtin_amdgcn_readfirstlane(blockIdx.x >= (gridDim.x >> 1) ? 1u : 0u);
+  // (the turn is worked out on the scalar unit, spelt in its own instructions: as C the compiler made a 64-bit vector
+  // compare and two selects per item of it -- the clock's value counts as divergent -- whatever was wrapped in readfirstlane)
+  unsigned late;
+  asm("s_cmp_ge_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0"
+      : "=s"(late)
+      : "s"(__builtin_amdgcn_readfirstlane((unsigned)blockIdx.x)), "s"(__builtin_amdgcn_readfirstlane((unsigned)gridDim.x >> 1))
+      : "scc");
 #endif
   for (;;) {
     // (an LDS read in flight together with the ticket; through a generic pointer it was a flat load with system scope)
@@ -2230,22 +2231,24 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
     if (j >= P || j > seen) break;
 #if NDTPSO_ALTERNATE_PRIO
     // the two workgroups of a compute unit take turns holding the higher priority (see pso_run_wg)
-    // (all of it on the scalar unit: as a comparison of two booleans it was a 64-bit vector compare and two selects per item)
-    if (((((unsigned)wall_clock64() >> 9) & 15u) < (unsigned)NDTPSO_PRIO_SHARE ? 1u : 0u) == late)
-      __builtin_amdgcn_s_setprio(1);
-    else
-      __builtin_amdgcn_s_setprio(0);
+    {
+      unsigned long long now;
+      unsigned turn;
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now));
+      asm("s_bfe_u32 %0, %1, 0x40009\n\ts_cmp_lt_u32 %0, %2\n\ts_cselect_b32 %0, 1, 0" : "=&s"(turn) : "s"((unsigned)now), "n"(NDTPSO_PRIO_SHARE) : "scc");
+      if (turn == late)
+        __builtin_amdgcn_s_setprio(1);
+      else
+        __builtin_amdgcn_s_setprio(0);
+    }
 #endif
-    const double c = sw.tc[j], s = sw.ts[j];
+    const double c = sw.it[4 * j], s = sw.it[4 * j + 1];
     const double pbc_j = sw.pbc[j];
     double cost;
     if constexpr (path_is_dense(PATH)) {
-      const DenseItem it{c, s, sw.ttx[j], sw.tty[j], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
+      const DenseItem it{c, s, sw.it[4 * j + 2], sw.it[4 * j + 3], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
       if constexpr (PATH == 3 || (PATH == 2 && NOCLIP)) {  // (the fused pairs kernels: they set up the guard)
-        typedef double v2d_t __attribute__((ext_vector_type(2)));
-        typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
-        const v2d_t gx = *(lds_d2_t)(uintptr_t)E.guard_lds, gy = *(lds_d2_t)(uintptr_t)(E.guard_lds + 16u);  // DenseGuard
-        if (it.TX >= gx.x && it.TX < gx.y && it.TY >= gy.x && it.TY < gy.y)
+        if (*reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)  // inside the guard both ways (proposal step)
           cost = eval_item_wave_dense<false, PATH == 3, true, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
         else
           cost = eval_item_wave_dense<false, PATH == 3, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
@@ -2403,7 +2406,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     uint4* buf = cl.xc + (size_t)(epoch & 1u) * cl.stride;
     const uint32_t tag = (cl.nonce << 16) | ((epoch + 1u) & 0xffffu);
     for (int j = first + cl.rank * n_waves + wave_id(); j < last; j += total_waves) {
-      const double c = sw.tc[j], s = sw.ts[j];
+      const double c = sw.it[4 * j], s = sw.it[4 * j + 1];
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       double cost;
       if constexpr (path_is_dense(PATH))  // (a cluster folds the constants here: its proposal step is on the critical path)
@@ -2546,13 +2549,17 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       }
       if constexpr (path_is_dense(PATH) && !CLUSTER) {  // DenseItem of this pose (dense_item), kept with it
         const double inv = sh->k_inv;
-        sw.tc[slot] = cn * inv;
-        sw.ts[slot] = sn * inv;
-        sw.ttx[slot] = (sw.tpos[slot] + sh->k_hw) * inv - sh->k_ox;
-        sw.tty[slot] = (sw.tpos[S + slot] + sh->k_hh) * inv - sh->k_oy;
+        const double TX = (sw.tpos[slot] + sh->k_hw) * inv - sh->k_ox, TY = (sw.tpos[S + slot] + sh->k_hh) * inv - sh->k_oy;
+        sw.it[4 * slot] = cn * inv;
+        sw.it[4 * slot + 1] = sn * inv;
+        sw.it[4 * slot + 2] = TX;
+        sw.it[4 * slot + 3] = TY;
+        // (NaN translations fail the tests and take the clamped loop)
+        sw.tgd[2 * slot] = (TX >= sh->guard.x_lo && TX < sh->guard.x_hi) ? 1 : 0;
+        sw.tgd[2 * slot + 1] = (TY >= sh->guard.y_lo && TY < sh->guard.y_hi) ? 1 : 0;
       } else {
-        sw.tc[slot] = cn;
-        sw.ts[slot] = sn;
+        sw.it[4 * slot] = cn;
+        sw.it[4 * slot + 1] = sn;
       }
     }
   }
@@ -2741,14 +2748,22 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           sw.tpos[k * S + j] = np;
           constexpr bool fold = path_is_dense(PATH) && !CLUSTER;
           if constexpr (fold) {  // each coordinate's share of the proposal's DenseItem (dense_item)
-            if (k == 0) sw.ttx[j] = (np + sh->k_hw) * sh->k_inv - sh->k_ox;
-            if (k == 1) sw.tty[j] = (np + sh->k_hh) * sh->k_inv - sh->k_oy;
+            if (k == 0) {
+              const double TX = (np + sh->k_hw) * sh->k_inv - sh->k_ox;
+              sw.it[4 * j + 2] = TX;
+              sw.tgd[2 * j] = (TX >= sh->guard.x_lo && TX < sh->guard.x_hi) ? 1 : 0;
+            }
+            if (k == 1) {
+              const double TY = (np + sh->k_hh) * sh->k_inv - sh->k_oy;
+              sw.it[4 * j + 3] = TY;
+              sw.tgd[2 * j + 1] = (TY >= sh->guard.y_lo && TY < sh->guard.y_hi) ? 1 : 0;
+            }
           }
           if (k == 2) {
             double sn, cn;
             sincos(np, &sn, &cn);
-            sw.tc[j] = fold ? cn * sh->k_inv : cn;
-            sw.ts[j] = fold ? sn * sh->k_inv : sn;
+            sw.it[4 * j] = fold ? cn * sh->k_inv : cn;
+            sw.it[4 * j + 1] = fold ? sn * sh->k_inv : sn;
             if constexpr (ARB) {
               sw.pcs[j] = cn;
               sw.pcs[S + j] = sn;
