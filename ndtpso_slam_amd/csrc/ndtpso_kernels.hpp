@@ -311,12 +311,24 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
                           __builtin_amdgcn_readlane(__double2loint(v), lane));
 }
+// lane 15 of a row into every lane of the next row (ROWS 0xa: rows 1 and 3 take it), lane 31 into rows 2 and 3 (0xc); 0. elsewhere
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_bcast_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_f64<0xB1>(v);   // quad_perm [1,0,3,2]
   v += dpp_f64<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_f64<0x141>(v);  // row_half_mirror
   v += dpp_f64<0x140>(v);  // row_mirror
-  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+  // the four row sums r0 .. r3 as (r0 + r1) + (r2 + r3): row 1 takes r0, row 3 takes r2 (row_bcast:15), then row 3 takes
+  // row 1's r1 + r0 (row_bcast:31) and holds (r3 + r2) + (r1 + r0) -- the same two additions per level as four readlanes
+  // and three scalar-operand adds gave (an addition does not care which operand comes first), in 8 instructions instead of 13
+  v += dpp_bcast_f64<0x142, 0xa>(v);  // row_bcast:15
+  v += dpp_bcast_f64<0x143, 0xc>(v);  // row_bcast:31
+  return readlane_f64(v, 63);
 }
 
 // cell coordinates of an in-frame point, following NDTFrame::getCellIndex (ndtframe.cpp:240-249):
@@ -2273,12 +2285,21 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
           ordinary = false;
         }
       }
-      if (ordinary && cost < gbc)
-        if (cost < pbc_j) __hip_atomic_fetch_min((lds_int_t)improver, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if constexpr (ARB) {
+        // The usual outcome first: worse than its pbest AND than the gbest by more than the margin -- then it is neither an
+        // improver nor a near tie, and the two differences and one comparison that say so are all the lane spends (the
+        // nested tests of core.cpp:94-104 and the two margin tests were eight fp64 compares per evaluation).
         const double tau = arb_margin(gbc, n);
-        // (a flag is all the phase needs: pso_run_wg reads the list off the stored costs)
-        if (near_tie(cost, pbc_j, tau) || near_tie(cost, gbc, tau)) *(lds_int_t)near_cnt = 1;
+        const double d1 = cost - pbc_j, d2 = cost - gbc;
+        if (ordinary && !(fmin(d1, d2) > tau)) {
+          if (cost < gbc)
+            if (cost < pbc_j) __hip_atomic_fetch_min((lds_int_t)improver, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // (a flag is all the phase needs: pso_run_wg reads the list off the stored costs)
+          if (fabs(d1) <= tau || fabs(d2) <= tau) *(lds_int_t)near_cnt = 1;
+        }
+      } else {
+        if (ordinary && cost < gbc)
+          if (cost < pbc_j) __hip_atomic_fetch_min((lds_int_t)improver, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     }
   }
