@@ -453,6 +453,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   if constexpr (CLUSTER) {
     size_t c0;
     if (!cluster_place(cl, &c0, &cl.rank)) return;  // (one cluster; the seven in eight workgroups that only place it leave here)
+    cl.spec = cl.spec_off >= 0 ? reinterpret_cast<double*>(g_lds + cl.spec_off) : nullptr;
   } else {
     cl.rank = 0;
   }
@@ -561,6 +562,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if constexpr (CLUSTER) {
     if (!cluster_place(cl, &b, &cl.rank)) return;
     cl.xc += b * 2 * (size_t)cl.stride;
+    cl.spec = cl.spec_off >= 0 ? reinterpret_cast<double*>(g_lds + cl.spec_off) : nullptr;
   }
   const bool writer = !CLUSTER || cl.rank == 0;
   if (CLUSTER && cl.rank == cl.absent) return;
@@ -1682,6 +1684,17 @@ static uint32_t next_cluster_nonce(ndtpso_ctx* c) {
   return c->cluster_nonce;
 }
 
+// Room behind a cluster workgroup's LDS layout for the two ready-made next proposals of every coordinate (SpecP:
+// 16 (P + 1) doubles), where it fits and the swarm is small enough for wave 0 to hold its comparisons (four per lane);
+// NDTPSO_CLUSTER_SPEC=0 leaves it out (the usual commit and proposal steps: same results)
+static void cluster_spec_room(int P, int* lds_total, ClusterP* cl) {
+  const char* e = std::getenv("NDTPSO_CLUSTER_SPEC");
+  if (e && e[0] == '0') return;
+  const int at = round_up(*lds_total, 16), bytes = 16 * (P + 1) * 8;
+  if (P > 4 * kWave || at + bytes > kMaxLds) return;
+  cl->spec_off = at;
+  *lds_total = at + bytes;
+}
 // NDTPSO_CLUSTER_SPREAD=1: a cluster's workgroups where the dispatcher puts consecutive ones (all eight XCDs) instead of on
 // one XCD (ClusterP::one_xcd) -- for comparison; the results do not depend on it
 static int cluster_one_xcd() {
@@ -1774,15 +1787,17 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), 1};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), 1, -1, nullptr};
+  int lds_total = L.total;
   if (K > 1) {
+    cluster_spec_room(cfg->population, &lds_total, &cl);
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
     cl.stride = round_up(cfg->population + 1, 8);
     if (int rc = cluster_slots(c, (size_t)2 * cl.stride * sizeof(uint4), &cl.xc)) return rc;
     cl.nonce = next_cluster_nonce(c);
   }
 #define LAUNCH_ALIGN_CA(MODE, PATH, CL, ARB)                                                                       \
-  hipLaunchKernelGGL((k_align<MODE, PATH, CL, ARB>), dim3(CL ? cluster_grid(cl) : 1u), dim3(waves * 64), L.total, c->stream, \
+  hipLaunchKernelGGL((k_align<MODE, PATH, CL, ARB>), dim3(CL ? cluster_grid(cl) : 1u), dim3(waves * 64), lds_total, c->stream, \
                      src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
                      ps, (const double*)c->inputs, (const double*)c->inputs + 3, seed,                             \
                      have_table && !staged_table ? (const int32_t*)((const unsigned char*)c->inputs + kGuessBytes) : nullptr, \
@@ -1975,7 +1990,9 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   if (K > 1) waves = cw;
   PsoP ps = make_pso(cfg, waves, mode, plan.L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), (int)n_pairs};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), (int)n_pairs, -1, nullptr};
+  int lds_total = plan.L.total;
+  if (K > 1) cluster_spec_room(cfg->population, &lds_total, &cl);
   // (one XCD per cluster only while an XCD's share of the clusters finds a compute unit per workgroup there; a batch that
   // fills the device is spread as the dispatcher spreads it)
   if (((int)n_pairs + 7) / 8 * K > std::max(1, c->n_cus / 8)) cl.one_xcd = 0;
@@ -1997,7 +2014,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   }
   unsigned char* d_ximg = ximg_stride ? (unsigned char*)c->ximg.p : nullptr;
 #define LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, SWARM)                                                      \
-  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM>), dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), plan.L.total, \
+  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM>), dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), lds_total, \
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
                      d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
                      cl, dirs, d_ximg, ximg_stride)

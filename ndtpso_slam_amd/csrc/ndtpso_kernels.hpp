@@ -2372,7 +2372,29 @@ struct ClusterP {
   // seven in eight leave on their first instruction.  Placement only: the exchange is correct wherever the workgroups land.
   int one_xcd;          // 1: that mapping; 0: K consecutive workgroups per cluster (NDTPSO_CLUSTER_SPREAD=1, for comparison)
   int n;                // clusters in this launch
+  int spec_off;         // LDS byte offset of the speculation scratch (16 (P + 1) doubles, SpecP), -1: none
+  double* spec;         // ... as a pointer (set by the kernel)
 };
+
+// ---- a cluster's next proposals, made while its costs travel ---------------------------------------------------------
+// A round of a cluster ends with the exchange: wave 0 of every workgroup reads slots for about a microsecond and the other
+// waves wait for it.  When the round is the iteration's only one (every particle in it) and nobody improves the gbest --
+// five rounds in six of the live sequence -- what follows is fixed but for ONE bit per particle: the commit of every
+// proposal (core.cpp:94-96) and the next iteration's proposals against the unchanged gbest (core.cpp:83-90), where
+// "pbest - position" is zero if the particle has just found a new pbest and "old pbest - new position" if not.  So the
+// idle waves make BOTH next proposals of every coordinate during the exchange (same expressions, same operation order:
+// the values are the proposal step's bit for bit), and after the round's barrier a short step commits and picks one by the
+// comparison the reference makes.  A gbest move, an iteration in several rounds or draws that are not there yet (the device
+// generator makes them during the same exchange) leave everything to the usual commit and proposal steps.
+struct SpecP {
+  double* buf;             // [2][3][S] velocity, [2][3][S] position, [2][2][S] cos / sin of the heading; candidate 0: new pbest
+  const int32_t* draws;    // the next iteration's draws (6 per particle), readable now; nullptr: no speculation this round
+  double w, c1, c2;        // the next iteration's inertia weight, c1, c2
+  const double* gb;        // gbest position
+};
+__device__ __forceinline__ double* spec_vel(double* buf, int S, int c, int k) { return buf + (c * 3 + k) * S; }
+__device__ __forceinline__ double* spec_pos(double* buf, int S, int c, int k) { return buf + (6 + c * 3 + k) * S; }
+__device__ __forceinline__ double* spec_cs(double* buf, int S, int c, int which) { return buf + (12 + c * 2 + which) * S; }
 // (cluster, rank) of this workgroup; false: it has no part in the launch
 __device__ __forceinline__ bool cluster_place(const ClusterP& cl, size_t* c, int* rank) {
   if (cl.one_xcd) {
@@ -2418,7 +2440,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
                                   double gbc, int* improver, int* tiny, const ClusterP& cl, unsigned& epoch,
                                   int* timed_out, int* near_cnt, unsigned short* near_list,
                                   RngState* gen_st = nullptr, int* gen_t = nullptr, int32_t* gen_dst = nullptr,
-                                  int gen_cnt = 0, int gen_wave = -1) {
+                                  int gen_cnt = 0, int gen_wave = -1, const SpecP* sp = nullptr) {
   if constexpr (!CLUSTER) {
     eval_items<MODE, PATH, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
   } else {
@@ -2440,6 +2462,28 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     // behind the exchange (wave 0 polls, everybody else would idle): one wave of every workgroup draws the next
     // iteration's rand() numbers -- 3.4 us that used to stand alone at the iteration's start
     if (gen_cnt > 0 && wave_id() == gen_wave) rng_fill_wave0(gen_st, gen_t, gen_dst, gen_cnt);
+    // ... and the waves that do not poll make the next iteration's proposals, both ways (SpecP)
+    if (sp && sp->draws && wave_id() != 0) {
+      const int P = S - 1, nt = (int)blockDim.x - kWave;
+      for (int t = (int)threadIdx.x - kWave; t < 6 * P; t += nt) {
+        const int c = t & 1, jk = t >> 1;  // headings first, as in the proposal step
+        const int j = jk < P ? jk : (jk - P) >> 1, k = jk < P ? 2 : ((jk - P) & 1);
+        const double r1 = fabs(uniform_pm1(sp->draws[6 * j + 2 * k]));
+        const double r2 = fabs(uniform_pm1(sp->draws[6 * j + 2 * k + 1]));
+        const double p = sw.tpos[k * S + j];  // the position the commit will make current
+        const double pbk = c == 0 ? p : sw.pb[k * S + j];  // pbest: the same position (new pbest) or the old one
+        const double v = sp->w * sw.tvel[k * S + j] + sp->c1 * r1 * (pbk - p) + sp->c2 * r2 * (sp->gb[k] - p);
+        const double np = p + v;
+        spec_vel(sp->buf, S, c, k)[j] = v;
+        spec_pos(sp->buf, S, c, k)[j] = np;
+        if (k == 2) {
+          double sn, cn;
+          sincos(np, &sn, &cn);
+          spec_cs(sp->buf, S, c, 0)[j] = cn;
+          spec_cs(sp->buf, S, c, 1)[j] = sn;
+        }
+      }
+    }
     // Wave 0 of every workgroup reads the round's slots until all of them carry the round's tag (its own workgroup's
     // among them), a lane per item, and does the round's detection on what it read.  One trip of the cost to memory and
     // one back: the first scheme -- costs, a fence, an arrival counter, a poll, a fence, the costs read back -- was four,
@@ -2493,7 +2537,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
                                   PsoShared* sh, double* out_pose, double* out_cost, AlignStats* stats,
-                                  const ClusterP& cl = ClusterP{1, 0, 0, -1, nullptr, 0u, 0, 1}) {
+                                  const ClusterP& cl = ClusterP{1, 0, 0, -1, nullptr, 0u, 0, 1, -1, nullptr}) {
   unsigned epoch = 0;
   constexpr bool kStream = NDTPSO_STREAM && !CLUSTER;  // phases dealt by ticket (eval_stream) instead of rounds
   const bool writer = !CLUSTER || cl.rank == 0;  // the workgroup that reports the result
@@ -2658,21 +2702,26 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 
   // ---- iterations: core.cpp:78-109 ----
   unsigned grp = 0;
+  [[maybe_unused]] bool pre_proposed = false;  // a cluster: the coming iteration's proposals are in place already (SpecP)
   if (tid == 0) {
     sh->jstar[0] = sh->jstar[1] = sh->jstar[2] = P;
     sh->near_cnt[0] = sh->near_cnt[1] = sh->near_cnt[2] = 0;
   }
-  // rand() table from the host (the live node): the draws of an iteration are fetched from HBM one iteration ahead --
-  // the loads are issued at the top of iteration it - 1, sit in two registers per thread while it runs, and land in the
-  // LDS buffer the device generator would otherwise fill -- so the proposal step, where most waves wait for one or
-  // two, starts from LDS instead of paying an HBM round trip every time
+  // rand() table from the host (the live node): the draws of an iteration are fetched from HBM TWO iterations ahead --
+  // the loads are issued at the top of iteration it - 2, sit in two registers per thread while it runs, and land at its
+  // end in the LDS buffer of that iteration's parity (the two buffers the device generator would otherwise fill) -- so
+  // the proposal step, where most waves wait for one or two, starts from LDS instead of paying an HBM round trip every
+  // time, and the iteration before can already make this one's proposals (SpecP) from LDS
   // (a cluster's kernels only -- the live node's: two more registers live through every iteration are two more spilled
   // in the batch kernels)
-  const bool prefetch = CLUSTER && !gen && ps.I > 0 && 6 * P <= 2 * (int)blockDim.x;
+  const bool prefetch = CLUSTER && !gen && ps.I > 0 && 6 * P <= 2 * (int)blockDim.x && sw.raw2 != nullptr;
   int32_t pre0 = 0, pre1 = 0;
   if (prefetch) {
     const int32_t* first = table + 3 * S;
-    for (int q = tid; q < 6 * P; q += blockDim.x) sw.raw[q] = first[q];
+    for (int q = tid; q < 6 * P; q += blockDim.x) {
+      sw.raw[q] = first[q];
+      if (ps.I > 1) sw.raw2[q] = first[6 * P + q];
+    }
   }
   __syncthreads();
 #ifdef NDTPSO_PROFILE_PSO
@@ -2723,9 +2772,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     }
     NDTPSO_PSO_MARK(0);
     NDTPSO_PB(2);
-    const int32_t* draws = gen ? dcur : (prefetch ? sw.raw : (table + 3 * S + (size_t)it * 6 * P));
-    if (prefetch && it + 1 < ps.I) {
-      const int32_t* next = table + 3 * S + (size_t)(it + 1) * 6 * P;
+    int32_t* const pbuf = (it & 1) ? sw.raw2 : sw.raw;  // (prefetch) this iteration's draws; refilled at its end for it + 2
+    const int32_t* draws = gen ? dcur : (prefetch ? pbuf : (table + 3 * S + (size_t)it * 6 * P));
+    if (prefetch && it + 2 < ps.I) {
+      const int32_t* next = table + 3 * S + (size_t)(it + 2) * 6 * P;
       if (tid < 6 * P) pre0 = next[tid];
       if (tid + (int)blockDim.x < 6 * P) pre1 = next[tid + blockDim.x];
     }
@@ -2739,7 +2789,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     // two barriers ahead of its next use).  Committing a group touches only pos/vel/pbest of that group,
     // which no evaluation reads, so waves run on into the next group without waiting for it.
     int lo = 0;
-    bool need_propose = true;
+    bool need_propose = !pre_proposed;
+    pre_proposed = false;
     while (lo < P) {
       [[maybe_unused]] const bool proposed_now = need_propose;
 #if NDTPSO_STREAM
@@ -2797,6 +2848,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         NDTPSO_PB(3);
       }
       int slot = (int)(grp % 3u), hi_g = P;
+      [[maybe_unused]] bool spec_made = false;  // this round made the next iteration's proposals both ways (SpecP)
 #if NDTPSO_STREAM
       if constexpr (kStream) {
         // ---- a phase: every particle not yet committed, dealt by ticket (eval_stream) ----
@@ -2888,9 +2940,20 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         hi_g = min(lo + ps.G, P);
         // a cluster draws the next iteration's numbers behind the first exchange of this one (eval_round)
         const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
+        // a cluster whose round is the whole iteration, with the next draws in its table: both next proposals of every
+        // coordinate are made during the exchange (SpecP)
+        [[maybe_unused]] SpecP spec{nullptr, nullptr, 0., 0., 0., nullptr};
+        if constexpr (CLUSTER) {
+          if (cl.spec && !gen && lo == 0 && hi_g == P && it + 1 < ps.I && blockDim.x > (unsigned)kWave) {
+            // (the next iteration's draws: in the other LDS buffer when the table is prefetched, else where the table lies)
+            spec = SpecP{cl.spec, prefetch ? ((it & 1) ? sw.raw : sw.raw2) : table + 3 * S + (size_t)(it + 1) * 6 * P,
+                         sh->k_w * ps.wdamp, sh->k_c1, sh->k_c2, sh->gb};
+            spec_made = true;
+          }
+        }
         eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
                                         &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
-                                        dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w);
+                                        dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w, CLUSTER ? &spec : nullptr);
         if (gen_here) next_filled = n_draw;
         NDTPSO_PB(4);
         if constexpr (!CLUSTER) {
@@ -2961,6 +3024,82 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         sh->near_cnt[(grp + 2u) % 3u] = 0;
       }
       ++grp;
+      if constexpr (CLUSTER) {
+        if (spec_made && js >= P) {
+          // No gbest move in a round that was the whole iteration: commit (core.cpp:94-96) and take, per particle, the one
+          // of the two ready-made next proposals its comparison selects (SpecP).  One thread per (particle, coordinate);
+          // the pbest COST is written behind the barrier below, by the lanes of wave 0 that hold the comparison -- the
+          // particle's other threads compare against it now, and the next reader is wave 0 itself (eval_round).
+          for (int q = tid; q < 3 * P; q += blockDim.x) {
+            const int j = q < P ? q : (q - P) >> 1, k = q < P ? 2 : ((q - P) & 1);
+            const double cst = sw.tcost[j];
+            const bool better = cst < sw.pbc[j];  // core.cpp:94
+            const int c = better ? 0 : 1;
+            const double np = sw.tpos[k * S + j], nv = sw.tvel[k * S + j];
+            const double v2 = spec_vel(cl.spec, S, c, k)[j], p2 = spec_pos(cl.spec, S, c, k)[j];
+            [[maybe_unused]] double hc = 0., hs = 0., cn = 0., sn = 0.;
+            if (k == 2) {
+              cn = spec_cs(cl.spec, S, c, 0)[j];
+              sn = spec_cs(cl.spec, S, c, 1)[j];
+              if constexpr (ARB) {
+                hc = sw.pcs[j];
+                hs = sw.pcs[S + j];
+              }
+            }
+            sw.pos[k * S + j] = np;
+            sw.vel[k * S + j] = nv;
+            if (better) sw.pb[k * S + j] = np;
+            sw.tvel[k * S + j] = v2;
+            sw.tpos[k * S + j] = p2;
+            if (k == 2) {
+              sw.it[4 * j] = cn;
+              sw.it[4 * j + 1] = sn;
+              if constexpr (ARB) {
+                if (better) {
+                  sw.bcs[j] = hc;
+                  sw.bcs[S + j] = hs;
+                  bool exact_j = false;
+                  const int arb_n = sh->near_cnt[slot];
+                  for (int t = 0; t < arb_n; ++t) exact_j |= (int)sh->near_list[slot][t] == j;
+                  sw.pex[j] = exact_j ? 1 : 0;
+                }
+                sw.pcs[j] = cn;
+                sw.pcs[S + j] = sn;
+              }
+            }
+          }
+          // wave 0: the comparisons again, for the pbest costs it stores behind the barrier
+          double keep[4];
+          bool take[4] = {false, false, false, false};
+          if (wave_id() == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int j = lane_id() + i * kWave;
+              if (j < P) {
+                keep[i] = sw.tcost[j];
+                take[i] = keep[i] < sw.pbc[j];
+              }
+            }
+          }
+          if (prefetch && it + 2 < ps.I) {  // this iteration's buffer is free: the draws of the one after the next
+            if (tid < 6 * P) pbuf[tid] = pre0;
+            if (tid + (int)blockDim.x < 6 * P) pbuf[tid + blockDim.x] = pre1;
+          }
+          if (tid == 0) sh->k_w *= ps.wdamp;  // core.cpp:108
+          __syncthreads();
+          if (wave_id() == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int j = lane_id() + i * kWave;
+              if (j < P && take[i]) sw.pbc[j] = keep[i];
+            }
+          }
+          NDTPSO_PB(11);
+          pre_proposed = true;  // (the iteration is over: its end below is skipped as well)
+          lo = P;
+          continue;
+        }
+      }
       const int last = (js < hi_g) ? js : (hi_g - 1);  // (js >= hi_g: P, no improver)
       // exact mode: items of this round whose costs the arbitration replaced by fp64 scores (what a pbest / the gbest
       // that takes such a cost over inherits: Swarm::pex, ExactArgs::gex)
@@ -3034,9 +3173,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       NDTPSO_PSO_MARK(3);
       NDTPSO_PB(8);
     }
-    if (prefetch && it + 1 < ps.I) {  // every proposal of this iteration has read its draws (barriers above)
-      if (tid < 6 * P) sw.raw[tid] = pre0;
-      if (tid + (int)blockDim.x < 6 * P) sw.raw[tid + blockDim.x] = pre1;
+    if (pre_proposed) continue;  // (a cluster's round that committed and proposed in one step has done all of this)
+    if (prefetch && it + 2 < ps.I) {  // every proposal of this iteration has read its draws (barriers above)
+      if (tid < 6 * P) pbuf[tid] = pre0;
+      if (tid + (int)blockDim.x < 6 * P) pbuf[tid + blockDim.x] = pre1;
     }
     if (tid == 0) sh->k_w *= ps.wdamp;  // core.cpp:108 (every proposal of this iteration has read it: barriers above)
     __syncthreads();  // all commits of this iteration done before the next draws/proposals
@@ -3066,10 +3206,11 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #endif
 #ifdef NDTPSO_PHASE_BUDGET
   NDTPSO_PB(10);
-  if (!CLUSTER && blockIdx.x < kBudgetMaxBlocks) {
-    unsigned* o = g_budget + (size_t)blockIdx.x * 16;
+  // (a cluster: its first workgroup's account in entry 0 -- scripts/cluster_budget.py; 11 = the commit-and-pick steps, SpecP)
+  if ((!CLUSTER && blockIdx.x < kBudgetMaxBlocks) || (CLUSTER && cl.rank == 0)) {
+    unsigned* o = g_budget + (CLUSTER ? (size_t)0 : (size_t)blockIdx.x * 16);
     if (tid == 0)
-      for (int k = 1; k <= 10; ++k) o[k] = (unsigned)pb_t[k];
+      for (int k = 1; k <= 11; ++k) o[k] = (unsigned)pb_t[k];
     if (tid == 64) {
       o[12] = (unsigned)pb_t[4];
       o[13] = (unsigned)pb_t[5];

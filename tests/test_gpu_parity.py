@@ -482,17 +482,22 @@ def test_cluster_of_workgroups_matches_one_workgroup(ctx, oracle, pairs8, monkey
                 want = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, mode=mode, **kw)
                 # (the last shape with the cluster's workgroups where consecutive ones land, on all eight XCDs, instead of
                 # on one XCD: ClusterP::one_xcd is placement only)
-                for shape in (None, ("2", "1"), ("5", "3"), ("32", "4"), ("7", "16"), ("9", "4", "spread")):
+                # and one without the ready-made next proposals a cluster otherwise makes during its exchanges (SpecP: they
+                # are what the host-table runs of every other shape go through)
+                for shape in (None, ("2", "1"), ("5", "3"), ("32", "4"), ("7", "16"), ("9", "4", "spread"), ("8", "4", "nospec")):
                     if shape is None:
                         monkeypatch.delenv("NDTPSO_CLUSTER")
                         monkeypatch.delenv("NDTPSO_CLUSTER_WAVES", raising=False)
                     else:
                         monkeypatch.setenv("NDTPSO_CLUSTER", shape[0])
                         monkeypatch.setenv("NDTPSO_CLUSTER_WAVES", shape[1])
-                        if len(shape) > 2:
+                        if len(shape) > 2 and shape[2] == "spread":
                             monkeypatch.setenv("NDTPSO_CLUSTER_SPREAD", "1")
+                        if len(shape) > 2 and shape[2] == "nospec":
+                            monkeypatch.setenv("NDTPSO_CLUSTER_SPEC", "0")
                     got = ctx.align(xy, (0, 0, 0), DEVIATION, cfg, mode=mode, **kw)
                     monkeypatch.delenv("NDTPSO_CLUSTER_SPREAD", raising=False)
+                    monkeypatch.delenv("NDTPSO_CLUSTER_SPEC", raising=False)
                     assert np.array_equal(got[0], want[0]) and got[1] == want[1], (P, I, mode, shape)
                     assert got[2]["gbest_updates"] == want[2]["gbest_updates"] and got[2]["status"] == want[2]["status"]
                 monkeypatch.delenv("NDTPSO_CLUSTER_WAVES", raising=False)
