@@ -1685,13 +1685,13 @@ static uint32_t next_cluster_nonce(ndtpso_ctx* c) {
 }
 
 // Room behind a cluster workgroup's LDS layout for the two ready-made next proposals of every coordinate (SpecP:
-// 16 (P + 1) doubles), where it fits and the swarm is small enough for wave 0 to hold its comparisons (four per lane);
+// 16 (P + 1) doubles), where it fits and the swarm is small enough for wave 0 to hold its comparisons (one per lane);
 // NDTPSO_CLUSTER_SPEC=0 leaves it out (the usual commit and proposal steps: same results)
 static void cluster_spec_room(int P, int* lds_total, ClusterP* cl) {
   const char* e = std::getenv("NDTPSO_CLUSTER_SPEC");
   if (e && e[0] == '0') return;
   const int at = round_up(*lds_total, 16), bytes = 16 * (P + 1) * 8;
-  if (P > 4 * kWave || at + bytes > kMaxLds) return;
+  if (P > kWave || at + bytes > kMaxLds) return;
   cl->spec_off = at;
   *lds_total = at + bytes;
 }

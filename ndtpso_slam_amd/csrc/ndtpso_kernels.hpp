@@ -3028,24 +3028,32 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         if (spec_made && js >= P) {
           // No gbest move in a round that was the whole iteration: commit (core.cpp:94-96) and take, per particle, the one
           // of the two ready-made next proposals its comparison selects (SpecP).  One thread per (particle, coordinate);
-          // the pbest COST is written behind the barrier below, by the lanes of wave 0 that hold the comparison -- the
-          // particle's other threads compare against it now, and the next reader is wave 0 itself (eval_round).
+          // the pbest COST is written behind the barrier below, by the heading's thread -- lane j of wave 0: the particle's
+          // other threads compare against the old one now, and the next reader is wave 0 itself (eval_round).
+          double keep = 0.;
+          bool take = false;
           for (int q = tid; q < 3 * P; q += blockDim.x) {
             const int j = q < P ? q : (q - P) >> 1, k = q < P ? 2 : ((q - P) & 1);
-            const double cst = sw.tcost[j];
-            const bool better = cst < sw.pbc[j];  // core.cpp:94
-            const int c = better ? 0 : 1;
+            // (both ready-made proposals are read with everything else -- one trip to LDS -- and one is kept)
+            const double cst = sw.tcost[j], pbj = sw.pbc[j];
             const double np = sw.tpos[k * S + j], nv = sw.tvel[k * S + j];
-            const double v2 = spec_vel(cl.spec, S, c, k)[j], p2 = spec_pos(cl.spec, S, c, k)[j];
+            const double vA = spec_vel(cl.spec, S, 0, k)[j], vB = spec_vel(cl.spec, S, 1, k)[j];
+            const double pA = spec_pos(cl.spec, S, 0, k)[j], pB = spec_pos(cl.spec, S, 1, k)[j];
             [[maybe_unused]] double hc = 0., hs = 0., cn = 0., sn = 0.;
+            const bool better = cst < pbj;  // core.cpp:94
             if (k == 2) {
-              cn = spec_cs(cl.spec, S, c, 0)[j];
-              sn = spec_cs(cl.spec, S, c, 1)[j];
+              const double cA = spec_cs(cl.spec, S, 0, 0)[j], cB = spec_cs(cl.spec, S, 1, 0)[j];
+              const double sA = spec_cs(cl.spec, S, 0, 1)[j], sB = spec_cs(cl.spec, S, 1, 1)[j];
+              cn = better ? cA : cB;
+              sn = better ? sA : sB;
               if constexpr (ARB) {
                 hc = sw.pcs[j];
                 hs = sw.pcs[S + j];
               }
+              keep = cst;  // (j == q == tid here: swarms of up to 64 particles, cluster_spec_room -- a lane of wave 0)
+              take = better;
             }
+            const double v2 = better ? vA : vB, p2 = better ? pA : pB;
             sw.pos[k * S + j] = np;
             sw.vel[k * S + j] = nv;
             if (better) sw.pb[k * S + j] = np;
@@ -3068,32 +3076,13 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
               }
             }
           }
-          // wave 0: the comparisons again, for the pbest costs it stores behind the barrier
-          double keep[4];
-          bool take[4] = {false, false, false, false};
-          if (wave_id() == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int j = lane_id() + i * kWave;
-              if (j < P) {
-                keep[i] = sw.tcost[j];
-                take[i] = keep[i] < sw.pbc[j];
-              }
-            }
-          }
           if (prefetch && it + 2 < ps.I) {  // this iteration's buffer is free: the draws of the one after the next
             if (tid < 6 * P) pbuf[tid] = pre0;
             if (tid + (int)blockDim.x < 6 * P) pbuf[tid + blockDim.x] = pre1;
           }
           if (tid == 0) sh->k_w *= ps.wdamp;  // core.cpp:108
           __syncthreads();
-          if (wave_id() == 0) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int j = lane_id() + i * kWave;
-              if (j < P && take[i]) sw.pbc[j] = keep[i];
-            }
-          }
+          if (take) sw.pbc[tid] = keep;
           NDTPSO_PB(11);
           pre_proposed = true;  // (the iteration is over: its end below is skipped as well)
           lo = P;
