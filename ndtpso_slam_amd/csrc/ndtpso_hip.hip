@@ -674,7 +674,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   } else {
     if constexpr (SWARM != 1) {
       const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
-      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+      // (SWARM == 0: the batches' kernels, whose layout always carries the arbitration's unit scratch -- make_layout)
+      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, false, (SWARM == 0 && ARB && !CLUSTER)>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                                            tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
                                            out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
     }

@@ -2027,9 +2027,11 @@ __device__ __forceinline__ void exact_task_body(const ExactArgs* ap, unsigned tk
 template <bool BYTE>
 __device__ __attribute__((noinline, cold)) void exact_task_call(const ExactArgs* ap, unsigned tk) { exact_task_body<BYTE>(ap, tk); }
 
-template <bool BYTE, bool INL = false>
+// UNITS: the kernel's launches always come with the units' scratch (the fused pairs kernels that keep the swarm in LDS): the
+// whole-task form -- and with it exact_task_call, whose frame was two thirds of those kernels' scratch memory -- is left out.
+template <bool BYTE, bool INL = false, bool UNITS = false>
 __device__ __forceinline__ void exact_tasks_wg(ExactArgs* ap, const unsigned short* list, int cnt, int kind) {
-  if (INL || ap->xs_slots == 0) {  // (xs_slots: uniform, set once by enable_arbitration)
+  if (!UNITS && (INL || ap->xs_slots == 0)) {  // (xs_slots: uniform, set once by enable_arbitration)
     // A cluster's workgroups have four waves (one per SIMD).  A whole score per wave, all of them at once, is as quick
     // there as the split into units (three scores are twelve units, three per wave), and it needs neither the work list
     // nor the second barrier: task slot t is fixed -- kind 0: the proposal of item t; kind 1: 2q the proposal and 2q + 1
@@ -2532,7 +2534,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
 // ARB: the exact mode (NDTPSO_SCORE_EXACT) of the fp32-score dense kernels.  A template parameter, not a run-time
 // switch: the arbitration code in the same kernel cost the plain fp32 mode 11 % (register pressure: spills in the
 // proposal / commit paths), see DESIGN.md.
-template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false, bool KGEN = false>
+template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false, bool KGEN = false, bool UNITS = false>
 __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
@@ -2664,7 +2666,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         return false;
       }
       if (__builtin_expect(cnt > 1, 0)) {  // (cold: the register allocator must not charge the evaluation loops for it)
-        exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[0], cnt, 0);
+        exact_tasks_wg<PATH == 3, CLUSTER, UNITS>(&sh->xa, sh->near_list[0], cnt, 0);
         n_arb += (uint32_t)cnt;
       }
     }
@@ -2899,7 +2901,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
               return false;
             }
             if (cnt != 0) {
-              exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[slot], cnt, 1);
+              exact_tasks_wg<PATH == 3, CLUSTER, UNITS>(&sh->xa, sh->near_list[slot], cnt, 1);
               if (tid == 0) {
                 if (sh->xa.gb_task) sh->gbc = sh->xgbc;  // (else it is the fp64 score of the gbest position already)
                 sh->jstar[slot] = P;  // (stays P: no improver among the established items -- the phase goes on behind them)
@@ -2994,7 +2996,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
               }
               // fp64 scores of the undecidable items' proposals and pbest positions and of the gbest position replace
               // the stored costs; the group's first improver is then looked for again (core.cpp:94-104, nested tests)
-              exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, sh->near_list[slot], cnt, 1);
+              exact_tasks_wg<PATH == 3, CLUSTER, UNITS>(&sh->xa, sh->near_list[slot], cnt, 1);
               if (tid == 0) {
                 if (sh->xa.gb_task) sh->gbc = sh->xgbc;  // (else it is the fp64 score of the gbest position already)
                 int first = P;
@@ -3188,7 +3190,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
 #ifndef NDTPSO_NO_FINAL_EXACT
   if constexpr (ARB) {
     if (out_cost) {  // exact mode: the returned cost is the fp64 score of the returned pose (what the fp64 mode holds);
-      exact_tasks_wg<PATH == 3, CLUSTER>(&sh->xa, nullptr, 0, 2);  // a caller that takes the pose only (NDTFrame::align) has
+      exact_tasks_wg<PATH == 3, CLUSTER, UNITS>(&sh->xa, nullptr, 0, 2);  // a caller that takes the pose only (NDTFrame::align) has
       exact_cost = true;                                           // passed no cost pointer and is spared the score
     }
   }
