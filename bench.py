@@ -477,7 +477,7 @@ def _pmc_traffic_bytes():
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 per the
     gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE; separate --pmc runs, scripts/pmc.sh).  A profile of
     THIS workload measured on MI355X, not collected live (rocprofv3 cannot wrap the timed run); null if absent."""
-    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         d = _load_json(name)
         try:
             d = d["derived"]
