@@ -3164,6 +3164,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       NDTPSO_PSO_MARK(3);
       NDTPSO_PB(8);
     }
+    NDTPSO_PB(5);
     if (pre_proposed) continue;  // (a cluster's round that committed and proposed in one step has done all of this)
     if (prefetch && it + 2 < ps.I) {  // every proposal of this iteration has read its draws (barriers above)
       if (tid < 6 * P) pbuf[tid] = pre0;

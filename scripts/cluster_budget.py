@@ -36,7 +36,7 @@ for k in range(n):
     rmap.insert(scan, prev)
 a = np.mean(acc, axis=0)
 names = {1: "swarm initialisation", 2: "top of iteration", 3: "proposal steps + barrier", 4: "thread 0: evaluation + exchange (poll)",
-         5: "-", 6: "thread 0: wait at the round's barrier", 7: "arbitration", 8: "commit steps + gbest barriers", 9: "end of iteration",
+         5: "between the last round and the end of the iteration", 6: "thread 0: wait at the round's barrier", 7: "arbitration", 8: "commit steps + gbest barriers", 9: "end of iteration",
          10: "final cost", 11: "commit-and-pick steps (SpecP)", 12: "thread 64: evaluation (+ the next proposals)", 14: "thread 64: wait at the round's barrier"}
 print("mean over %d alignments, us (rounds %.1f, gbest moves %.1f):" % (len(acc), a[16], a[17]))
 for k in sorted(names):
