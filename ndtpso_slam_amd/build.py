@@ -23,7 +23,8 @@ LIB = os.path.join(LIB_DIR, "libndtpso_hip.so")
 # seen to write instead of the calling convention's.  Six builds of the round-4 sources made that way returned the same
 # wrong poses from the arbitration's unit form on swarms kept in HBM (7 of 130 pairs, any workgroup size); the same six
 # sources without IPRA, and every other build without it, are right (NOTEBOOK, "The unit form on swarms kept in HBM";
-# tests/test_gpu_fullsize.py::test_unit_form_on_swarms_kept_in_hbm).  Cost: 4 % of the exact kernel on config 3.
+# tests/test_gpu_fullsize.py::test_unit_form_on_swarms_kept_in_hbm).  Cost: 4 % of the exact kernel when the switch was made,
+# nothing measurable on the round's final kernels.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
          "-mllvm", "-enable-ipra=0", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
