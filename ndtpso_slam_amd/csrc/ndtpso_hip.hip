@@ -583,6 +583,18 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   __syncthreads();
   NDTPSO_SETUP_MARK(1);
   DenseGuard guard{1., 0., 1., 0.};  // (empty: every pose takes the clamped loop)
+  if constexpr (MODE == kScoreF64 && !path_is_dense(PATH) && !CLUSTER) {
+    // fp64 score, bitmap form: scan B's points lie within rho of the sensor, so a pose whose translation keeps that disc
+    // strictly inside the frame AND inside the table's window needs none of the per-point frame / window / wrap tests
+    // (score_trip<..., GUARD>) -- the translations of such poses, in metres, are the guard's box (empty if there is none)
+    const float rho = scan_max_range_wg(new_ranges + b * sp.n_beams, sp, lds_cnt(L.ctrl_off) + 30);
+    if (rho > 0.f) {
+      const double rr = (double)rho * (1. + 1e-9) + 1e-6 * g.cs;  // rounding of the transform included
+      const double x_lo = fmax(-g.hw, (double)wn.x0 * g.cs - g.hw) + rr, x_hi = fmin(g.hw, (double)(wn.x0 + wn.w) * g.cs - g.hw) - rr;
+      const double y_lo = fmax(-g.hh, (double)wn.y0 * g.cs - g.hh) + rr, y_hi = fmin(g.hh, (double)(wn.y0 + wn.h) * g.cs - g.hh) - rr;
+      if (x_lo < x_hi && y_lo < y_hi) guard = DenseGuard{x_lo, x_hi, y_lo, y_hi};
+    }
+  }
   if constexpr (path_is_dense(PATH)) {
     wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
     if constexpr (!CLUSTER) {

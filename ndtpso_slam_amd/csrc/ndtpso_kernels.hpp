@@ -377,10 +377,14 @@ __device__ __forceinline__ void cell_coords_rt(const GridP& g, double qx, double
 // The body is branch-free (misses read slot 0 and are masked) and written phase by phase over U
 // points per lane, so the three dependent LDS round trips of U independent points overlap.
 // Returns the cost (-sum) on every lane.
-template <int MODE, bool POW2, int U, bool DUMP>
+// GUARD: the caller has established that every point of these chunks lands strictly inside the frame and inside the
+// table's window under this pose (DenseGuard in metres, fp64 score of the batches): the frame, wrap and window tests go,
+// nothing else changes, so the terms are the tested form's bit for bit.  Only for chunks without padding.
+template <int MODE, bool POW2, int U, bool DUMP, bool GUARD = false>
 __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const TableView& T,
                                            const double2* __restrict__ pts, int base, int n, double c, double s,
                                            double tx, double ty, double (&acc)[4], int32_t* __restrict__ dump) {
+  static_assert(!(GUARD && DUMP), "the guarded form has no cell dump");
   const int lane = lane_id();
   double2 p[U];
 #pragma unroll
@@ -399,6 +403,12 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
       qx[u] = fma(p[u].x, c, fma(-p[u].y, s, tx));
       qy[u] = fma(p[u].x, s, fma(p[u].y, c, ty));
     }
+    if constexpr (GUARD) {
+      int ix, iy;
+      cell_coords<POW2>(g, qx[u], qy[u], ix, iy);
+      ok[u] = true;
+      lin[u] = __umul24((unsigned)(iy - wn.y0), (unsigned)wn.w) + (unsigned)(ix - wn.x0);
+    } else {
     const bool inframe = (int)(fabs(qx[u]) < g.hw) & (int)(fabs(qy[u]) < g.hh);  // strict bounds, ndtframe.cpp:242
     int ix, iy;
     cell_coords<POW2>(g, qx[u], qy[u], ix, iy);
@@ -410,6 +420,7 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
     const unsigned rx = (unsigned)(ix - wn.x0), ry = (unsigned)(iy - wn.y0);
     ok[u] = (int)inframe & (int)(rx < (unsigned)wn.w) & (int)(ry < (unsigned)wn.h);
     lin[u] = ok[u] ? __umul24(ry, (unsigned)wn.w) + rx : 0u;
+    }
   }
 
   unsigned long long e[U];
@@ -769,7 +780,7 @@ __device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const Den
 }
 
 // pts must be padded to a multiple of kPointPad with out-of-frame sentinels (pad_points_wg)
-template <int MODE, bool POW2, bool DUMP>
+template <int MODE, bool POW2, bool DUMP, bool GUARD = false>
 __device__ __forceinline__ double eval_pose_wave_t(const GridP& g, const WinP& wn, const TableView& T,
                                                    const double2* __restrict__ pts, int n, double c, double s,
                                                    double tx, double ty, int32_t* __restrict__ dump) {
@@ -777,6 +788,9 @@ __device__ __forceinline__ double eval_pose_wave_t(const GridP& g, const WinP& w
   double acc[4] = {0., 0., 0., 0.};
   const int n_pad = round_up(n, kWave);
   int base = 0;
+  if constexpr (GUARD)  // (the same trips in the same order: the guarded form wherever a trip holds no padding)
+    for (; base + U * kWave <= n; base += U * kWave)
+      score_trip<MODE, POW2, U, false, true>(g, wn, T, pts, base, n, c, s, tx, ty, acc, dump);
   for (; base + U * kWave <= n_pad; base += U * kWave)
     score_trip<MODE, POW2, U, DUMP>(g, wn, T, pts, base, n, c, s, tx, ty, acc, dump);
   for (; base < n_pad; base += kWave)
@@ -2158,7 +2172,14 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       }
     } else {
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
-      cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+      if constexpr (MODE == kScoreF64 && PATH < 4) {  // (fp64 score of the batches: the guard in metres, set with the proposal)
+        if (E.guard_lds && *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
+          cost = eval_pose_wave_t<MODE, (PATH & 3) == 1, false, true>(E.g, E.wn, E.T, pts, n, c, s, tx, ty, nullptr);
+        else
+          cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+      } else {
+        cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+      }
     }
 #ifdef NDTPSO_VERIFY_MARGIN
     if constexpr (ARB && (PATH == 2 || PATH == 3))
@@ -2271,7 +2292,14 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
       }
     } else {
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
-      cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+      if constexpr (MODE == kScoreF64 && PATH < 4) {  // (fp64 score of the batches: the guard in metres, set with the proposal)
+        if (E.guard_lds && *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
+          cost = eval_pose_wave_t<MODE, (PATH & 3) == 1, false, true>(E.g, E.wn, E.T, pts, n, c, s, tx, ty, nullptr);
+        else
+          cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+      } else {
+        cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
+      }
     }
 #ifdef NDTPSO_VERIFY_MARGIN
     if constexpr (ARB && (PATH == 2 || PATH == 3))
@@ -2627,6 +2655,11 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       } else {
         sw.it[4 * slot] = cn;
         sw.it[4 * slot + 1] = sn;
+        if constexpr (MODE == kScoreF64 && !CLUSTER) {  // (the fp64 score's guard, in metres: score_trip<..., GUARD>)
+          const double px = sw.tpos[slot], py = sw.tpos[S + slot];
+          sw.tgd[2 * slot] = (px >= sh->guard.x_lo && px < sh->guard.x_hi) ? 1 : 0;
+          sw.tgd[2 * slot + 1] = (py >= sh->guard.y_lo && py < sh->guard.y_hi) ? 1 : 0;
+        }
       }
     }
   }
@@ -2821,6 +2854,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           sw.tvel[k * S + j] = v;
           sw.tpos[k * S + j] = np;
           constexpr bool fold = path_is_dense(PATH) && !CLUSTER;
+          if constexpr (!fold && MODE == kScoreF64 && !CLUSTER) {  // (the fp64 score's guard, in metres)
+            if (k == 0) sw.tgd[2 * j] = (np >= sh->guard.x_lo && np < sh->guard.x_hi) ? 1 : 0;
+            if (k == 1) sw.tgd[2 * j + 1] = (np >= sh->guard.y_lo && np < sh->guard.y_hi) ? 1 : 0;
+          }
           if constexpr (fold) {  // each coordinate's share of the proposal's DenseItem (dense_item)
             if (k == 0) {
               const double TX = (np + sh->k_hw) * sh->k_inv - sh->k_ox;
