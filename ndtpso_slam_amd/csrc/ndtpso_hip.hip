@@ -586,7 +586,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if constexpr (MODE == kScoreF64 && !path_is_dense(PATH) && !CLUSTER) {
     // fp64 score, bitmap form: scan B's points lie within rho of the sensor, so a pose whose translation keeps that disc
     // strictly inside the frame AND inside the table's window needs none of the per-point frame / window / wrap tests
-    // (score_trip<..., GUARD>) -- the translations of such poses, in metres, are the guard's box (empty if there is none)
+    // (score_trip_guarded) -- the translations of such poses, in metres, are the guard's box (empty if there is none)
     const float rho = scan_max_range_wg(new_ranges + b * sp.n_beams, sp, lds_cnt(L.ctrl_off) + 30);
     if (rho > 0.f) {
       const double rr = (double)rho * (1. + 1e-9) + 1e-6 * g.cs;  // rounding of the transform included

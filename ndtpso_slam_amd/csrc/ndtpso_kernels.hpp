@@ -377,14 +377,10 @@ __device__ __forceinline__ void cell_coords_rt(const GridP& g, double qx, double
 // The body is branch-free (misses read slot 0 and are masked) and written phase by phase over U
 // points per lane, so the three dependent LDS round trips of U independent points overlap.
 // Returns the cost (-sum) on every lane.
-// GUARD: the caller has established that every point of these chunks lands strictly inside the frame and inside the
-// table's window under this pose (DenseGuard in metres, fp64 score of the batches): the frame, wrap and window tests go,
-// nothing else changes, so the terms are the tested form's bit for bit.  Only for chunks without padding.
-template <int MODE, bool POW2, int U, bool DUMP, bool GUARD = false>
+template <int MODE, bool POW2, int U, bool DUMP>
 __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const TableView& T,
                                            const double2* __restrict__ pts, int base, int n, double c, double s,
                                            double tx, double ty, double (&acc)[4], int32_t* __restrict__ dump) {
-  static_assert(!(GUARD && DUMP), "the guarded form has no cell dump");
   const int lane = lane_id();
   double2 p[U];
 #pragma unroll
@@ -403,12 +399,6 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
       qx[u] = fma(p[u].x, c, fma(-p[u].y, s, tx));
       qy[u] = fma(p[u].x, s, fma(p[u].y, c, ty));
     }
-    if constexpr (GUARD) {
-      int ix, iy;
-      cell_coords<POW2>(g, qx[u], qy[u], ix, iy);
-      ok[u] = true;
-      lin[u] = __umul24((unsigned)(iy - wn.y0), (unsigned)wn.w) + (unsigned)(ix - wn.x0);
-    } else {
     const bool inframe = (int)(fabs(qx[u]) < g.hw) & (int)(fabs(qy[u]) < g.hh);  // strict bounds, ndtframe.cpp:242
     int ix, iy;
     cell_coords<POW2>(g, qx[u], qy[u], ix, iy);
@@ -420,7 +410,6 @@ __device__ __forceinline__ void score_trip(const GridP& g, const WinP& wn, const
     const unsigned rx = (unsigned)(ix - wn.x0), ry = (unsigned)(iy - wn.y0);
     ok[u] = (int)inframe & (int)(rx < (unsigned)wn.w) & (int)(ry < (unsigned)wn.h);
     lin[u] = ok[u] ? __umul24(ry, (unsigned)wn.w) + rx : 0u;
-    }
   }
 
   unsigned long long e[U];
@@ -779,6 +768,90 @@ __device__ __forceinline__ double eval_pose_wave_dense(const GridP& g, const Den
   return eval_pose_wave_dense_c<DUMP, false, WIDE, BYTE>(g, dn, lds0, pts, n, c, s, tx, ty, dump);
 }
 
+__device__ __forceinline__ double uniform_f64(double v) {  // a value every lane holds, moved to scalar registers
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// The fp64 score's trip for a pose under the guard (DenseGuard in metres: every point of scan B lands strictly inside the
+// frame and inside the table's window), U chunks without padding, table in LDS.  The terms are score_trip's bit for bit;
+// what differs is how the integer side gets there:
+//   * power-of-two cell side: (q + hw) * inv_cs is fma(q, inv_cs, hw * inv_cs) -- scaling by a power of two commutes with
+//     the rounding of the sum (no overflow; a sum below 2^-1021 truncates to cell 0 either way), one instruction for two;
+//   * no frame / wrap / window tests, one subtraction for the window's origin;
+//   * the built bit comes out as a mask (v_bfe_i32, width 1) and goes into the exponent's high word with one v_bfi_b32:
+//     a miss scores exp(-65536 - something) = +0. exactly as exp(-inf) did (the library returns 0 below -745.2), a hit
+//     keeps its exponent untouched, NaN included; the bit-field instructions take the bit number from the low five bits
+//     of the cell's linear index themselves;
+//   * a miss reads the record its prefix count points at (<= n_built <= rec_cap: inside LDS, value unused) instead of
+//     selecting record 0, and every address is one v_lshl_add_u32.
+// 9 integer instructions per point for the lookup instead of 17, 2 fp64 ones fewer.
+template <bool POW2, int U>
+__device__ __forceinline__ void score_trip_guarded(const GridP& g, const WinP& wn, const TableView& T,
+                                                   const double2* __restrict__ pts, int base, double c, double s,
+                                                   double tx, double ty, double hwi, double hhi, double (&acc)[4]) {
+  typedef const unsigned long long __attribute__((address_space(3))) * lds_u64_t;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+  const unsigned bm_a = (unsigned)(uintptr_t)(const uint2 __attribute__((address_space(3)))*)T.bm;
+  const unsigned mean_a = (unsigned)(uintptr_t)(const double2 __attribute__((address_space(3)))*)T.mean;
+  const unsigned ab_a = (unsigned)(uintptr_t)(const double2 __attribute__((address_space(3)))*)T.ab;
+  const unsigned cd_a = (unsigned)(uintptr_t)(const double2 __attribute__((address_space(3)))*)T.cd;
+  const unsigned origin = (unsigned)(wn.y0 * wn.w + wn.x0);
+  const int lane = lane_id();
+  double2 p[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) p[u] = pts[base + u * kWave + lane];
+  double qx[U], qy[U];
+  unsigned lin[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    qx[u] = (p[u].x * c - p[u].y * s) + tx;  // reference rounding, no fma
+    qy[u] = (p[u].x * s + p[u].y * c) + ty;
+    int ix, iy;
+    if constexpr (POW2) {
+      ix = (int)fma(qx[u], g.inv_cs, hwi);  // hwi = hw * inv_cs, hhi = hh * inv_cs (exact)
+      iy = (int)fma(qy[u], g.inv_cs, hhi);
+    } else {
+      cell_coords<false>(g, qx[u], qy[u], ix, iy);
+    }
+    unsigned t;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(iy), "s"(wn.w), "v"(ix));
+    lin[u] = t - origin;
+  }
+  unsigned long long e[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    unsigned a;
+    asm("v_lshl_add_u32 %0, %1, 3, %2" : "=v"(a) : "v"(lin[u] >> 5), "s"(bm_a));
+    e[u] = *(lds_u64_t)(uintptr_t)a;
+  }
+  int hit[U];
+  v2d_t m[U], ab[U], cd[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned bits = (unsigned)e[u], pre = (unsigned)(e[u] >> 32);
+    unsigned below;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(hit[u]) : "v"(bits), "v"(lin[u]));   // -1: built
+    asm("v_bfe_u32 %0, %1, 0, %2" : "=v"(below) : "v"(bits), "v"(lin[u]));     // the bits below the cell's
+    const unsigned slot = pre + __popc(below);
+    unsigned a0, a1, a2;
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(a0) : "v"(slot), "s"(mean_a));
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(a1) : "v"(slot), "s"(ab_a));
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(a2) : "v"(slot), "s"(cd_a));
+    m[u] = *(lds_d2_t)(uintptr_t)a0;
+    ab[u] = *(lds_d2_t)(uintptr_t)a1;
+    cd[u] = *(lds_d2_t)(uintptr_t)a2;
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double d0 = qx[u] - m[u].x, d1 = qy[u] - m[u].y;
+    const double r0 = d0 * ab[u].x + d1 * cd[u].x;  // (diff^T * inv_covar), ndtcell.cpp:73-75
+    const double r1 = d0 * ab[u].y + d1 * cd[u].y;
+    const double x = -(r0 * d0 + r1 * d1) / 2.;
+    const int hi = (__double2hiint(x) & hit[u]) | ((int)0xC0F00000 & ~hit[u]);
+    acc[u] += exp(__hiloint2double(hi, __double2loint(x)));
+  }
+}
+
 // pts must be padded to a multiple of kPointPad with out-of-frame sentinels (pad_points_wg)
 template <int MODE, bool POW2, bool DUMP, bool GUARD = false>
 __device__ __forceinline__ double eval_pose_wave_t(const GridP& g, const WinP& wn, const TableView& T,
@@ -788,9 +861,12 @@ __device__ __forceinline__ double eval_pose_wave_t(const GridP& g, const WinP& w
   double acc[4] = {0., 0., 0., 0.};
   const int n_pad = round_up(n, kWave);
   int base = 0;
-  if constexpr (GUARD)  // (the same trips in the same order: the guarded form wherever a trip holds no padding)
+  static_assert(!GUARD || (MODE == kScoreF64 && !DUMP), "the guarded form is the fp64 score's, without cell dump");
+  if constexpr (GUARD) {  // (the same trips in the same order: the guarded form wherever a trip holds no padding)
+    const double hwi = uniform_f64(g.hw * g.inv_cs), hhi = uniform_f64(g.hh * g.inv_cs);  // wave-uniform: scalar registers
     for (; base + U * kWave <= n; base += U * kWave)
-      score_trip<MODE, POW2, U, false, true>(g, wn, T, pts, base, n, c, s, tx, ty, acc, dump);
+      score_trip_guarded<POW2, U>(g, wn, T, pts, base, c, s, tx, ty, hwi, hhi, acc);
+  }
   for (; base + U * kWave <= n_pad; base += U * kWave)
     score_trip<MODE, POW2, U, DUMP>(g, wn, T, pts, base, n, c, s, tx, ty, acc, dump);
   for (; base < n_pad; base += kWave)
@@ -2655,7 +2731,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       } else {
         sw.it[4 * slot] = cn;
         sw.it[4 * slot + 1] = sn;
-        if constexpr (MODE == kScoreF64 && !CLUSTER) {  // (the fp64 score's guard, in metres: score_trip<..., GUARD>)
+        if constexpr (MODE == kScoreF64 && !CLUSTER) {  // (the fp64 score's guard, in metres: score_trip_guarded)
           const double px = sw.tpos[slot], py = sw.tpos[S + slot];
           sw.tgd[2 * slot] = (px >= sh->guard.x_lo && px < sh->guard.x_hi) ? 1 : 0;
           sw.tgd[2 * slot + 1] = (py >= sh->guard.y_lo && py < sh->guard.y_hi) ? 1 : 0;
