@@ -99,17 +99,17 @@ def _addr(line: str):
     return int(m.group(1), 16) if m else None
 
 
-def find_trips(body: list[str]):
+def find_trips(body: list[str], marker: str = "v_exp_f32", span: int = 8):
     """Innermost loops containing four consecutive v_exp_f32: [(first line, last line)], by their backward branch
     (llvm-objdump prints a branch as a signed word offset and every instruction's address in its trailing comment)."""
     ins = [(i, l.strip(), _addr(l)) for i, l in enumerate(body) if l.strip() and _addr(l) is not None]
     by_addr = {a: i for i, _, a in ins}
-    exp_pos = [k for k, (_, t, _) in enumerate(ins) if t.startswith("v_exp_f32")]
+    exp_pos = [k for k, (_, t, _) in enumerate(ins) if t.startswith(marker)]
     trips, k = [], 0
     while k + 3 < len(exp_pos):
-        if exp_pos[k + 3] - exp_pos[k] <= 8:   # four in a row (a few scalar instructions may sit between them)
+        if exp_pos[k + 3] - exp_pos[k] <= span:   # four in a row (a few scalar instructions may sit between them)
             first = ins[exp_pos[k]][2]
-            for q in range(exp_pos[k + 3] + 1, min(len(ins), exp_pos[k + 3] + 80)):
+            for q in range(exp_pos[k + 3] + 1, min(len(ins), exp_pos[k + 3] + 80 + span)):
                 i, t, a = ins[q]
                 m = re.match(r"s_cbranch_\w+\s+(\d+)", t)
                 if m:
@@ -187,11 +187,14 @@ def main():
     ap.add_argument("--ubench", default=os.path.join(ROOT, "profiles", "r02_ubench_valu.txt"))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_isa_mix.json"))
     ap.add_argument("--dump", default=os.path.join(ROOT, "profiles", "r02_score_loop_isa.txt"))
+    ap.add_argument("--marker", default="v_exp_f32", help="the instruction a four-chunk trip holds four of (fp64-score kernels: v_ldexp_f64, "
+                    "the tail of the library exp)")
+    ap.add_argument("--marker-span", type=int, default=8, help="the four lie within this many instructions of each other (fp64: 60)")
     args = ap.parse_args()
 
     lines = disassemble(extract_code_object(args.lib))
     body = kernel_body(lines, args.kernel)
-    trips = find_trips(body)
+    trips = find_trips(body, args.marker, args.marker_span)
     if not trips:
         raise SystemExit("no four-chunk score trip found in " + args.kernel)
     def insns(a, b):

@@ -4,6 +4,7 @@ SRC=gpurun_out/$1; P=profiles/$2
 mkdir -p ${P}_pmc
 cp $SRC/bench.json ${P}_bench.json
 cp $SRC/bench_one_at_a_time.json ${P}_bench_one_at_a_time.json
+for sc in f64 f32; do [ -f $SRC/bench_$sc.json ] && cp $SRC/bench_$sc.json ${P}_bench_$sc.json; done
 cp $SRC/ubench_valu.txt ${P}_ubench_valu.txt
 cp $SRC/isa_mix.json ${P}_isa_mix.json
 cp $SRC/score_loop_isa.txt ${P}_score_loop_isa.txt

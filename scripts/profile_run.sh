@@ -12,6 +12,8 @@ python scripts/isa_mix.py --kernel "k_align_pairs<0, 3, false, true, true, 0>" -
 cp $OUT/isa_mix.json profiles/r04_isa_mix.json   # the bench line's roofline.floor reads it
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --pipeline 1 --no-latency --cpu-sample 0 > $OUT/bench_one_at_a_time.json 2>> $OUT/bench.err
+# the other two score modes of the same workload (fp64 score throughout; plain fp32 score), two batches in flight and one at a time
+for sc in f64 f32; do timeout 300 python bench.py --score $sc --no-latency --cpu-sample 0 > $OUT/bench_$sc.json 2>> $OUT/bench.err; done
 # kernel traces (own runs): one batch at a time -- the per-launch duration the roofline divides by -- and two in flight
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace1 -o t -- python $GRAFT_REPO_ROOT/bench.py --pipeline 1 --steps 40 --warmup 20 --cpu-sample 0 --no-latency > $OUT/trace1.log 2>&1)
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o t -- python $GRAFT_REPO_ROOT/bench.py --pipeline 2 --steps 40 --warmup 20 --cpu-sample 0 --no-latency > $OUT/trace2.log 2>&1)
