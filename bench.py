@@ -279,7 +279,7 @@ def main():
             dt = time.perf_counter() - t1
             return {"alignments_per_s": n_pairs * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps, "pairs": n_pairs}
         modes = {}
-        for name, m, steps in (("f32", capi.SCORE_F32, 150), ("f64", capi.SCORE_F64, 60), ("exact", capi.SCORE_EXACT, 150)):
+        for name, m, steps in (("f32", capi.SCORE_F32, 300), ("f64", capi.SCORE_F64, 150), ("exact", capi.SCORE_EXACT, 300)):
             if m != mode:
                 modes[name] = timed(B, m, steps, geom, grid, cfg, d_ref, d_new, d_seeds)
         out["extra"]["modes"] = modes
