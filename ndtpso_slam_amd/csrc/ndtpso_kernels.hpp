@@ -2451,6 +2451,7 @@ __device__ unsigned long long g_phase_last;
 #ifdef NDTPSO_PHASE_BUDGET
 constexpr unsigned kBudgetMaxBlocks = 8192;
 __device__ unsigned g_budget[kBudgetMaxBlocks * 16];
+__device__ unsigned g_polls;  // a cluster's first workgroup: sweeps of the exchange's slots by its polling wave (entry 15)
 #define NDTPSO_PB_DECL                          \
   unsigned long long pb_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; \
   unsigned long long pb_last = wall_clock64()
@@ -2607,6 +2608,9 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
             ok = v.y == tag && v.w == tag;
             cost = __hiloint2double((int)v.z, (int)v.x);
           }
+#ifdef NDTPSO_PHASE_BUDGET
+          if (cl.rank == 0 && lane_id() == 0) atomicAdd(&g_polls, 1u);
+#endif
           if (__all(ok)) break;
           if (wall_clock64() - t0 > kClusterWaitTicks) {
             *timed_out = 1;
@@ -3314,8 +3318,13 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // (a cluster: its first workgroup's account in entry 0 -- scripts/cluster_budget.py; 11 = the commit-and-pick steps, SpecP)
   if ((!CLUSTER && blockIdx.x < kBudgetMaxBlocks) || (CLUSTER && cl.rank == 0)) {
     unsigned* o = g_budget + (CLUSTER ? (size_t)0 : (size_t)blockIdx.x * 16);
-    if (tid == 0)
+    if (tid == 0) {
       for (int k = 1; k <= 11; ++k) o[k] = (unsigned)pb_t[k];
+      if (CLUSTER) {
+        o[15] = g_polls;
+        g_polls = 0;
+      }
+    }
     if (tid == 64) {
       o[12] = (unsigned)pb_t[4];
       o[13] = (unsigned)pb_t[5];

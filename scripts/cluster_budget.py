@@ -42,3 +42,4 @@ print("mean over %d alignments, us (rounds %.1f, gbest moves %.1f):" % (len(acc)
 for k in sorted(names):
     if names[k] != "-": print("  %-50s %7.1f" % (names[k], a[k]))
 print("  sum of thread 0's phases %.1f" % a[1:12].sum())
+print("  sweeps of the exchange's slots by the polling wave: %.1f per alignment, %.2f per round" % (a[15] * 100, a[15] * 100 / a[16]))
