@@ -320,7 +320,8 @@ typedef struct {
   uint32_t lds_bytes;        /* dynamic LDS per workgroup (0 if the configuration does not fit) */
   uint32_t block_threads;    /* workgroup size */
   uint32_t workgroups_per_cu;/* by LDS and by the 16-waves-per-CU register budget */
-  uint32_t table_form;       /* 0 bitmap + true division, 1 bitmap + power-of-two cells, 2 dense u16 table */
+  uint32_t table_form;       /* 0 bitmap + true division, 1 bitmap + power-of-two cells, 2 dense u16 table (fp32 records),
+                                8 / 9 dense u16 table with fp64 records (fp64 score; true division / power-of-two cells) */
   uint32_t swarm_in_hbm;     /* 1: the swarm state lives in an HBM workspace instead of LDS */
   uint32_t window_w, window_h; /* staging window in cells */
   uint32_t table_bytes;      /* LDS bytes of the cell index + records */
@@ -368,6 +369,19 @@ int ndtpso_align_pairs_sharded_dev(ndtpso_shard_group *group, uint32_t n_pairs, 
 int ndtpso_shard_last_timing(const ndtpso_shard_group *group, double *per_device /* [G][3] or NULL */,
                              double *call /* [3] or NULL */);
 const double *ndtpso_shard_gathered(const ndtpso_shard_group *group, int index);
+
+/* ---- probes of the device arithmetic the parity claims rest on (tests/test_gpu_exp.py) --------------------------
+ * NDTCell::normalDistribution ends in exp() (ndtcell.cpp:76) and transform_point takes the cosine and sine of the pose's
+ * heading (core.h:28-31): on the device those are the ROCm math library's exp / sincos, and the fp64 score's own spelling
+ * of exp(-q / 2) (exp_neg_half, ndtpso_kernels.hpp: the library's operations without its two range guards).
+ * ndtpso_selftest_exp: for every binade b in [exp2_lo, exp2_hi], per_binade pseudo-random arguments x = -(1 + u) 2^b
+ * (positive != 0: +), the library's exp(x) against exp_neg_half(-2 x) bit for bit (two NaNs count as equal); returns the
+ * number checked, the number that differ and one differing argument (NaN if none).
+ * ndtpso_device_math: kind 0: out0 = exp(x) (library); 1: out0 = exp_neg_half(-2 x); 2: out0 = sin(x), out1 = cos(x) from
+ * one sincos(x) -- HOST pointers, n arguments. */
+int ndtpso_selftest_exp(ndtpso_ctx *ctx, int exp2_lo, int exp2_hi, uint32_t per_binade, uint32_t seed, int positive,
+                        uint64_t *checked, uint64_t *mismatched, double *first_bad);
+int ndtpso_device_math(ndtpso_ctx *ctx, int kind, const double *x, uint32_t n, double *out0, double *out1);
 
 #ifdef __cplusplus
 }

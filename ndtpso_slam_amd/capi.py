@@ -109,6 +109,7 @@ EXPORTS = [
     "ndtpso_shard_group_create", "ndtpso_shard_group_destroy", "ndtpso_shard_group_size", "ndtpso_shard_last_error",
     "ndtpso_shard_range", "ndtpso_align_pairs_sharded", "ndtpso_align_pairs_sharded_dev", "ndtpso_shard_last_timing",
     "ndtpso_shard_gathered",
+    "ndtpso_selftest_exp", "ndtpso_device_math",
 ]
 
 _lib = None
@@ -161,6 +162,9 @@ def load(build_if_missing: bool = True):
     L.ndtpso_align_pairs_describe.argtypes = [C.POINTER(ScanGeom), C.POINTER(Grid), C.POINTER(PSOConfig), C.c_int,
                                               C.c_uint32, C.POINTER(PairsPlan)]
     L.ndtpso_align_pairs_footprint.argtypes = [C.POINTER(ScanGeom), C.POINTER(Grid), C.POINTER(PSOConfig), up, up]
+    L.ndtpso_selftest_exp.argtypes = [vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint64), dp]
+    L.ndtpso_device_math.argtypes = [vp, C.c_int, dp, C.c_uint32, dp, dp]
     L.ndtpso_points_create.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     L.ndtpso_points_destroy.argtypes = [vp]
     L.ndtpso_points_destroy.restype = None
@@ -260,6 +264,22 @@ class Context:
 
     def pipeline_flush(self, keep_newest: int = 0):
         self._chk(self._lib.ndtpso_pipeline_flush(self._h, int(keep_newest)))
+
+    # ---- probes of the device arithmetic (tests/test_gpu_exp.py) ----
+    def selftest_exp(self, exp2_lo: int, exp2_hi: int, per_binade: int, seed: int = 1, positive: bool = False):
+        """(checked, mismatched, one differing argument or NaN): exp_neg_half against the library's exp on the device."""
+        n, bad, x = C.c_uint64(), C.c_uint64(), C.c_double()
+        self._chk(self._lib.ndtpso_selftest_exp(self._h, exp2_lo, exp2_hi, per_binade, seed, 1 if positive else 0,
+                                                C.byref(n), C.byref(bad), C.byref(x)))
+        return n.value, bad.value, x.value
+
+    def device_math(self, kind: str, x):
+        """'exp' / 'exp_neg_half' -> values; 'sincos' -> (sin, cos): the device's own arithmetic on x."""
+        x = _f64(x).ravel()
+        k = {"exp": 0, "exp_neg_half": 1, "sincos": 2}[kind]
+        o0, o1 = np.empty_like(x), np.empty_like(x)
+        self._chk(self._lib.ndtpso_device_math(self._h, k, _p(x, C.c_double), x.size, _p(o0, C.c_double), _p(o1, C.c_double)))
+        return (o0, o1) if k == 2 else o0
 
     # ---- K3 ----
     def scan_to_points(self, ranges, geom: ScanGeom, trans=(0.0, 0.0, 0.0)) -> np.ndarray:

@@ -29,12 +29,15 @@ constexpr int kCtrlBytes = 1440;     // control block (PsoShared + compaction co
 //   bitmap form: [ctrl | header | bitmap | mean | (ab | cd) | (chol) | points | region]
 //                header..chol are contiguous exactly as in the HBM image
 //   dense form : [u16 cell table @0 | ctrl | dense records (cap+1, blocks of 16 means + 16 factors) | header | points | region]
+//   dense form of the fp64 score: [ctrl | records (cap+1) x 48 B | u16 cell table | header | points | region]
+//                (records first: their LDS byte addresses are the table's u16 entries)
 //   region = max(table-build scratch {key, cellkey, cnt, bm2, plist, (bm)}, swarm)
 struct Layout {
   int ctrl_off, hdr_off, bm_off, mean_off, ab_off, cd_off, chol_off, drec_off, pts_off, region_off, total;
   int key_off, cellkey_off, cnt_off, bm2_off, plist_off;  // build scratch inside region
   int swarm_global;  // 1: the swarm does not fit in LDS and lives in an HBM workspace (large-swarm configs)
   int xs_off, xs_slots;  // exact mode: partial-sum scratch of the arbitration, xs_slots x 512 bytes (exact_tasks_wg); -1: none
+  int dtab_off;          // fp64 score on the dense table (PATH 8 / 9): the u16 cell table; -1: none
 };
 
 // fmt: kScoreF32 -> mean+chol, kScoreF64 -> mean+ab+cd, 2 -> everything (table build kernel);
@@ -43,12 +46,18 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
                    bool swarm_global = false, bool exact = false, bool exact_units = false) {
   Layout L;
   L.swarm_global = swarm_global ? 1 : 0;
-  const bool dense = ddw > 0;
-  int off = dense ? dense_tab_bytes(ddw, ddh) : 0;
+  const bool dense = ddw > 0, d64 = dense && fmt == kScoreF64;
+  int off = (dense && !d64) ? dense_tab_bytes(ddw, ddh) : 0;
   L.ctrl_off = off;
   off += kCtrlBytes;
   L.drec_off = -1;
-  if (dense) {
+  L.dtab_off = -1;
+  if (d64) {
+    L.drec_off = off;
+    off += align16(d64_rec_bytes(rec_cap + 1));
+    L.dtab_off = off;
+    off += dense_tab_bytes(ddw, ddh);
+  } else if (dense) {
     L.drec_off = off;
     off += dense_rec_bytes(rec_cap + 1);
   }
@@ -168,6 +177,7 @@ __device__ __forceinline__ EvalCtx make_eval_ctx(const GridP& g, const WinP& wn,
   E.lds0 = g_lds;
   E.light = 0;
   E.guard_lds = 0;
+  E.d64_tab = 0;
   return E;
 }
 
@@ -214,6 +224,7 @@ __device__ __forceinline__ EvalCtx make_eval_ctx_global(const GridP& g, const Wi
   E.lds0 = g_lds;
   E.light = 0;
   E.guard_lds = 0;
+  E.d64_tab = 0;
   return E;
 }
 
@@ -583,7 +594,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   __syncthreads();
   NDTPSO_SETUP_MARK(1);
   DenseGuard guard{1., 0., 1., 0.};  // (empty: every pose takes the clamped loop)
-  if constexpr (MODE == kScoreF64 && !path_is_dense(PATH) && !CLUSTER) {
+  if constexpr (MODE == kScoreF64 && !path_is_dense(PATH) && !path_is_dense64(PATH) && !CLUSTER) {
     // fp64 score, bitmap form: scan B's points lie within rho of the sensor, so a pose whose translation keeps that disc
     // strictly inside the frame AND inside the table's window needs none of the per-point frame / window / wrap tests
     // (score_trip_guarded) -- the translations of such poses, in metres, are the guard's box (empty if there is none)
@@ -635,6 +646,44 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
       return;
     }
   }
+  if constexpr (path_is_dense64(PATH)) {
+    // fp64 score on the dense table: the window is scan A's occupied box joined, where the provisioned table has room, with
+    // the box scan B's points can reach around the guess (as above); the guard is the bitmap form's, in metres -- the
+    // translations that keep scan B's disc strictly inside the frame and inside the window
+    static_assert(!path_is_dense64(PATH) || !CLUSTER, "PATH 8 / 9 run one workgroup per alignment");
+    wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
+    const float rho = scan_max_range_wg(new_ranges + b * sp.n_beams, sp, lds_cnt(L.ctrl_off) + 30);
+    const double rc = (double)rho / g.cs * (1. + 1e-9) + 1e-6;
+    const double cx = (guess[3 * b] + g.hw) / g.cs, cy = (guess[3 * b + 1] + g.hh) / g.cs;
+    constexpr double kMarginCells = 4.;
+    if (rho > 0.f && fabs(cx) < 1e6 && fabs(cy) < 1e6) {
+      const int bx0 = max((int)floor(cx - rc - kMarginCells), 0), bx1 = min((int)floor(cx + rc + kMarginCells), g.W - 1);
+      const int by0 = max((int)floor(cy - rc - kMarginCells), 0), by1 = min((int)floor(cy + rc + kMarginCells), g.H - 1);
+      if (bx1 >= bx0 && by1 >= by0) {
+        const int ux0 = min(wn.x0, bx0), uy0 = min(wn.y0, by0);
+        const int uw = max(wn.x0 + wn.w - 1, bx1) - ux0 + 1, uh = max(wn.y0 + wn.h - 1, by1) - uy0 + 1;
+        if (dense_entries(uw + 1, uh + 1) <= dense_cap) {
+          wn.x0 = ux0;
+          wn.y0 = uy0;
+          wn.w = uw;
+          wn.h = uh;
+          wn.n_words = (uw * uh + 31) / 32;
+        }
+      }
+      const double rr = (double)rho * (1. + 1e-9) + 1e-6 * g.cs;  // rounding of the transform included
+      const double x_lo = fmax(-g.hw, (double)wn.x0 * g.cs - g.hw) + rr, x_hi = fmin(g.hw, (double)(wn.x0 + wn.w) * g.cs - g.hw) - rr;
+      const double y_lo = fmax(-g.hh, (double)wn.y0 * g.cs - g.hh) + rr, y_hi = fmin(g.hh, (double)(wn.y0 + wn.h) * g.cs - g.hh) - rr;
+      if (x_lo < x_hi && y_lo < y_hi) guard = DenseGuard{x_lo, x_hi, y_lo, y_hi};
+    }
+    dn.dw = wn.w + 1;
+    dn.dh = wn.h + 1;
+    dn.ox = wn.x0 - 1;
+    dn.oy = wn.y0 - 1;
+    if (dense_entries(dn.dw, dn.dh) > dense_cap) {  // uniform
+      if (threadIdx.x == 0) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
+      return;
+    }
+  }
   NDTPSO_SETUP_MARK(2);
   // exact mode (ximg): the bitmap-form fp64 table goes to this workgroup's image in HBM as well
   unsigned char* my_ximg = nullptr;
@@ -650,7 +699,16 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
                  reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
                  reinterpret_cast<uint2*>(g_lds + L.bm2_off), reinterpret_cast<unsigned short*>(g_lds + L.plist_off),
-                 nullptr, nullptr, path_is_dense(PATH) ? &dn : nullptr, g_lds, PATH == 3, my_ximg ? &xout : nullptr);
+                 nullptr, nullptr, (path_is_dense(PATH) || path_is_dense64(PATH)) ? &dn : nullptr, g_lds, PATH == 3,
+                 my_ximg ? &xout : nullptr, path_is_dense64(PATH) ? L.dtab_off : -1);
+  if constexpr (path_is_dense64(PATH)) {
+    // a cell whose exponents exp_neg_half must not be trusted with (d64_cell_tame), or more built cells than records: the
+    // bitmap form's kernel, which calls the library's exp, takes the alignment
+    if (hdr->status & (kHdrWildCell | 2u)) {  // uniform (build_table_wg ends with a barrier)
+      if (threadIdx.x == 0) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
+      return;
+    }
+  }
   NDTPSO_SETUP_MARK(3);
   // new frame <- scan B (one-cell frame of the same size: the point list inside the frame, ndtpso_slam_node.cpp:229-230)
   const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
@@ -671,6 +729,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   EvalCtx E = make_eval_ctx(g, wn, L, dn);
   E.light = CLUSTER ? 0 : ps.light;
   E.guard_lds = (unsigned)(uintptr_t)(const DenseGuard __attribute__((address_space(3)))*)&lds_ctrl(L.ctrl_off)->guard;
+  if constexpr (path_is_dense64(PATH))
+    E.d64_tab = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)(g_lds + L.dtab_off);
   if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg, L);
 #ifdef NDTPSO_VERIFY_MARGIN
   if constexpr (ARB && !CLUSTER) E.xa = &lds_ctrl(L.ctrl_off)->xa;
@@ -694,7 +754,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   }
   if (threadIdx.x == 0 && writer) {
     stats[b].n_built = hdr->n_built;
-    stats[b].status |= hdr->status;
+    stats[b].status |= hdr->status & 3u;
     stats[b].t_start = t_start;
     stats[b].t_end = (uint32_t)wall_clock64();
 #ifdef NDTPSO_PHASE_BUDGET
@@ -1037,7 +1097,10 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
   const int bitmap_path = g.cs_pow2 ? 1 : 0;
   int force = -1;
   if (const char* e = std::getenv("NDTPSO_PATH")) force = std::atoi(e);  // tuning knob
-  const bool dense_ok = allow_dense && mode == kScoreF32 && force != 0 && force != 1;
+  // (fp64 score: the dense form exists in the fused pairs kernel only -- dynamic_window -- and needs every record below 64 KB)
+  const bool d64_ok = allow_dense && mode == kScoreF64 && dynamic_window && force != 0 && force != 1 &&
+                      kCtrlBytes + d64_rec_bytes(wn.rec_cap + 1) <= 65536;
+  const bool dense_ok = (allow_dense && mode == kScoreF32 && force != 0 && force != 1) || d64_ok;
   const bool force_global = allow_global && (force == 4 || force == 5);
   for (int swarm_global = 0; swarm_global < 2 && !force_global; ++swarm_global) {
     if (swarm_global && P <= 0) break;
@@ -1063,7 +1126,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         }
       }
       if (Ld.total <= kMaxLds) {
-        plan->path = 2;
+        plan->path = d64_ok ? (8 | bitmap_path) : 2;
         plan->L = Ld;
         plan->dn = make_dense(g, wn, Ld);
         plan->dense_cap = cap;
@@ -1161,6 +1224,8 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   BIG_PATHS(k_align_pairs, COMMA true)
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF64, 8, false>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF64, 9, false>);
   // exact mode (arbitrating variants of the fp32-score dense kernels)
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, true, true>);
@@ -1976,7 +2041,10 @@ int ndtpso_align_pairs_describe(const ndtpso_scan_geom* geom, const ndtpso_grid*
   out->table_form = (uint32_t)plan.path;
   out->swarm_in_hbm = (uint32_t)plan.L.swarm_global;
   out->workgroups_per_cu = (uint32_t)std::max(1, std::min(kMaxLds / plan.L.total, 16 / waves));
-  out->table_bytes = (uint32_t)(plan.L.pts_off - (plan.path == 2 ? 0 : plan.L.bm_off) - (plan.path == 2 ? kCtrlBytes + kImageHeaderBytes : 0));
+  if (path_is_dense64(plan.path))
+    out->table_bytes = (uint32_t)(plan.L.pts_off - plan.L.drec_off - kImageHeaderBytes);
+  else
+    out->table_bytes = (uint32_t)(plan.L.pts_off - (plan.path == 2 ? 0 : plan.L.bm_off) - (plan.path == 2 ? kCtrlBytes + kImageHeaderBytes : 0));
   return NDTPSO_OK;
 }
 
@@ -1985,22 +2053,25 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
                         const ndtpso_pso_config* cfg, const uint32_t* d_seeds, const int32_t* d_tables, int mode,
                         double* d_pose, double* d_cost, AlignStats* d_stats, uint32_t gate, bool allow_dense,
                         int* path_out, bool allow_cluster = false, bool exact = false) {
+  if (!cfg || cfg->population < 1) return fail(c, NDTPSO_E_ARG, "bad scan/grid/PSO configuration");
+  // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
+  int K = 1, cw = 4;
+  cluster_shape(cfg->population, true, allow_cluster && gate == 0, &K, &cw);
+  if (K > 1) K = std::min<int>(K, c->n_cus / (int)std::min<uint32_t>(n_pairs, (uint32_t)c->n_cus));
+  if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   GridP g;
   WinP wn;
   Plan plan;
   int waves = 0;
-  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves, allow_dense, (unsigned)c->n_cus, exact);
+  // (the fp64 score's dense form runs one workgroup per alignment: a cluster keeps the bitmap form)
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves,
+                            allow_dense && !(mode == NDTPSO_SCORE_F64 && K > 1), (unsigned)c->n_cus, exact);
   if (path_out) *path_out = plan.path;
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
   ScanP sp;
   const double2* dirs = nullptr;
   if (int rc = make_scan(c, geom, &sp, &dirs)) return rc;
-  // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
-  int K = 1, cw = 4;
-  cluster_shape(cfg->population, true, allow_cluster && gate == 0, &K, &cw);
-  if (K > 1) K = std::min<int>(K, c->n_cus / (int)std::min<uint32_t>(n_pairs, (uint32_t)c->n_cus));
-  if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
   if (K > 1) waves = cw;
   PsoP ps = make_pso(cfg, waves, mode, plan.L.swarm_global != 0);
   ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), (int)n_pairs, -1, nullptr};
@@ -2067,7 +2138,9 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   } else if (mode == NDTPSO_SCORE_F32) {
     if (byte_entries) LAUNCH_PAIRS(kScoreF32, 3); else if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
   } else {
-    if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
+    if (plan.path == 9) LAUNCH_PAIRS_CANS(kScoreF64, 9, false, false, false, 2);
+    else if (plan.path == 8) LAUNCH_PAIRS_CANS(kScoreF64, 8, false, false, false, 2);
+    else if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
   }
 #undef LAUNCH_PAIRS
 #undef LAUNCH_PAIRS_X
@@ -2161,7 +2234,16 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
                       st, kStatusClusterTimeout, true, nullptr, false, exact);
     if (rc != NDTPSO_OK) return rc;
   }
-  if (mode != NDTPSO_SCORE_F32) return rc;
+  if (mode != NDTPSO_SCORE_F32) {
+    // fp64 score on the dense table (path 8 / 9): an occupied box that outgrew the provisioned table, or a table holding a
+    // cell whose exponents the spelt-out exponential must not be trusted with -> the bitmap form, gated
+    if (path >= 8) {
+      rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose,
+                        d_cost, st, kStatusNeedsBitmap, false, nullptr);
+      if (rc == NDTPSO_E_CAPACITY) rc = NDTPSO_OK;
+    }
+    return rc;
+  }
   // Gated redo launches (every workgroup whose alignment is not flagged exits on its first instruction):
   //  - dense form only: alignments whose occupied box exceeded the provisioned cell table -> bitmap form;
   //  - alignments whose fp32 costs fell in the underflow regime (degenerate overlap) -> fp64 score.
@@ -2265,3 +2347,4 @@ int ndtpso_profile_phase_budget(uint32_t* out, uint32_t n_blocks) {
 
 #include "ndtpso_map.inc"
 #include "ndtpso_shard.inc"
+#include "ndtpso_selftest.inc"

@@ -852,6 +852,203 @@ __device__ __forceinline__ void score_trip_guarded(const GridP& g, const WinP& w
   }
 }
 
+// ---- fp64 score on a dense cell table (round 5; PATH 8 / 9 of the fused pairs kernel) ------------------------------------
+//
+// The fp64 score mode -- the reference's operations in the reference's order -- looked its cells up through the bitmap
+// table: bitmap word, bit-field extract, popcount, three record addresses; 59 vector instructions per point of which ~30 were
+// not fp64 arithmetic, and 21 the math library's exp.  Here:
+//   * the dense u16 table of the fp32-score kernels (one entry per cell of a window sized per alignment, a null entry for
+//     every cell that is not built), entries = LDS byte addresses of 48-byte fp64 records {mean, s_inv_covar row 0, row 1}
+//     read with three 16-byte loads off ONE address (immediate offsets): per point one mad24, one shift-add, one 2-byte read;
+//   * record 0, the null record, scores exp(-4.5e5 ... -1.8e6) = +0. for any point inside a frame of up to 65 535 m: a miss
+//     adds +0. as the reference's `continue` does (core.cpp:40), with no mask, select or compare;
+//   * exp(-q / 2) spelt out (exp_neg_half): the library's reduction, polynomial and ldexp -- same constants, same operations,
+//     same order -- without its two range guards and with the factor -1/2 folded into the constants (below).
+// 43 vector instructions per point (8 transform, 6 index, 11 differences and quadratic form, 17 exponential, 1 add).
+constexpr int kD64RecBytes = 48;
+__host__ __device__ constexpr bool path_is_dense64(int path) { return path == 8 || path == 9; }
+__host__ __device__ inline int d64_rec_bytes(int n_records) { return kD64RecBytes * n_records; }
+constexpr uint32_t kHdrWildCell = 64u;  // ImageHeader::status, internal: d64_cell_tame failed for a built cell
+constexpr double kD64NullMean = 1e5, kD64NullScale = 1e-4;  // null record: mean (1e5, 1e5), s_inv_covar 1e-4 I
+
+// exp(x) at x = -q / 2 as __ocml_exp_f64 computes it (ROCm 7: t = x log2(e); n = rint(t); r = fma(-ln2_hi, n, x);
+// r = fma(-ln2_lo, n, r); eleven Horner steps; ldexp(p, n)), from q itself:
+//   * x = -q / 2 is exact, so t = fl(x L) = fl(q (-L / 2)) and the reduction's two fused steps give R = -2 r exactly from q
+//     (a power-of-two factor commutes with every rounding; nothing here comes near the subnormal range -- r is 0 or above
+//     1e-17 in magnitude unless n = 0, where a subnormal q leaves the polynomial at exactly 1 either way);
+//   * Horner in R = -2 r with coefficient k scaled by (-2)^-k carries P_k = (-2)^-k p_k, every step the library's step times a
+//     power of two: P_0 = p_0 bit for bit.  The last two constants are -0.5 and 1 (inline operands).
+//   * the library then returns +inf for x > 1024 and 0 for x < -1075.  Between those bounds it relies on v_ldexp_f64 for
+//     overflow, gradual underflow and +0. -- so does this form, everywhere: for |x| < 2^40 (n exact, r accurate, p in
+//     [0.7, 1.5]) ldexp(p, n) IS +inf above 1024 and +0. below -1075, and a NaN stays a NaN through every step.  Beyond 2^40
+//     (an infinite or absurd exponent: a singular cell's inverse covariance) the guards differ from what the arithmetic gives,
+//     which is why a table holding such a cell is not scored by this form (build_table_wg: kStatusNeedsBitmap).
+// tests/test_gpu_exp.py compares it with the library's exp on the device over every binade of [-1100, 64] and the specials.
+__device__ __forceinline__ double exp_neg_half(double q) {
+  const double t = q * __longlong_as_double(0xbfe71547652b82feLL);  // -log2(e) / 2
+  const double dn = __builtin_rint(t);                              // v_rndne_f64
+  double r = fma(dn, __longlong_as_double(0x3ff62e42fefa39efLL), q);  // 2 ln2_hi
+  r = fma(dn, __longlong_as_double(0x3c8abc9e3b39803fLL), r);         // 2 ln2_lo
+  // c_k (-2)^-k: the library's coefficients (c11 ... c2 = 0x3e5ade156a5dcb37, 0x3e928af3fca7ab0c, 0x3ec71dee623fde64,
+  // 0x3efa01997c89e6b0, 0x3f2a01a014761f6e, 0x3f56c16c1852b7b0, 0x3f81111111122322, 0x3fa55555555502a1, 0x3fc5555555555511,
+  // 0x3fe000000000000b) with k subtracted from the exponent field and the sign set for odd k
+  double p = __longlong_as_double((long long)0xbdaade156a5dcb37ULL);             // c11 / -2048
+  p = fma(r, p, __longlong_as_double(0x3df28af3fca7ab0cLL));                      // c10 / 1024
+  p = fma(r, p, __longlong_as_double((long long)0xbe371dee623fde64ULL));          // c9 / -512
+  p = fma(r, p, __longlong_as_double(0x3e7a01997c89e6b0LL));                      // c8 / 256
+  p = fma(r, p, __longlong_as_double((long long)0xbeba01a014761f6eULL));          // c7 / -128
+  p = fma(r, p, __longlong_as_double(0x3ef6c16c1852b7b0LL));                      // c6 / 64
+  p = fma(r, p, __longlong_as_double((long long)0xbf31111111122322ULL));          // c5 / -32
+  p = fma(r, p, __longlong_as_double(0x3f655555555502a1LL));                      // c4 / 16
+  p = fma(r, p, __longlong_as_double((long long)0xbf95555555555511ULL));          // c3 / -8
+  p = fma(r, p, __longlong_as_double(0x3fc000000000000bLL));                      // c2 / 4
+  p = fma(r, p, -0.5);
+  p = fma(r, p, 1.0);
+  int n;
+  asm("v_cvt_i32_f64 %0, %1" : "=v"(n) : "v"(dn));  // (saturating; 0 for a NaN -- the C cast is undefined there)
+  return __builtin_ldexp(p, n);
+}
+
+// U chunks of a pose under the guard (every point strictly inside the frame and inside the table's window; DenseGuard in
+// metres as for score_trip_guarded).  MASK: the trip's last chunk holds the list's padding -- those lanes read the null entry.
+// The terms are score_trip<kScoreF64>'s bit for bit.  tab_a: LDS byte address of the table's entry for frame cell (0, 0)
+// (may lie "below" the table: unsigned arithmetic); stride: entries per table row.
+template <bool POW2, int U, bool MASK>
+__device__ __forceinline__ void score_trip_d64(const GridP& g, unsigned stride, unsigned tab_a, unsigned null_a,
+                                               const double2* __restrict__ pts, int base, int n, double c, double s,
+                                               double tx, double ty, double hwi, double hhi, double (&acc)[4]) {
+  typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+  const int lane = lane_id();
+  double2 p[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) p[u] = pts[base + u * kWave + lane];
+  double qx[U], qy[U];
+  unsigned ea[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    qx[u] = (p[u].x * c - p[u].y * s) + tx;  // transform_point, reference rounding (core.h:28-31): no fma
+    qy[u] = (p[u].x * s + p[u].y * c) + ty;
+    int ix, iy;
+    if constexpr (POW2) {
+      ix = (int)fma(qx[u], g.inv_cs, hwi);  // = (int)((qx + hw) * inv_cs): hwi = hw * inv_cs, a power-of-two scaling
+      iy = (int)fma(qy[u], g.inv_cs, hhi);
+    } else {
+      cell_coords<false>(g, qx[u], qy[u], ix, iy);
+    }
+    unsigned t;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(iy), "s"(stride), "v"(ix));
+    asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(ea[u]) : "v"(t), "s"(tab_a));
+    if constexpr (MASK)
+      if (u == U - 1) ea[u] = (base + u * kWave + lane < n) ? ea[u] : null_a;
+  }
+  unsigned e[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) e[u] = *(lds_u16_t)(uintptr_t)ea[u];
+  v2d_t m[U], ab[U], cd[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    m[u] = *(lds_d2_t)(uintptr_t)e[u];
+    ab[u] = *(lds_d2_t)(uintptr_t)(e[u] + 16u);
+    cd[u] = *(lds_d2_t)(uintptr_t)(e[u] + 32u);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double d0 = qx[u] - m[u].x, d1 = qy[u] - m[u].y;
+    const double r0 = d0 * ab[u].x + d1 * cd[u].x;  // (diff^T * inv_covar), ndtcell.cpp:73-75
+    const double r1 = d0 * ab[u].y + d1 * cd[u].y;
+    acc[u] += exp_neg_half(r0 * d0 + r1 * d1);
+  }
+}
+
+// The same for a pose outside the guard: frame, wrap and window tests per point as getCellIndex makes them
+// (ndtframe.cpp:240-249); a point that fails one adds +0. (core.cpp:40).
+template <bool POW2, int U>
+__device__ __forceinline__ void score_trip_d64_tested(const GridP& g, const DenseP& dn, unsigned stride, unsigned tab0,
+                                                      const double2* __restrict__ pts, int base, double c, double s,
+                                                      double tx, double ty, double (&acc)[4]) {
+  typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+  const int lane = lane_id();
+  double2 p[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) p[u] = pts[base + u * kWave + lane];
+  double qx[U], qy[U];
+  unsigned lin[U];
+  bool in[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    qx[u] = (p[u].x * c - p[u].y * s) + tx;
+    qy[u] = (p[u].x * s + p[u].y * c) + ty;
+    const bool inframe = (int)(fabs(qx[u]) < g.hw) & (int)(fabs(qy[u]) < g.hh);  // strict bounds, ndtframe.cpp:242
+    int ix, iy;
+    cell_coords<POW2>(g, qx[u], qy[u], ix, iy);
+    const bool wrap = (ix == g.W);  // fl(x + w/2) == w: the reference's linear index lands in the next row
+    ix = wrap ? 0 : ix;
+    iy = wrap ? iy + 1 : iy;
+    const unsigned rx = (unsigned)(ix - dn.ox), ry = (unsigned)(iy - dn.oy);
+    in[u] = (int)inframe & (int)(iy < g.H) & (int)(rx <= (unsigned)dn.dw) & (int)(ry <= (unsigned)dn.dh);
+    lin[u] = in[u] ? ry * stride + rx : 0u;  // entry 0: the empty low border, null
+  }
+  unsigned e[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) e[u] = *(lds_u16_t)(uintptr_t)(tab0 + (lin[u] << 1));
+  v2d_t m[U], ab[U], cd[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    m[u] = *(lds_d2_t)(uintptr_t)e[u];
+    ab[u] = *(lds_d2_t)(uintptr_t)(e[u] + 16u);
+    cd[u] = *(lds_d2_t)(uintptr_t)(e[u] + 32u);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double d0 = qx[u] - m[u].x, d1 = qy[u] - m[u].y;
+    const double r0 = d0 * ab[u].x + d1 * cd[u].x;
+    const double r1 = d0 * ab[u].y + d1 * cd[u].y;
+    const double t = exp_neg_half(r0 * d0 + r1 * d1);
+    acc[u] += in[u] ? t : 0.;  // (the coordinates of a point outside the frame may be anything, NaN included)
+  }
+}
+
+// One pose, one wave: eval_pose_wave_t<kScoreF64>'s trips in its order -- groups of four chunks into the four lane
+// accumulators, the chunks behind the last group into the first -- so the sum is that function's bit for bit.
+// d64_tab: LDS byte address of the u16 table; dn.rec_off: of record 0 (the null record).
+template <bool POW2, bool GUARD>
+__device__ __forceinline__ double eval_pose_wave_d64(const GridP& g, const DenseP& dn, unsigned d64_tab,
+                                                     const double2* __restrict__ pts, int n, double c, double s,
+                                                     double tx, double ty) {
+  constexpr int U = 4;
+  double acc[4] = {0., 0., 0., 0.};
+  const int n_pad = round_up(n, kWave);
+  const unsigned stride = (unsigned)dense_stride(dn.dw);
+  int base = 0;
+  if constexpr (GUARD) {
+    const double hwi = uniform_f64(g.hw * g.inv_cs), hhi = uniform_f64(g.hh * g.inv_cs);  // wave-uniform: scalar registers
+    const unsigned tab_a = d64_tab - 2u * ((unsigned)dn.oy * stride + (unsigned)dn.ox);
+    // (entry 0 of the table -- the low border's corner -- is a null entry: the padding's lanes read it)
+    for (; base + U * kWave <= n_pad; base += U * kWave) {
+      if (base + U * kWave <= n)
+        score_trip_d64<POW2, U, false>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
+      else
+        score_trip_d64<POW2, U, true>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
+    }
+    for (; base < n_pad; base += kWave) {
+      if (base + kWave <= n)
+        score_trip_d64<POW2, 1, false>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
+      else
+        score_trip_d64<POW2, 1, true>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
+    }
+  } else {
+    for (; base + U * kWave <= n_pad; base += U * kWave)
+      score_trip_d64_tested<POW2, U>(g, dn, stride, d64_tab, pts, base, c, s, tx, ty, acc);
+    for (; base < n_pad; base += kWave)
+      score_trip_d64_tested<POW2, 1>(g, dn, stride, d64_tab, pts, base, c, s, tx, ty, acc);
+  }
+  return -wave_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+}
+
 // pts must be padded to a multiple of kPointPad with out-of-frame sentinels (pad_points_wg)
 template <int MODE, bool POW2, bool DUMP, bool GUARD = false>
 __device__ __forceinline__ double eval_pose_wave_t(const GridP& g, const WinP& wn, const TableView& T,
@@ -1110,14 +1307,55 @@ __device__ __forceinline__ void dense_put(const GridP& g, const DenseP& dn, unsi
       byte_entries ? (unsigned short)at : (unsigned short)(at >> 4);
 }
 
+// ---- the fp64 score's dense form (score_trip_d64): u16 table at lds0 + tab_off, 48-byte records at lds0 + dn.rec_off ----
+__device__ inline void d64_clear_wg(const DenseP& dn, unsigned char* lds0, int tab_off) {
+  const unsigned null16 = (unsigned)dn.rec_off;  // entries are the records' LDS byte addresses
+  uint32_t* t32 = reinterpret_cast<uint32_t*>(lds0 + tab_off);
+  const int n32 = dense_tab_bytes(dn.dw, dn.dh) >> 2;
+  for (int i = threadIdx.x; i < n32; i += blockDim.x) t32[i] = null16 | (null16 << 16);
+  if (threadIdx.x == 0) {
+    double* r = reinterpret_cast<double*>(lds0 + dn.rec_off);
+    r[0] = r[1] = kD64NullMean;
+    r[2] = kD64NullScale;
+    r[3] = 0.;
+    r[4] = 0.;
+    r[5] = kD64NullScale;
+  }
+}
+// Can every exponent this cell produces be left to exp_neg_half?  |x| <= (|a| + |b| + |c| + |d|) max(d0^2, |d0 d1|, d1^2) / 2
+// (1 + 1e-15), and a point scored against a cell lies in it, as does the mean of the points it was built from: both
+// differences are below the cell side (twice that is assumed).  2^39 leaves a factor of two to the form's own bound of 2^40;
+// a NaN or infinite entry fails the comparison.
+__device__ __forceinline__ bool d64_cell_tame(double cs, double ia, double ib, double ic, double id) {
+  const double S = (fabs(ia) + fabs(ib)) + (fabs(ic) + fabs(id));
+  return S * (2. * cs * cs) < 549755813888.;
+}
+__device__ __forceinline__ void d64_put(const DenseP& dn, unsigned char* lds0, int tab_off, unsigned slot, int rx, int ry,
+                                        double mx, double my, double ia, double ib, double ic, double id) {
+  const unsigned at = (unsigned)dn.rec_off + (unsigned)kD64RecBytes * (slot + 1u);
+  double* r = reinterpret_cast<double*>(lds0 + at);
+  r[0] = mx;
+  r[1] = my;
+  r[2] = ia;
+  r[3] = ib;
+  r[4] = ic;
+  r[5] = id;
+  reinterpret_cast<unsigned short*>(lds0 + tab_off)[(ry + 1) * dense_stride(dn.dw) + (rx + 1)] = (unsigned short)at;
+}
+
+// d64_tab_off >= 0 (with dn): the dense form is the fp64 score's (d64_put) and a cell exp_neg_half must not score raises
+// kHdrWildCell in the header (the kernel hands the alignment to the bitmap form)
 __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const double2* pts, int n,
                                       ImageHeader* hdr, const TableOut& out, int* key, int* cellkey, int* cnt,
                                       uint2* bm2, unsigned short* plist, CellRow* rows, uint32_t* n_rows_out,
                                       const DenseP* dn, unsigned char* lds0, bool byte_entries = false,
-                                      const TableOut* xout = nullptr /* exact mode: bitmap, mean, ab, cd also to HBM */) {
+                                      const TableOut* xout = nullptr /* exact mode: bitmap, mean, ab, cd also to HBM */,
+                                      int d64_tab_off = -1) {
   const int tid = threadIdx.x, nt = blockDim.x;
   uint2* bm = out.bm;
-  if (dn) dense_clear_wg(*dn, lds0, byte_entries);
+  if (dn) {
+    if (d64_tab_off >= 0) d64_clear_wg(*dn, lds0, d64_tab_off); else dense_clear_wg(*dn, lds0, byte_entries);
+  }
 
   for (int w = tid; w < wn.n_words; w += nt) {
     bm[w] = make_uint2(0u, 0u);
@@ -1313,7 +1551,14 @@ __device__ inline void build_table_wg(const GridP& g, const WinP& wn, const doub
       id = inv[3];
       const unsigned slot = bm_slot(bm, mykey);
       if ((int)slot < wn.rec_cap) {
-        if (dn) dense_put(g, *dn, lds0, slot, mykey % wn.w, mykey / wn.w, mx, my, ia, ib, ic, id, byte_entries);
+        if (dn) {
+          if (d64_tab_off >= 0) {
+            d64_put(*dn, lds0, d64_tab_off, slot, mykey % wn.w, mykey / wn.w, mx, my, ia, ib, ic, id);
+            if (!d64_cell_tame(g.cs, ia, ib, ic, id)) atomicOr(&hdr->status, kHdrWildCell);
+          } else {
+            dense_put(g, *dn, lds0, slot, mykey % wn.w, mykey / wn.w, mx, my, ia, ib, ic, id, byte_entries);
+          }
+        }
         if (xout) {
           xout->mean[slot] = make_double2(mx, my);
           xout->ab[slot] = make_double2(ia, ib);
@@ -1614,6 +1859,7 @@ struct EvalCtx {
   const unsigned char* lds0;
   int light;  // PsoP::light (the item -> wave deal of eval_items)
   unsigned guard_lds;  // LDS byte address of the DenseGuard, 0: none
+  unsigned d64_tab;    // PATH 8 / 9: LDS byte address of the u16 cell table (records at dn.rec_off)
 #ifdef NDTPSO_VERIFY_MARGIN
   const struct ExactArgs* xa = nullptr;  // diagnostic builds: every fp32 score is checked against its fp64 value
 #endif
@@ -2248,7 +2494,13 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       }
     } else {
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
-      if constexpr (MODE == kScoreF64 && PATH < 4) {  // (fp64 score of the batches: the guard in metres, set with the proposal)
+      if constexpr (path_is_dense64(PATH)) {  // (fp64 score on the dense table: the same guard)
+        static_assert(!path_is_dense64(PATH) || MODE == kScoreF64, "PATH 8 / 9 are the fp64 score's");
+        if (*reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
+          cost = eval_pose_wave_d64<(PATH & 3) == 1, true>(E.g, E.dn, E.d64_tab, pts, n, c, s, tx, ty);
+        else
+          cost = eval_pose_wave_d64<(PATH & 3) == 1, false>(E.g, E.dn, E.d64_tab, pts, n, c, s, tx, ty);
+      } else if constexpr (MODE == kScoreF64 && PATH < 4) {  // (fp64 score of the batches: the guard in metres, set with the proposal)
         if (E.guard_lds && *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
           cost = eval_pose_wave_t<MODE, (PATH & 3) == 1, false, true>(E.g, E.wn, E.T, pts, n, c, s, tx, ty, nullptr);
         else
@@ -2368,7 +2620,13 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
       }
     } else {
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
-      if constexpr (MODE == kScoreF64 && PATH < 4) {  // (fp64 score of the batches: the guard in metres, set with the proposal)
+      if constexpr (path_is_dense64(PATH)) {  // (fp64 score on the dense table: the same guard)
+        static_assert(!path_is_dense64(PATH) || MODE == kScoreF64, "PATH 8 / 9 are the fp64 score's");
+        if (*reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
+          cost = eval_pose_wave_d64<(PATH & 3) == 1, true>(E.g, E.dn, E.d64_tab, pts, n, c, s, tx, ty);
+        else
+          cost = eval_pose_wave_d64<(PATH & 3) == 1, false>(E.g, E.dn, E.d64_tab, pts, n, c, s, tx, ty);
+      } else if constexpr (MODE == kScoreF64 && PATH < 4) {  // (fp64 score of the batches: the guard in metres, set with the proposal)
         if (E.guard_lds && *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
           cost = eval_pose_wave_t<MODE, (PATH & 3) == 1, false, true>(E.g, E.wn, E.T, pts, n, c, s, tx, ty, nullptr);
         else

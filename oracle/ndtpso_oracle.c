@@ -875,3 +875,12 @@ int orc_align_pairs(int n_pairs, const float *ref_ranges, const float *new_range
   }
   return used;
 }
+
+/* glibc's exp / sincos over arrays: what tests/test_gpu_exp.py holds the device's math library against (the host's libm
+ * is what the reference runs on: ndtcell.cpp:76, core.h:28-31 through GCC's sincos fusion). */
+void orc_libm_exp(const double *x, size_t n, double *out) {
+  for (size_t i = 0; i < n; ++i) out[i] = exp(x[i]);
+}
+void orc_libm_sincos(const double *x, size_t n, double *s, double *c) {
+  for (size_t i = 0; i < n; ++i) sincos(x[i], &s[i], &c[i]);
+}

@@ -165,6 +165,10 @@ int orc_align_pairs(int n_pairs, const float *ref_ranges, const float *new_range
                     const orc_pso_config *cfg, const uint32_t *seeds, int n_threads,
                     double *out_pose /*[n_pairs*3]*/, double *out_cost /*[n_pairs]*/);
 
+/* the host libm's exp / sincos over arrays (the device's math library is compared with them, tests/test_gpu_exp.py) */
+void orc_libm_exp(const double *x, size_t n, double *out);
+void orc_libm_sincos(const double *x, size_t n, double *s, double *c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -100,6 +100,10 @@ def lib():
     L.orc_align_pairs.argtypes = [C.c_int, fp, fp, C.c_uint, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_ushort, C.c_ushort, C.c_double, dp, dp, C.POINTER(PSOConfig),
                                   C.POINTER(C.c_uint32), C.c_int, dp, dp]
+    L.orc_libm_exp.argtypes = [dp, C.c_size_t, dp]
+    L.orc_libm_exp.restype = None
+    L.orc_libm_sincos.argtypes = [dp, C.c_size_t, dp, dp]
+    L.orc_libm_sincos.restype = None
     _lib = L
     return L
 
@@ -280,3 +284,19 @@ def align_pairs(ref_ranges, new_ranges, min_angle, angle_increment, max_range, e
                                  float(cell_side), _dp(guess), _dp(deviation), C.byref(cfg),
                                  seeds.ctypes.data_as(C.POINTER(C.c_uint32)), int(n_threads), _dp(pose), _dp(cost))
     return pose, cost, used
+
+
+def libm_exp(x):
+    """glibc's exp, element by element (numpy's own exp is a SIMD routine of its own)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    out = np.empty_like(x)
+    lib().orc_libm_exp(_dp(x), x.size, _dp(out))
+    return out
+
+
+def libm_sincos(x):
+    """glibc's sincos, element by element: (sin, cos)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    s, c = np.empty_like(x), np.empty_like(x)
+    lib().orc_libm_sincos(_dp(x), x.size, _dp(s), _dp(c))
+    return s, c
