@@ -382,6 +382,14 @@ const double *ndtpso_shard_gathered(const ndtpso_shard_group *group, int index);
 int ndtpso_selftest_exp(ndtpso_ctx *ctx, int exp2_lo, int exp2_hi, uint32_t per_binade, uint32_t seed, int positive,
                         uint64_t *checked, uint64_t *mismatched, double *first_bad);
 int ndtpso_device_math(ndtpso_ctx *ctx, int kind, const double *x, uint32_t n, double *out0, double *out1);
+/* The start-up known-answer check of NDTPSO_SCORE_EXACT.  The first request for the exact mode on a device (any entry
+ * point, any context of the process) first runs a fixed small problem -- a batch through the 8-wave batch kernel, single
+ * alignments on a cluster of workgroups and on one workgroup -- in the exact mode and in NDTPSO_SCORE_F64 and compares poses
+ * and costs bit for bit (and checks that comparisons were in fact arbitrated).  If they differ the device is refused the
+ * exact mode: every later request for it runs NDTPSO_SCORE_F64 (the same results by definition, at its speed), and
+ * ndtpso_last_error explains.  ndtpso_exact_check runs the check if it has not run and reports: state 1 passed, 2 refused;
+ * the comparisons the check arbitrated; its duration in ms.  NDTPSO_EXACT_CHECK=0 in the environment skips it. */
+int ndtpso_exact_check(ndtpso_ctx *ctx, int *state, uint32_t *arbitrated_batch, uint32_t *arbitrated_single, double *ms);
 
 #ifdef __cplusplus
 }

@@ -109,7 +109,7 @@ EXPORTS = [
     "ndtpso_shard_group_create", "ndtpso_shard_group_destroy", "ndtpso_shard_group_size", "ndtpso_shard_last_error",
     "ndtpso_shard_range", "ndtpso_align_pairs_sharded", "ndtpso_align_pairs_sharded_dev", "ndtpso_shard_last_timing",
     "ndtpso_shard_gathered",
-    "ndtpso_selftest_exp", "ndtpso_device_math",
+    "ndtpso_selftest_exp", "ndtpso_device_math", "ndtpso_exact_check",
 ]
 
 _lib = None
@@ -165,6 +165,7 @@ def load(build_if_missing: bool = True):
     L.ndtpso_selftest_exp.argtypes = [vp, C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint64), dp]
     L.ndtpso_device_math.argtypes = [vp, C.c_int, dp, C.c_uint32, dp, dp]
+    L.ndtpso_exact_check.argtypes = [vp, C.POINTER(C.c_int), up, up, dp]
     L.ndtpso_points_create.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     L.ndtpso_points_destroy.argtypes = [vp]
     L.ndtpso_points_destroy.restype = None
@@ -280,6 +281,13 @@ class Context:
         o0, o1 = np.empty_like(x), np.empty_like(x)
         self._chk(self._lib.ndtpso_device_math(self._h, k, _p(x, C.c_double), x.size, _p(o0, C.c_double), _p(o1, C.c_double)))
         return (o0, o1) if k == 2 else o0
+
+    def exact_check(self):
+        """The start-up known-answer check of the exact mode (run now if it has not run): dict(state 1 passed / 2 refused,
+        arbitrated_batch, arbitrated_single, ms)."""
+        st, a, b, ms = C.c_int(), C.c_uint32(), C.c_uint32(), C.c_double()
+        self._chk(self._lib.ndtpso_exact_check(self._h, C.byref(st), C.byref(a), C.byref(b), C.byref(ms)))
+        return dict(state=st.value, arbitrated_batch=a.value, arbitrated_single=b.value, ms=ms.value)
 
     # ---- K3 ----
     def scan_to_points(self, ranges, geom: ScanGeom, trans=(0.0, 0.0, 0.0)) -> np.ndarray:

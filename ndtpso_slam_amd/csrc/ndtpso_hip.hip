@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -107,7 +108,8 @@ Layout make_layout(int n_words, int rec_cap, int n_max, int P, int fmt, int ddw 
   // (NDTPSO_UNITS_HBM=<slots>, tests only) against the fp64 mode in every build.
   static const int units_hbm = [] {  // tests only: scratch slots of the unit form for swarms kept in HBM (0: whole tasks)
     const char* e = std::getenv("NDTPSO_UNITS_HBM");
-    return e ? std::atoi(e) : 0;
+    // (a task's four units take four consecutive slots: a multiple of four, at most 64)
+    return e ? std::min(std::max(std::atoi(e), 0) & ~3, 64) : 0;
   }();
   if (exact && exact_units && (!swarm_global || units_hbm > 0)) {
     L.xs_slots = swarm_global ? units_hbm : 8;  // one unit per wave of the workgroup
@@ -1187,6 +1189,8 @@ int check_pso(ndtpso_ctx* ctx, const ndtpso_pso_config* cfg) {
   return NDTPSO_OK;
 }
 
+int exact_mode_resolve(ndtpso_ctx* c, int* mode);  // ndtpso_selftest.inc: the start-up check of NDTPSO_SCORE_EXACT
+
 }  // namespace
 
 extern "C" {
@@ -1867,6 +1871,9 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
   ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), 1, -1, nullptr};
   int lds_total = L.total;
+  // (one XCD holds an eighth of the compute units; a cluster it cannot hold -- a forced K, a partitioned part -- is spread as
+  // the dispatcher spreads it instead of spinning to the exchange's timeout, as launch_pairs does)
+  if (K > std::max(1, c->n_cus / 8)) cl.one_xcd = 0;
   if (K > 1) {
     cluster_spec_room(cfg->population, &lds_total, &cl);
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
@@ -1937,6 +1944,11 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     AlignStats st;
     std::memcpy(&st, host + 4, sizeof(st));
     if (st.status & kStatusClusterTimeout) {  // the cluster was not co-resident (device shared with other work): one workgroup,
+      static bool logged = false;
+      if (!logged) {
+        logged = true;
+        std::fprintf(stderr, "ndtpso: a cluster of %d workgroups did not meet within 20 ms (device shared?); alignments run on one workgroup for a while\n", K);
+      }
       c->cluster_penalty = cluster_test_absent() >= 0 ? 1 : 200;  // and no new attempt for the next 200 alignments (a
                                                                    // robot's 5-20 s; one under the test hook)
     }
@@ -1948,15 +1960,27 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
 
 static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
                         int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats,
-                        AfterLaunch after = AfterLaunch{nullptr, nullptr});
+                        AfterLaunch after = AfterLaunch{nullptr, nullptr}, bool allow_cluster = true);
+
+// ndtpso_align; allow_cluster = false keeps the alignment on one workgroup (the start-up check runs both forms)
+static int align_points(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess[3], const double deviation[3],
+                        const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
+                        double* out_cost, ndtpso_align_stats* stats, bool allow_cluster);
 
 int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess[3], const double deviation[3],
                  const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
                  double* out_cost, ndtpso_align_stats* stats) {
+  return align_points(c, xy, n, guess, deviation, cfg, seed, rand_table, mode, out_pose, out_cost, stats, true);
+}
+
+static int align_points(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess[3], const double deviation[3],
+                        const ndtpso_pso_config* cfg, uint32_t seed, const int32_t* rand_table, int mode, double out_pose[3],
+                        double* out_cost, ndtpso_align_stats* stats, bool allow_cluster) {
   if (!c || (!xy && n) || !guess || !deviation || !out_pose) return fail(c, NDTPSO_E_ARG, "null argument");
   if (mode != NDTPSO_SCORE_F32 && mode != NDTPSO_SCORE_F64 && mode != NDTPSO_SCORE_EXACT) return fail(c, NDTPSO_E_ARG, "bad score mode");
   if (int rc = check_pso(c, cfg)) return rc;
   if (!c->have_ref) return fail(c, NDTPSO_E_STATE, "no reference table");
+  if (int rc = exact_mode_resolve(c, &mode)) return rc;
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t n_draw = ndtpso_rand_draws(cfg);
   HIP_TRY(c, c->xy2.reserve((size_t)std::max<uint32_t>(n, 1) * 16));
@@ -1968,15 +1992,16 @@ int ndtpso_align(ndtpso_ctx* c, const double* xy, uint32_t n, const double guess
   c->inputs = c->table.p;
   c->inputs_pinned = false;
   const AlignSrc src{(const unsigned char*)c->image.p, c->g, c->wn, (const double2*)c->xy2.p, n, nullptr, out_cost != nullptr};
-  return align_finish(c, src, cfg, seed, rand_table != nullptr, mode, out_pose, out_cost, stats);
+  return align_finish(c, src, cfg, seed, rand_table != nullptr, mode, out_pose, out_cost, stats, AfterLaunch{nullptr, nullptr}, allow_cluster);
 }
 
 // launch, fetch pose/cost/stats; an alignment the fp32 score flags (underflow regime, see ndtpso_kernels.hpp) is
 // redone with the fp64 score
 static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
-                        int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats, AfterLaunch after) {
+                        int mode, double out_pose[3], double* out_cost, ndtpso_align_stats* stats, AfterLaunch after,
+                        bool allow_cluster) {
   double host[4 + sizeof(AlignStats) / 8];
-  int rc = align_once(c, src, cfg, seed, have_table, mode, host, true, after);
+  int rc = align_once(c, src, cfg, seed, have_table, mode, host, allow_cluster, after);
   if (rc != NDTPSO_OK) return rc;
   AlignStats st;
   std::memcpy(&st, host + 4, sizeof(st));
@@ -2164,6 +2189,7 @@ int ndtpso_align_pairs_dev(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, 
                            const int32_t* d_tables, int mode, double* d_pose, double* d_cost,
                            ndtpso_align_stats* d_stats) {
   if (!c) return NDTPSO_E_ARG;
+  if (int rc = exact_mode_resolve(c, &mode)) return rc;
   // one batch at a time (the default), or a batch too small to fill the device (those run as clusters of workgroups
   // with per-context counters): on the context's stream, behind whatever is still in flight
   if (c->pipe_depth < 2 || n_pairs * 2u <= (uint32_t)c->n_cus) {
@@ -2268,6 +2294,7 @@ int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges,
     return fail(c, NDTPSO_E_ARG, "null argument");
   if (int rc = check_pso(c, cfg)) return rc;
   if (n_pairs == 0) return NDTPSO_OK;
+  if (int rc = exact_mode_resolve(c, &mode)) return rc;  // (before anything is staged in the context's buffers)
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t B = n_pairs, nb = geom->n_beams, n_draw = ndtpso_rand_draws(cfg);
   HIP_TRY(c, c->ranges.reserve(B * nb * 4));

@@ -1828,6 +1828,9 @@ struct PsoShared {  // small control block in LDS
   double gbc;
   int jstar[3];  // first improver of a group, rotating by group number (see pso_run_wg)
   int tiny;      // fp32 score mode: some cost of the current group fell in the underflow regime
+  int tiny_j;    // NDTPSO_STREAM: the lowest item of the phase whose cost did (INT_MAX: none) -- only an item the phase
+                 // establishes, i.e. one up to its first improver, may hand the alignment over: what lies behind is evaluated
+                 // or not depending on timing, and is proposed again anyway
   int timed_out; // cluster mode: a workgroup of the cluster did not arrive at an exchange
   int ticket;    // NDTPSO_STREAM: the next item of the phase (eval_stream)
   int jmax;      //                the highest item evaluated in it
@@ -2324,7 +2327,11 @@ __device__ __forceinline__ void exact_combine(const ExactArgs* ap, int t) {
   const unsigned base = ap->xs_lds + (unsigned)(((4 * t) % ap->xs_slots) * kWave + lane_id()) * 8u;
   const double a0 = *(lds_d_t)(uintptr_t)base, a1 = *(lds_d_t)(uintptr_t)(base + kWave * 8u),
                a2 = *(lds_d_t)(uintptr_t)(base + 2u * kWave * 8u), a3 = *(lds_d_t)(uintptr_t)(base + 3u * kWave * 8u);
+#ifdef NDTPSO_BREAK_ARBITRATION  // test builds only (tests/test_gpu_exact_check.py): the start-up check must refuse this library
+  const double c = -wave_sum((a0 + a1) + (a2 + a3)) * (1. + 0x1p-44);
+#else
   const double c = -wave_sum((a0 + a1) + (a2 + a3));
+#endif
   if (lane_id() == 0) {
     const unsigned tk = ap->task[t];
     const int j = (int)(tk >> 2), kind = (int)(tk & 3u);
@@ -2645,7 +2652,7 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
       bool ordinary = true;
       if (MODE == kScoreF32 && !(cost <= -kTinyCost)) {  // NaN, or the underflow regime
         if (cost != cost || pbc_j > -kTinyCost) {
-          *tiny = 1;
+          __hip_atomic_fetch_min((lds_int_t)tiny, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (tiny: PsoShared::tiny_j here)
           ordinary = false;
         }
       }
@@ -3171,6 +3178,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         if (tid == 0) {  // the phase's ticket counter (published by the barrier that follows)
           sh->ticket = lo;
           sh->jmax = lo - 1;
+          sh->tiny_j = 0x7fffffff;
         }
 #endif
       if (need_propose) {
@@ -3239,13 +3247,15 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           next_filled = n_draw;
         }
         NDTPSO_PB(5);
-        eval_stream<MODE, PATH, ARB, NOCLIP>(E, pts, n, sw, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny,
+        eval_stream<MODE, PATH, ARB, NOCLIP>(E, pts, n, sw, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny_j,
                                              &sh->near_cnt[slot], sh->near_list[slot]);
         NDTPSO_PB(4);
         __syncthreads();
         NDTPSO_PSO_MARK(2);
         NDTPSO_PB(6);
-        if (MODE == kScoreF32 && sh->tiny) {
+        // (an item behind the phase's first improver does not count: whether it was evaluated at all depends on timing, and
+        // it is proposed again against the new gbest -- the alignment's fate must not hang on it)
+        if (MODE == kScoreF32 && sh->tiny_j <= min(sh->jstar[slot], P - 1)) {
           if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
           return false;
         }
