@@ -91,9 +91,11 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
 #   budget  -DNDTPSO_PHASE_BUDGET   per-workgroup, per-phase clocks (scripts/phase_budget.py)
 #   verify  -DNDTPSO_VERIFY_MARGIN  every fp32 score checked against its fp64 value and an a-priori error bound
 #                                   (scripts/verify_margin.py, tests/test_gpu_margin.py)
+#   why     -DNDTPSO_WHY_BITS       status bits that say why an alignment was handed to the fp64-score kernel (scripts/shape_diag.py)
 #   broken  -DNDTPSO_BREAK_ARBITRATION  the arbitration's unit form returns scores that are off by 2^-44: what the start-up check
 #                                   of the exact mode exists to catch (tests/test_gpu_exact_check.py loads it in a subprocess)
-VARIANTS = {"budget": ["-DNDTPSO_PHASE_BUDGET"], "verify": ["-DNDTPSO_VERIFY_MARGIN"], "broken": ["-DNDTPSO_BREAK_ARBITRATION"]}
+VARIANTS = {"budget": ["-DNDTPSO_PHASE_BUDGET"], "verify": ["-DNDTPSO_VERIFY_MARGIN"], "broken": ["-DNDTPSO_BREAK_ARBITRATION"],
+            "why": ["-DNDTPSO_WHY_BITS"]}
 
 
 def variant_path(name: str) -> str:

@@ -1086,6 +1086,7 @@ struct Plan {
   Layout L;
   DenseP dn;
   int dense_cap;  // cell-table entries provisioned (fused kernel: the window is chosen per alignment)
+  bool shrunk;    // ... fewer than the static window's: an alignment's box may not fit (kStatusNeedsBitmap)
 };
 // `wn` is the staging window: final for a prebuilt table; for the fused pairs kernel (dynamic_window) it is the
 // static range box -- the worst case the bitmap form must hold -- while the dense form sizes its window per
@@ -1094,9 +1095,12 @@ struct Plan {
 // CU still beats bitmap at two), swarm in LDS over swarm in HBM.
 // allow_global: when neither form fits, read the table from its HBM image (path 4 / 5; kernels that stage a prebuilt
 // table only -- a long-lived map can hold more built cells than LDS has room for).
+// big_table (fused pairs kernel, a redo launch): the largest table a workgroup can hold, whatever that does to the number of
+// workgroups per compute unit -- for the alignments whose box did not fit the table of the first launch
 bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan* plan, bool dynamic_window = false,
-               bool allow_dense = true, bool allow_global = false, bool exact = false) {
+               bool allow_dense = true, bool allow_global = false, bool exact = false, bool big_table = false) {
   const int bitmap_path = g.cs_pow2 ? 1 : 0;
+  plan->shrunk = false;
   int force = -1;
   if (const char* e = std::getenv("NDTPSO_PATH")) force = std::atoi(e);  // tuning knob
   // (fp64 score: the dense form exists in the fused pairs kernel only -- dynamic_window -- and needs every record below 64 KB)
@@ -1110,10 +1114,11 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
       const int full_w = wn.w + 1, full_h = wn.h + 1;
       Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, full_w, full_h, swarm_global != 0, exact, dynamic_window);
       int cap = dense_entries(full_w, full_h);
-      if (dynamic_window && Ld.total > kMaxLds / 2) {
+      if (dynamic_window && Ld.total > (big_table ? kMaxLds : kMaxLds / 2)) {
         // shrink the provisioned (square) table until two workgroups fit per CU, else until one does;
         // never below 64 x 64 cells
         for (int limit : {kMaxLds / 2, kMaxLds}) {
+          if (big_table && limit != kMaxLds) continue;
           bool found = false;
           for (int side = (int)std::sqrt((double)(full_w * full_h)); side >= 64; side -= 4) {
             const Layout Lt = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0, exact, dynamic_window);
@@ -1132,6 +1137,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         plan->L = Ld;
         plan->dn = make_dense(g, wn, Ld);
         plan->dense_cap = cap;
+        plan->shrunk = cap < dense_entries(full_w, full_h);
         return true;
       }
     }
@@ -2023,12 +2029,12 @@ static int align_finish(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_con
 
 static int pairs_plan(const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const ndtpso_pso_config* cfg, int mode,
                       unsigned n_pairs, GridP* g, WinP* wn, Plan* plan, int* waves, bool allow_dense = true,
-                      unsigned n_cus = 0, bool exact = false) {
+                      unsigned n_cus = 0, bool exact = false, bool big_table = false) {
   if (!geom || geom->n_beams == 0 || !cfg || cfg->population < 1 || cfg->iterations < 0) return NDTPSO_E_ARG;
   if (make_grid(grid, g) != NDTPSO_OK) return NDTPSO_E_ARG;
   const double r = (double)geom->max_range;
   *wn = make_window(*g, -r, r, -r, r, (int)(geom->n_beams / 3) + 1);
-  const bool ok = make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan, true, allow_dense, false, exact);
+  const bool ok = make_plan(mode, *g, *wn, (int)geom->n_beams, cfg->population, plan, true, allow_dense, false, exact, big_table);
   *waves = pick_waves(cfg->population, plan->L.total, n_pairs, n_cus);
   return ok ? NDTPSO_OK : NDTPSO_E_CAPACITY;
 }
@@ -2077,7 +2083,8 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
                         const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* d_guess, const double* d_dev,
                         const ndtpso_pso_config* cfg, const uint32_t* d_seeds, const int32_t* d_tables, int mode,
                         double* d_pose, double* d_cost, AlignStats* d_stats, uint32_t gate, bool allow_dense,
-                        int* path_out, bool allow_cluster = false, bool exact = false) {
+                        int* path_out, bool allow_cluster = false, bool exact = false, bool big_table = false,
+                        bool* shrunk_out = nullptr) {
   if (!cfg || cfg->population < 1) return fail(c, NDTPSO_E_ARG, "bad scan/grid/PSO configuration");
   // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
   int K = 1, cw = 4;
@@ -2090,8 +2097,9 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   int waves = 0;
   // (the fp64 score's dense form runs one workgroup per alignment: a cluster keeps the bitmap form)
   const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves,
-                            allow_dense && !(mode == NDTPSO_SCORE_F64 && K > 1), (unsigned)c->n_cus, exact);
+                            allow_dense && !(mode == NDTPSO_SCORE_F64 && K > 1), (unsigned)c->n_cus, exact, big_table);
   if (path_out) *path_out = plan.path;
+  if (shrunk_out) *shrunk_out = plan.shrunk;
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
   if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
   ScanP sp;
@@ -2251,10 +2259,20 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
     mode = (rc0 == NDTPSO_OK && p0.path == 2) ? NDTPSO_SCORE_F32 : NDTPSO_SCORE_F64;
     exact = mode == NDTPSO_SCORE_F32;
   }
+  bool shrunk = false;
   int rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
-                        st, 0u, true, &path, small_batch, exact);
+                        st, 0u, true, &path, small_batch, exact, false, &shrunk);
   if (rc != NDTPSO_OK) return rc;
   if (std::getenv("NDTPSO_NO_REDO")) return rc;  // diagnostics only
+  // Gated redo launches (every workgroup whose alignment is not flagged exits on its first instruction).  First of all: the
+  // dense forms size their cell table so that two workgroups share a compute unit; an alignment whose box -- scan A's
+  // occupied cells -- outgrew that table gets the same kernel again with the largest table a workgroup can hold (0.25 m cells,
+  // a room seen at an angle: 7 of 512 pairs; 1441 beams at 0.3 m: 370 of 512), before anything slower is considered
+  if (shrunk && (path == 2 || path >= 8) && !small_batch) {
+    rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
+                      st, kStatusNeedsBitmap, true, nullptr, false, exact, true);
+    if (rc != NDTPSO_OK && rc != NDTPSO_E_CAPACITY) return rc;
+  }
   if (small_batch) {  // a cluster that was not co-resident gave up (bounded wait): those alignments on one workgroup each
     rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
                       st, kStatusClusterTimeout, true, nullptr, false, exact);
@@ -2280,8 +2298,15 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
                       d_cost, st, kStatusNeedsBitmap, false, nullptr);
     if (rc != NDTPSO_OK && rc != NDTPSO_E_CAPACITY) return rc;
   }
+  // (the fp64 score's dense form first -- it sets kStatusNeedsBitmap itself where it cannot run --, the bitmap form for what is left)
+  int path64 = 0;
   rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose,
-                    d_cost, st, exact ? (kStatusNeedsF64 | kStatusNeedsBitmap) : kStatusNeedsF64, false, nullptr);
+                    d_cost, st, exact ? (kStatusNeedsF64 | kStatusNeedsBitmap) : kStatusNeedsF64, true, &path64);
+  if (rc != NDTPSO_OK && rc != NDTPSO_E_CAPACITY) return rc;
+  if (path64 >= 8) {
+    rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose,
+                      d_cost, st, kStatusNeedsBitmap, false, nullptr);
+  }
   return rc == NDTPSO_E_CAPACITY ? NDTPSO_OK : rc;
 }
 

@@ -926,19 +926,36 @@ __device__ __forceinline__ void score_trip_d64(const GridP& g, unsigned stride, 
   for (int u = 0; u < U; ++u) p[u] = pts[base + u * kWave + lane];
   double qx[U], qy[U];
   unsigned ea[U];
+  int ix[U], iy[U];
+  [[maybe_unused]] bool amb = false;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     qx[u] = (p[u].x * c - p[u].y * s) + tx;  // transform_point, reference rounding (core.h:28-31): no fma
     qy[u] = (p[u].x * s + p[u].y * c) + ty;
-    int ix, iy;
     if constexpr (POW2) {
-      ix = (int)fma(qx[u], g.inv_cs, hwi);  // = (int)((qx + hw) * inv_cs): hwi = hw * inv_cs, a power-of-two scaling
-      iy = (int)fma(qy[u], g.inv_cs, hhi);
+      ix[u] = (int)fma(qx[u], g.inv_cs, hwi);  // = (int)((qx + hw) * inv_cs): hwi = hw * inv_cs, a power-of-two scaling
+      iy[u] = (int)fma(qy[u], g.inv_cs, hhi);
     } else {
-      cell_coords<false>(g, qx[u], qy[u], ix, iy);
+      // Any other cell side: floor(fl((x + w/2) / cs)) (ndtframe.cpp:244-245) by reciprocal.  t = fl(u fl(1 / cs)) and the
+      // correctly rounded quotient both lie within 2.2e-11 of u / cs (u / cs < 65536 inside the frame), so their floors can
+      // differ only if an integer lies that close to t: then -- 2e-10 of all points -- the trip takes the true divisions
+      // (below).  Two fp64 divisions per point were 60 of this trip's 110 instructions per point.
+      const double ux = (qx[u] + g.hw) * g.inv_cs, uy = (qy[u] + g.hh) * g.inv_cs;
+      ix[u] = (int)ux;
+      iy[u] = (int)uy;
+      amb |= (int)(fabs(ux - __builtin_rint(ux)) < 1e-10) | (int)(fabs(uy - __builtin_rint(uy)) < 1e-10);
     }
+  }
+  if constexpr (!POW2) {
+    if (__builtin_expect(__any((int)amb), 0)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cell_coords<false>(g, qx[u], qy[u], ix[u], iy[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
     unsigned t;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(iy), "s"(stride), "v"(ix));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(t) : "v"(iy[u]), "s"(stride), "v"(ix[u]));
     asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(ea[u]) : "v"(t), "s"(tab_a));
     if constexpr (MASK)
       if (u == U - 1) ea[u] = (base + u * kWave + lane < n) ? ea[u] : null_a;
@@ -1879,6 +1896,11 @@ struct EvalCtx {
 // PATH 2 and 3 are the dense form (3: table entries are byte addresses, see score_trip_dense)
 __host__ __device__ constexpr bool path_is_dense(int path) { return path == 2 || path == 3; }
 constexpr uint32_t kStatusNeedsF64 = 4u;
+#ifdef NDTPSO_WHY_BITS  // diagnostic builds (scripts/shape_diag.py): why an alignment was handed to the fp64-score kernel -- 0x100 / 0x200
+#define NDTPSO_WHY(bit) (bit)  // underflow regime / more than kMaxNear near-ties at the swarm's initialisation, 0x400 / 0x800 in an iteration
+#else
+#define NDTPSO_WHY(bit) 0u
+#endif
 constexpr uint32_t kStatusNeedsBitmap = 8u;  // dense form: the occupied box exceeds the provisioned cell table
 constexpr double kTinyCost = 1e-28;
 
@@ -2530,7 +2552,10 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       // these few instructions are issued once per evaluation by every wave, about 1 % of the kernel)
       bool ordinary = true;
       if (MODE == kScoreF32 && !(cost <= -kTinyCost)) {  // NaN, or the underflow regime
-        if (cost != cost || !improver || pbc_j > -kTinyCost) {
+        // (exact mode: a cost in the underflow regime lies within the arbitration margin -- never below 7e-7 per point -- of
+        // whatever it could be confused with, so the comparison is arbitrated in fp64 like any other near tie and nothing
+        // needs handing over; only a NaN, which no comparison notices, still does)
+        if (cost != cost || (!ARB && (!improver || pbc_j > -kTinyCost))) {
           *tiny = 1;  // the alignment is handed to the fp64-score kernel (see pso_run_wg)
           ordinary = false;
         }
@@ -2650,8 +2675,8 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
     if (lane_id() == 0) {  // (as eval_items, with an improver to look for)
       sw.tcost[j] = cost;
       bool ordinary = true;
-      if (MODE == kScoreF32 && !(cost <= -kTinyCost)) {  // NaN, or the underflow regime
-        if (cost != cost || pbc_j > -kTinyCost) {
+      if (MODE == kScoreF32 && !(cost <= -kTinyCost)) {  // NaN, or the underflow regime (exact mode: NaN only, see eval_items)
+        if (cost != cost || (!ARB && pbc_j > -kTinyCost)) {
           __hip_atomic_fetch_min((lds_int_t)tiny, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (tiny: PsoShared::tiny_j here)
           ordinary = false;
         }
@@ -2884,8 +2909,8 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
         }
         if (mine) {
           sw.tcost[j] = cost;
-          if (MODE == kScoreF32 && (cost != cost || (cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))))
-            *tiny = 1;
+          if (MODE == kScoreF32 && (cost != cost || (!ARB && cost > -kTinyCost && (!improver || sw.pbc[j] > -kTinyCost))))
+            *tiny = 1;  // (exact mode: NaN only, see eval_items)
           else if (improver && cost < gbc && cost < sw.pbc[j])  // nested tests of core.cpp:94-104, see eval_items
             atomicMin(improver, j);
           if constexpr (ARB) {  // exact mode, as in eval_items: every workgroup of the cluster notes the same items
@@ -3019,7 +3044,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     return false;
   }
   if (MODE == kScoreF32 && sh->tiny) {  // underflow regime: give up, the fp64-score kernel redoes this alignment
-    if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+    if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64 | NDTPSO_WHY(0x100u);
     return false;
   }
   if constexpr (ARB) {
@@ -3040,7 +3065,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
       __syncthreads();
       const int cnt = sh->near_cnt[0];
       if (__builtin_expect(cnt > kMaxNear, 0)) {  // a swarm of near-identical costs: the fp64-score kernel takes the whole alignment
-        if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+        if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64 | NDTPSO_WHY(0x200u);
         return false;
       }
       if (__builtin_expect(cnt > 1, 0)) {  // (cold: the register allocator must not charge the evaluation loops for it)
@@ -3256,7 +3281,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         // (an item behind the phase's first improver does not count: whether it was evaluated at all depends on timing, and
         // it is proposed again against the new gbest -- the alignment's fate must not hang on it)
         if (MODE == kScoreF32 && sh->tiny_j <= min(sh->jstar[slot], P - 1)) {
-          if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+          if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64 | NDTPSO_WHY(0x400u);
           return false;
         }
         n_evals += (uint32_t)(sh->jmax - lo + 1);
@@ -3282,7 +3307,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             __syncthreads();
             const int cnt = sh->near_cnt[slot];
             if (__builtin_expect(cnt > kMaxNear, 0)) {  // (a converged swarm: nearly every comparison is a near-tie)
-              if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+              if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64 | NDTPSO_WHY(0x800u);
               return false;
             }
             if (cnt != 0) {
@@ -3365,7 +3390,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           return false;
         }
         if (MODE == kScoreF32 && sh->tiny) {
-          if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+          if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64 | NDTPSO_WHY(0x400u);
           return false;
         }
         if constexpr (ARB) {
@@ -3376,7 +3401,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
               const unsigned long long arb_t0 = wall_clock64();
 #endif
               if (__builtin_expect(cnt > kMaxNear, 0)) {  // (a converged swarm: nearly every comparison is a near-tie)
-                if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64;
+                if (tid == 0 && stats && writer) stats->status |= kStatusNeedsF64 | NDTPSO_WHY(0x800u);
                 return false;
               }
               // fp64 scores of the undecidable items' proposals and pbest positions and of the gbest position replace
