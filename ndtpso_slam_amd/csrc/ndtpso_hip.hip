@@ -570,7 +570,8 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
               const double* __restrict__ dev, const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables,
               size_t table_stride, unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
               double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl,
-              const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride) {
+              const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride,
+              uint32_t* __restrict__ feedback /* counts the alignments whose box outgrew the cell table (pinned host word) */) {
   size_t b = blockIdx.x;
   if constexpr (CLUSTER) {
     if (!cluster_place(cl, &b, &cl.rank)) return;
@@ -644,7 +645,10 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     dn.oy = wn.y0 - 1;
     dense_set_limits(dn, g.hw, g.hh, g.inv_cs);
     if (dense_entries(dn.dw, dn.dh) > dense_cap) {  // uniform (and the same in every workgroup of a cluster)
-      if (threadIdx.x == 0 && writer) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
+      if (threadIdx.x == 0 && writer) {
+        stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
+        if (feedback) __hip_atomic_fetch_add(feedback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       return;
     }
   }
@@ -682,7 +686,10 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     dn.ox = wn.x0 - 1;
     dn.oy = wn.y0 - 1;
     if (dense_entries(dn.dw, dn.dh) > dense_cap) {  // uniform
-      if (threadIdx.x == 0) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
+      if (threadIdx.x == 0) {
+        stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
+        if (feedback) __hip_atomic_fetch_add(feedback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       return;
     }
   }
@@ -942,6 +949,14 @@ struct ndtpso_ctx {
   bool inputs_pinned = false;         // `inputs` is a pinned host slot (the kernel fetches the table from there itself)
   const void* inputs = nullptr;       // [guess | deviation | pad to kGuessBytes | rand() table] of the alignment about to be launched:
                                       // `table` (uploaded) or a pinned slot the kernel reads in place (ndtpso_map_align)
+  // Batches whose cell tables keep overflowing (ndtpso_align_pairs*): the fused kernel counts the alignments whose occupied
+  // box outgrew the table sized for two workgroups per compute unit into a pinned word; when more than a quarter of a
+  // call's pairs did, the next calls of the same configuration start with the largest table instead (one workgroup per
+  // compute unit) -- a scheduling decision only: the results do not depend on it
+  uint32_t* pairs_fb = nullptr;
+  uint32_t fb_seen = 0, fb_last_pairs = 0;
+  uint64_t fb_key = 0;
+  bool fb_big_first = false;
   void* result_pinned = nullptr;      // pinned landing slot of one alignment's pose / cost / statistics (align_once)
   hipEvent_t result_event = nullptr;
 };
@@ -1295,6 +1310,7 @@ void ndtpso_ctx_destroy(ndtpso_ctx* c) {
   if (c->pipe_in) (void)hipEventDestroy(c->pipe_in);
   if (c->result_event) (void)hipEventDestroy(c->result_event);
   if (c->result_pinned) (void)hipHostFree(c->result_pinned);
+  if (c->pairs_fb) (void)hipHostFree(c->pairs_fb);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -2084,7 +2100,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
                         const ndtpso_pso_config* cfg, const uint32_t* d_seeds, const int32_t* d_tables, int mode,
                         double* d_pose, double* d_cost, AlignStats* d_stats, uint32_t gate, bool allow_dense,
                         int* path_out, bool allow_cluster = false, bool exact = false, bool big_table = false,
-                        bool* shrunk_out = nullptr) {
+                        bool* shrunk_out = nullptr, uint32_t* fb = nullptr) {
   if (!cfg || cfg->population < 1) return fail(c, NDTPSO_E_ARG, "bad scan/grid/PSO configuration");
   // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
   int K = 1, cw = 4;
@@ -2134,7 +2150,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM>), dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), lds_total, \
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
                      d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
-                     cl, dirs, d_ximg, ximg_stride)
+                     cl, dirs, d_ximg, ximg_stride, fb)
 // (the kernels without clipping trips exist per home of the swarm, the others carry both copies of the PSO)
 #define LAUNCH_PAIRS_CAN(MODE, PATH, CL, ARB, NOCLIP)                                    \
   do {                                                                                   \
@@ -2260,8 +2276,34 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
     exact = mode == NDTPSO_SCORE_F32;
   }
   bool shrunk = false;
+  // (what the previous call of this configuration reported: see ndtpso_ctx::pairs_fb)
+  if (!c->pairs_fb) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->pairs_fb, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *c->pairs_fb = 0;
+  }
+  {
+    uint64_t key = 1469598103934665603ull;
+    auto mix = [&key](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
+    mix(geom->n_beams), mix((uint64_t)(geom->max_range * 1024.f)), mix(grid->width), mix(grid->height), mix((uint64_t)(grid->cell_side * 65536.));
+    mix((uint64_t)cfg->population), mix((uint64_t)mode), mix(exact ? 1 : 0);
+    const uint32_t now = __atomic_load_n(c->pairs_fb, __ATOMIC_RELAXED);
+    if (key != c->fb_key) {
+      c->fb_key = key;
+      c->fb_big_first = false;
+    } else if (!c->fb_big_first && c->fb_last_pairs && (uint64_t)(now - c->fb_seen) * 4u > c->fb_last_pairs) {
+      c->fb_big_first = true;
+      static const bool log_plan = std::getenv("NDTPSO_LOG_PLAN") != nullptr;  // diagnostics
+      if (log_plan)
+        std::fprintf(stderr, "ndtpso: %u of the last call's %u pairs outgrew the two-per-CU cell table: largest table first from now on\n",
+                     now - c->fb_seen, c->fb_last_pairs);
+    }
+    c->fb_seen = now;
+    c->fb_last_pairs = n_pairs;
+  }
+  const bool big_first = c->fb_big_first && !small_batch;
   int rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
-                        st, 0u, true, &path, small_batch, exact, false, &shrunk);
+                        st, 0u, true, &path, small_batch, exact, big_first, &shrunk, big_first ? nullptr : c->pairs_fb);
+  if (big_first) shrunk = false;  // (nothing larger to fall back to)
   if (rc != NDTPSO_OK) return rc;
   if (std::getenv("NDTPSO_NO_REDO")) return rc;  // diagnostics only
   // Gated redo launches (every workgroup whose alignment is not flagged exits on its first instruction).  First of all: the

@@ -995,13 +995,31 @@ __device__ __forceinline__ void score_trip_d64_tested(const GridP& g, const Dens
   double qx[U], qy[U];
   unsigned lin[U];
   bool in[U];
+  int cx[U], cy[U];
+  [[maybe_unused]] bool amb = false;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     qx[u] = (p[u].x * c - p[u].y * s) + tx;
     qy[u] = (p[u].x * s + p[u].y * c) + ty;
+    if constexpr (POW2) {
+      cell_coords<true>(g, qx[u], qy[u], cx[u], cy[u]);
+    } else {  // by reciprocal, the true divisions only where an integer lies within 1e-10 of a quotient (score_trip_d64)
+      const double ux = (qx[u] + g.hw) * g.inv_cs, uy = (qy[u] + g.hh) * g.inv_cs;
+      cx[u] = (int)ux;
+      cy[u] = (int)uy;
+      amb |= (int)(fabs(ux - __builtin_rint(ux)) < 1e-10) | (int)(fabs(uy - __builtin_rint(uy)) < 1e-10);
+    }
+  }
+  if constexpr (!POW2) {
+    if (__builtin_expect(__any((int)amb), 0)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cell_coords<false>(g, qx[u], qy[u], cx[u], cy[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
     const bool inframe = (int)(fabs(qx[u]) < g.hw) & (int)(fabs(qy[u]) < g.hh);  // strict bounds, ndtframe.cpp:242
-    int ix, iy;
-    cell_coords<POW2>(g, qx[u], qy[u], ix, iy);
+    int ix = cx[u], iy = cy[u];
     const bool wrap = (ix == g.W);  // fl(x + w/2) == w: the reference's linear index lands in the next row
     ix = wrap ? 0 : ix;
     iy = wrap ? iy + 1 : iy;

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=512)
     ap.add_argument("--launches", type=int, default=8)
     ap.add_argument("--oracle-pairs", type=int, default=8)
+    ap.add_argument("--beams", default="", help="comma-separated subset of the beam counts")
     ap.add_argument("--quick", action="store_true", help="beams {541, 1081, 2048} x cells {0.3, 0.5} x frames {60, 100}")
     args = ap.parse_args()
     import torch
@@ -46,6 +47,8 @@ def main():
     cfg = capi.PSOConfig.make(I, P)
     modes = {"exact": capi.SCORE_EXACT, "f32": capi.SCORE_F32, "f64": capi.SCORE_F64}
     beams_l, cells_l, frames_l = (BEAMS, CELLS, FRAMES) if not args.quick else ([541, 1081, 2048], [0.3, 0.5], [60, 100])
+    if args.beams:
+        beams_l = [int(b) for b in args.beams.split(",")]
     rows = []
     for nb in beams_l:
         p = synth.make_pairs(B, n_beams=nb, seed=2024)
