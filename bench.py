@@ -324,8 +324,16 @@ def main():
             out["extra"]["live_sequence"] = {"error": str(e)}
         try:
             out["extra"]["live_sequence_cpp_drop_in"] = _live_sequence_cpp(synth, args.score)
+            # ... and at the node's own default frame (100 m x 100 m, include/ndtpso_slam_node.hpp:25-26)
+            out["extra"]["live_sequence_cpp_drop_in_node_default_frame"] = _live_sequence_cpp(synth, args.score, frame=100)
         except Exception as e:  # noqa: BLE001
             out["extra"]["live_sequence_cpp_drop_in"] = {"error": str(e)}
+        try:
+            # R replicas of that sequence in one process, a host thread + device context + stream each (the
+            # live stream does not shard -- "replicas only"): what one GPU delivers when it serves R robots
+            out["extra"]["live_replicas"] = [_live_replicas(synth, args.score, R) for R in (1, 4, 16, 32)]
+        except Exception as e:  # noqa: BLE001
+            out["extra"]["live_replicas"] = {"error": str(e)}
 
     # CPU baseline: the oracle -- a port of the reference's algorithm -- on this box's host cores
     if rank == 0 and world == 1 and args.cpu_sample > 0:
@@ -389,7 +397,38 @@ def _live_sequence(ctx, capi, synth, mode, n_scans=60):
             "map_cells_built": int(info["n_built"]), "through": "ctypes binding (host/replay/node_replay.cpp is the C++ equivalent)"}
 
 
-def _live_sequence_cpp(synth, score, n_scans=200):
+def _write_live_scans(synth, path, n_scans):
+    rng = np.random.default_rng(4)
+    s = np.linspace(0.0, 0.6, n_scans)
+    poses = np.stack([2.0 + 1.2 * s, -1.0 + 0.8 * np.sin(1.5 * s), 0.3 + 0.25 * s], axis=1)
+    clean = synth.raycast(poses)
+    ranges = np.where(clean > 0, clean + rng.normal(0, 0.01, clean.shape), 0.0).astype(np.float32)
+    with open(path, "wb") as f:
+        np.array([n_scans, synth.N_BEAMS], dtype=np.int32).tofile(f)
+        np.array([synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX], dtype=np.float32).tofile(f)
+        ranges.tofile(f)
+
+
+def _live_replicas(synth, score, R, n_scans=120):
+    """host/replay/node_replicas: R node sequences (30 x 50 PSO, resident map) on R host threads of one process."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "host", "replay", "node_replicas")
+    if not os.path.exists(exe):
+        return {"replicas": R, "error": "host/replay/node_replicas is not built (make -C host)"}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "scans.bin")
+        _write_live_scans(synth, path, n_scans)
+        r = subprocess.run([exe, path, str(FRAME_M), str(CELL_SIDE), "50", "30", "7", str(R)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, NDTPSO_RESIDENT="1", NDTPSO_SCORE=score))
+    if r.returncode != 0 or not r.stdout.strip():
+        return {"replicas": R, "error": "node_replicas failed: " + r.stderr[-300:]}
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    d["score"] = score
+    return d
+
+
+def _live_sequence_cpp(synth, score, n_scans=200, frame=FRAME_M):
     """The same sequence through the C++ drop-in library itself: host/replay/node_replay makes the node's calls
     (NDTFrame::loadLaser / align / update, re-allocation of the per-scan frame; ndtpso_slam_node.cpp:177-244) on
     libndtpso_slam.so, frames resident on the device, and reports the node's own "matching rate" (:239)."""
@@ -399,23 +438,15 @@ def _live_sequence_cpp(synth, score, n_scans=200):
     exe = os.path.join(ROOT, "host", "replay", "node_replay")
     if not os.path.exists(exe):
         return {"error": "host/replay/node_replay is not built (make -C host)"}
-    rng = np.random.default_rng(4)
-    s = np.linspace(0.0, 0.6, n_scans)
-    poses = np.stack([2.0 + 1.2 * s, -1.0 + 0.8 * np.sin(1.5 * s), 0.3 + 0.25 * s], axis=1)
-    clean = synth.raycast(poses)
-    ranges = np.where(clean > 0, clean + rng.normal(0, 0.01, clean.shape), 0.0).astype(np.float32)
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "scans.bin")
-        with open(path, "wb") as f:
-            np.array([n_scans, synth.N_BEAMS], dtype=np.int32).tofile(f)
-            np.array([synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX], dtype=np.float32).tofile(f)
-            ranges.tofile(f)
-        r = subprocess.run([exe, path, str(FRAME_M), str(CELL_SIDE), "50", "30", "7"], capture_output=True, text=True, timeout=120,
+        _write_live_scans(synth, path, n_scans)
+        r = subprocess.run([exe, path, str(frame), str(CELL_SIDE), "50", "30", "7"], capture_output=True, text=True, timeout=120,
                            env=dict(os.environ, NDTPSO_RESIDENT="1", NDTPSO_SCORE=score))
     m = re.search(r"matching rate: ([0-9.]+) Hz \(([0-9.]+) ms per scan\)", r.stderr)
     if r.returncode != 0 or not m:
         return {"error": "node_replay failed: " + r.stderr[-300:]}
-    return {"scans_per_s": float(m.group(1)), "ms_per_scan": float(m.group(2)), "pso": "30 x 50", "scans": n_scans, "score": score,
+    return {"scans_per_s": float(m.group(1)), "ms_per_scan": float(m.group(2)), "pso": "30 x 50", "scans": n_scans, "score": score, "frame_m": frame,
             "through": "libndtpso_slam.so (C++ drop-in), host/replay/node_replay; per scan: loadLaser + align + update"}
 
 

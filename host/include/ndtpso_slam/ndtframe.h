@@ -26,6 +26,10 @@ struct ndtpso_map;     // device-resident map
 // call rand().  ndtpso_slam_last_error() / ndtpso_slam_error_count(): what a failed (skipped) device call left behind.
 #include "ndtpso_slam/status.h"
 
+namespace ndtpso_host {
+struct Ctx;
+}
+
 class NDTFrame {
  public:
   uint16_t width, height, widthNumOfCells, heightNumOfCells;
@@ -123,6 +127,15 @@ class NDTFrame {
   uint32_t d_scan_cap_{0};
   ndtpso_map* ensureMap();
   void residentPoints(bool slot0_only, std::vector<double>& xy) const;
+  // the device context this frame lives in: the calling thread's at the frame's first device operation, then for good
+  // (host/src/device.h: one context per host thread; every device-touching member locks and uses this one)
+  mutable ndtpso_host::Ctx* s_dev{nullptr};
+  ndtpso_host::Ctx* dev() const;
+  unsigned long s_updates_refused{0};
+
+ public:
+  // update() calls refused because the frame's last align() had failed on the device (see update()); not in the reference
+  unsigned long updatesRefused() const { return s_updates_refused; }
 };
 
 #endif

@@ -23,8 +23,19 @@ const char* ndtpso_slam_last_error(void);
 /* number of failed (skipped) device calls since start-up or the last ndtpso_slam_clear_error() */
 unsigned long ndtpso_slam_error_count(void);
 void ndtpso_slam_clear_error(void);
-/* creates the process-wide device context now instead of at the first frame operation */
+/* creates the calling thread's device context now instead of at its first frame operation.  Every host thread that uses
+ * frames gets a context of its own (stream, workspaces, staged table): frames used by different threads run concurrently on
+ * the device.  A frame belongs to the context of the thread that first used it and may be handed to another thread (its
+ * calls are then serialised against that context's other users). */
 void ndtpso_slam_device_init(void);
+/* The reference draws its PSO's random numbers from the process-wide std::rand() (Eigen's Random(), core.cpp:14,84): ONE
+ * stream for every thread, so two matchers in one process disturb each other's streams -- in the reference as here.
+ * ndtpso_slam_thread_srand(seed) gives the CALLING THREAD a private generator instead (glibc's own algorithm on private
+ * state: the numbers srand(seed) + rand() would produce if the thread were alone); from then on the alignments that thread
+ * runs draw from it and leave std::rand() untouched.  ndtpso_slam_thread_rand() is its rand() (std::rand() on a thread
+ * that never seeded one).  An addition of this build: replicas of the live sequence in one process stay reproducible. */
+void ndtpso_slam_thread_srand(unsigned seed);
+int ndtpso_slam_thread_rand(void);
 
 #ifdef __cplusplus
 }

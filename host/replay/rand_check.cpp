@@ -6,7 +6,10 @@
 #include <vector>
 #include <cstdint>
 #include <chrono>
+#include <thread>
 namespace ndtpso_host { void draw_rand(int32_t* out, size_t n); }
+extern "C" void ndtpso_slam_thread_srand(unsigned seed);
+extern "C" int ndtpso_slam_thread_rand(void);
 int main() {
   // the bulk draw must be indistinguishable from n calls of rand(), from any state
   for (unsigned seed : {1u, 7u, 123456789u}) {
@@ -22,6 +25,31 @@ int main() {
       const int next_got = std::rand();
       if (want != got || next_want != next_got) { std::printf("MISMATCH seed %u n %zu\n", seed, n); return 1; }
     }
+  }
+  // a thread's private generator (ndtpso_slam_thread_srand) is srand(seed) + rand() on private state: same numbers, and the
+  // process-wide generator does not move (run on a thread of its own: the seeding is per thread and for good)
+  {
+    bool ok = true;
+    std::thread th([&ok] {
+      for (unsigned seed : {0u, 1u, 42u, 2147483647u, 4000000000u}) {
+        std::srand(seed);
+        std::vector<int32_t> want(20000);
+        for (auto& v : want) v = std::rand();
+        std::srand(99u);
+        const int global_next = [] { std::srand(99u); return std::rand(); }();
+        std::srand(99u);
+        ndtpso_slam_thread_srand(seed);
+        std::vector<int32_t> got(20000);
+        for (size_t i = 0; i < 7; ++i) got[i] = ndtpso_slam_thread_rand();
+        ndtpso_host::draw_rand(got.data() + 7, got.size() - 7);
+        if (want != got || std::rand() != global_next) {
+          std::printf("MISMATCH private generator, seed %u\n", seed);
+          ok = false;
+        }
+      }
+    });
+    th.join();
+    if (!ok) return 1;
   }
   std::vector<int32_t> buf(9093);
   auto t0 = std::chrono::steady_clock::now();

@@ -7,19 +7,26 @@
 #include <cstring>
 #include <atomic>
 #include <mutex>
+#include <thread>
 #include <set>
 #include <string>
 #include <utility>
 #include <vector>
 
 namespace ndtpso_host {
+struct Ctx {
+  ndtpso_ctx* c = nullptr;
+  std::recursive_mutex mu;
+  const void* table_owner = nullptr;
+  std::vector<std::pair<ndtpso_points*, uint32_t>> scan_pool;
+};
 
 namespace {
-ndtpso_ctx* g_ctx = nullptr;
-std::once_flag g_once;
-bool g_alive = false;
-std::vector<std::pair<ndtpso_points*, uint32_t>> g_scan_pool;
-std::mutex g_pool_mutex;
+std::mutex g_registry_mutex;
+std::vector<Ctx*> g_registry;  // every context ever made (they outlive their threads: frames may)
+bool g_alive = false, g_atexit = false;
+thread_local Ctx* t_own = nullptr;     // this thread's context
+thread_local Ctx* t_active = nullptr;  // the innermost Use's
 
 // error state of the library (ndtpso_slam/status.h)
 std::mutex g_err_mutex;
@@ -53,34 +60,54 @@ void record_error(const char* what, int rc, const char* text) {
 }
 }  // namespace
 
-ndtpso_ctx* device() {
-  std::call_once(g_once, [] {
-    int dev = 0;
-    if (const char* e = std::getenv("NDTPSO_DEVICE")) dev = std::atoi(e);
-    const int rc = ndtpso_ctx_create(dev, &g_ctx);
-    if (rc != NDTPSO_OK || !g_ctx) {
-      g_ctx = nullptr;  // every later device call fails with NDTPSO_E_ARG and is skipped: there is no CPU path
-      char what[96];
-      std::snprintf(what, sizeof(what), "creating a context on HIP device %d", dev);
-      record_error(what, rc, "no usable HIP device");
-      return;
+Ctx* thread_ctx() {
+  if (t_own) return t_own;
+  Ctx* x = new Ctx();
+  int dev = 0;
+  if (const char* e = std::getenv("NDTPSO_DEVICE")) dev = std::atoi(e);
+  const int rc = ndtpso_ctx_create(dev, &x->c);
+  if (rc != NDTPSO_OK || !x->c) {
+    x->c = nullptr;  // every later device call fails with NDTPSO_E_ARG and is skipped: there is no CPU path
+    char what[96];
+    std::snprintf(what, sizeof(what), "creating a context on HIP device %d", dev);
+    record_error(what, rc, "no usable HIP device");
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    g_registry.push_back(x);
+    if (x->c) g_alive = true;
+    if (!g_atexit) {
+      g_atexit = true;
+      std::atexit([] {
+        std::lock_guard<std::mutex> lock(g_registry_mutex);
+        g_alive = false;
+        for (Ctx* q : g_registry) {
+          for (auto& e : q->scan_pool) ndtpso_points_destroy(e.first);
+          q->scan_pool.clear();
+          if (q->c) ndtpso_ctx_destroy(q->c);
+          q->c = nullptr;
+        }
+      });
     }
-    g_alive = true;
-    std::atexit([] {
-      g_alive = false;
-      for (auto& e : g_scan_pool) ndtpso_points_destroy(e.first);
-      g_scan_pool.clear();
-      if (g_ctx) ndtpso_ctx_destroy(g_ctx);
-      g_ctx = nullptr;
-    });
-  });
-  return g_ctx;
+  }
+  t_own = x;
+  return x;
 }
 
-const void*& table_owner() {
-  static const void* owner = nullptr;
-  return owner;
+Use::Use(Ctx* ctx) : ctx_(ctx ? ctx : (t_active ? t_active : thread_ctx())), prev_(t_active) {
+  ctx_->mu.lock();
+  t_active = ctx_;
 }
+Use::~Use() {
+  t_active = prev_;
+  ctx_->mu.unlock();
+}
+
+static Ctx* active_ctx() { return t_active ? t_active : thread_ctx(); }
+
+ndtpso_ctx* device() { return active_ctx()->c; }
+
+const void*& table_owner() { return active_ctx()->table_owner; }
 
 bool alive() { return g_alive; }
 
@@ -90,27 +117,28 @@ bool resident_default() {
 }
 
 ndtpso_points* acquire_scan(uint32_t capacity) {
-  ndtpso_ctx* c = device();
+  Ctx* x = active_ctx();
   {
-    std::lock_guard<std::mutex> lock(g_pool_mutex);
-    for (size_t i = 0; i < g_scan_pool.size(); ++i)
-      if (g_scan_pool[i].second >= capacity) {
-        ndtpso_points* p = g_scan_pool[i].first;
-        g_scan_pool.erase(g_scan_pool.begin() + (long)i);
+    std::lock_guard<std::recursive_mutex> lock(x->mu);
+    for (size_t i = 0; i < x->scan_pool.size(); ++i)
+      if (x->scan_pool[i].second >= capacity) {
+        ndtpso_points* p = x->scan_pool[i].first;
+        x->scan_pool.erase(x->scan_pool.begin() + (long)i);
         return p;
       }
   }
   ndtpso_points* p = nullptr;
-  if (!check(ndtpso_points_create(c, capacity, &p), "scan buffer")) return nullptr;
+  if (!check(ndtpso_points_create(x->c, capacity, &p), "scan buffer")) return nullptr;
   return p;
 }
 
-void release_scan(ndtpso_points* p, uint32_t capacity) {
+void release_scan(ndtpso_points* p, uint32_t capacity) {  // (under a Use of the context the buffer was acquired from)
   if (!p) return;
-  if (!g_alive) return;  // the context is gone, and the device memory with it
-  std::lock_guard<std::mutex> lock(g_pool_mutex);
-  if (g_scan_pool.size() < 8)
-    g_scan_pool.emplace_back(p, capacity);
+  if (!g_alive) return;  // the contexts are gone, and the device memory with them
+  Ctx* x = active_ctx();
+  std::lock_guard<std::recursive_mutex> lock(x->mu);
+  if (x->scan_pool.size() < 8)
+    x->scan_pool.emplace_back(p, capacity);
   else
     ndtpso_points_destroy(p);
 }
@@ -177,7 +205,50 @@ bool fast_fill_verified() {
 #endif
 }  // namespace
 
+// A thread's PRIVATE generator (ndtpso_slam_thread_srand): glibc's TYPE_3 algorithm restated -- srandom_r's seeding (Park-Miller
+// by Schrage's method into 31 words, 310 outputs discarded), then r[i] = r[i-31] + r[i-3], output >> 1 -- on state of its own, so
+// that replicas of the live sequence in one process each see the stream srand(seed) + rand() would have given them alone
+// (the process-wide generator is one stream for everybody: with two threads drawing from it neither is reproducible, in
+// the reference as here).  host/replay/rand_check.cpp holds it to the libc's.
+namespace {
+struct PrivateRand {
+  bool on = false;
+  uint32_t t[31];
+  int f = 3, r = 0;
+  void seed(unsigned s) {
+    int32_t word = (int32_t)(s ? s : 1u);
+    t[0] = (uint32_t)word;
+    for (int i = 1; i < 31; ++i) {
+      const int32_t hi = word / 127773, lo = word % 127773;
+      word = 16807 * lo - 2836 * hi;
+      if (word < 0) word += 2147483647;
+      t[i] = (uint32_t)word;
+    }
+    f = 3;
+    r = 0;
+    int32_t sink;
+    for (int i = 0; i < 310; ++i) fill(&sink, 1);
+    on = true;
+  }
+  void fill(int32_t* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+      t[f] += t[r];
+      out[i] = (int32_t)(t[f] >> 1);
+      if (++f == 31) f = 0;
+      if (++r == 31) r = 0;
+    }
+  }
+};
+thread_local PrivateRand t_rand;
+std::mutex g_rand_mutex;  // the process-wide generator's state is edited in place (fast_fill)
+}  // namespace
+
 void draw_rand(int32_t* out, size_t n) {
+  if (t_rand.on) {
+    t_rand.fill(out, n);
+    return;
+  }
+  std::lock_guard<std::mutex> lock(g_rand_mutex);
 #if defined(__GLIBC__)
   if (fast_fill_verified() && fast_fill(out, n)) return;
 #endif
@@ -196,7 +267,8 @@ int score_mode() {
 
 bool check(int rc, const char* what) {
   if (rc == NDTPSO_OK) return true;
-  record_error(what, rc, g_ctx ? ndtpso_last_error(g_ctx) : "no device context");
+  ndtpso_ctx* c = active_ctx()->c;
+  record_error(what, rc, c ? ndtpso_last_error(c) : "no device context");
   return false;
 }
 
@@ -207,7 +279,18 @@ extern "C" {
 // of THEIR choice, so a mismatch is an undefined reference at link time
 int NDTPSO_ABI_TAG = 1;
 
-void ndtpso_slam_device_init(void) { (void)ndtpso_host::device(); }
+void ndtpso_slam_device_init(void) {
+  ndtpso_ctx* c = ndtpso_host::device();
+  // ... and, where the exact mode will be used, its once-per-process self check (ndtpso_exact_check, ~30 ms) now rather
+  // than inside the first align()
+  if (c && ndtpso_host::score_mode() == NDTPSO_SCORE_EXACT) (void)ndtpso_exact_check(c, nullptr, nullptr, nullptr, nullptr);
+}
+void ndtpso_slam_thread_srand(unsigned seed) { ndtpso_host::t_rand.seed(seed); }
+int ndtpso_slam_thread_rand(void) {
+  int32_t v;
+  ndtpso_host::draw_rand(&v, 1);
+  return (int)v;
+}
 
 // ndtpso_slam/status.h
 const char* ndtpso_slam_last_error(void) {

@@ -85,6 +85,7 @@ bool NDTCell::build() {
     xy[2 * i + 1] = pts[i].y();
   }
   const uint32_t off[2] = {0u, (uint32_t)pts.size()};
+  ndtpso_host::Use use(nullptr);  // (a cell on its own: the calling thread's context, unless a frame's is in use already)
   if (!ndtpso_host::check(ndtpso_cells_build_windowed(ndtpso_host::device(), 1, &cw, off, xy.data()), "NDTCell::build"))
     return built;  // device fault: the cell keeps its previous statistics
   w.global_sum = Vector2d(cw.global_sum[0], cw.global_sum[1]);
@@ -124,6 +125,7 @@ double NDTCell::normalDistribution(const Vector2d& point) {
     grid.width = grid.height = side;
     grid.cell_side = (double)side;
   }
+  ndtpso_host::Use use(nullptr);
   ndtpso_host::table_owner() = nullptr;
   if (!ndtpso_host::check(ndtpso_ref_set_cells(ndtpso_host::device(), &grid, 1, &index, m, win_->inv_covar), "normalDistribution"))
     return 0.;

@@ -67,7 +67,14 @@ NDTFrame::NDTFrame(Vector3d trans, unsigned short width_, unsigned short height_
 #endif
 }
 
+ndtpso_host::Ctx* NDTFrame::dev() const {
+  if (!s_dev) s_dev = ndtpso_host::thread_ctx();
+  return s_dev;
+}
+
 NDTFrame::~NDTFrame() {
+  if (!d_scan_ && !d_map_) return;
+  ndtpso_host::Use use(dev());
   if (d_scan_) ndtpso_host::release_scan(d_scan_, d_scan_cap_);
   if (d_map_ && ndtpso_host::alive()) ndtpso_map_destroy(d_map_);
 }
@@ -114,6 +121,7 @@ void NDTFrame::residentPoints(bool slot0_only, std::vector<double>& xy) const {
 }
 
 void NDTFrame::syncHostView() {
+  ndtpso_host::Use use(dev());
   if (!s_resident) return;
   if (!d_map_) {
     if (d_scan_) {  // a one-cell frame holding loaded scans: its only cell exists as soon as one point survived
@@ -151,6 +159,7 @@ void NDTFrame::append(const double* xy, const int32_t* idx, uint32_t n) {
 // reference: loadLaser, ndtframe.cpp:144-185 (beam filter, fp32 angle, fp64 polar->xy, s_trans, binning)
 void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle, const float& angle_increment,
                          const float& max_range) {
+  ndtpso_host::Use use(dev());
   built = false;
   const uint32_t n = (uint32_t)laser_data.size();
   if (n == 0) {
@@ -196,6 +205,7 @@ void NDTFrame::loadLaser(const vector<float>& laser_data, const float& min_angle
 }
 
 void NDTFrame::collectPoints(std::vector<double>& xy) const {
+  ndtpso_host::Use use(dev());
   xy.clear();
   if (s_resident) {
     residentPoints(true, xy);
@@ -219,16 +229,31 @@ void NDTFrame::collectPoints(std::vector<double>& xy) const {
 
 // reference: update, ndtframe.cpp:187-198 (transform every slot-0 point of new_frame by `trans`, re-bin here)
 void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
+  // The node merges every scan at the pose align() has just returned (ndtpso_slam_node.cpp:194-198) and never asks whether
+  // that alignment ran: the reference's cannot fail.  Here it can (a device fault: align() then returns its initial guess,
+  // lastAlignOk() says so), and a scan merged at an unrefined guess would corrupt the map for good.  So an update() that
+  // follows a failed align() against this frame is REFUSED -- the scan is dropped, counted (updatesRefused()) and recorded
+  // in the error state (ndtpso_slam/status.h) -- and the next successful align() clears the condition.
+  if (!s_last_align_ok) {
+    ++s_updates_refused;
+    ndtpso_host::check(NDTPSO_E_STATE, "update after a failed align (scan not merged)");
+    return;
+  }
+  // a frame that lives in another thread's device context: its points travel through the host (collected under ITS context)
+  std::vector<double> foreign;
+  const bool is_foreign = new_frame->dev() != dev();
+  if (is_foreign) new_frame->collectPoints(foreign);
+  ndtpso_host::Use use(dev());
   built = false;
   if (s_resident) {
     const double pose[3] = {trans.x(), trans.y(), trans.z()};
     ndtpso_map* m = ensureMap();
     if (!ndtpso_host::check(ndtpso_map_mark_unbuilt(m), "update")) return;  // ndtframe.cpp:188, also when no point follows
-    if (new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {  // device to device, nothing to wait for
+    if (!is_foreign && new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {  // device to device, nothing to wait for
       if (!ndtpso_host::check(ndtpso_map_insert(m, new_frame->d_scan_, pose), "update")) return;
     } else {
       std::vector<double> pts;
-      new_frame->collectPoints(pts);
+      if (is_foreign) pts.swap(foreign); else new_frame->collectPoints(pts);
       if (!ndtpso_host::check(ndtpso_map_insert_host(m, pts.data(), (uint32_t)(pts.size() / 2), pose), "update")) return;
     }
     // A frame that is aligned against gets its cells built and its table packed right away, off the next align()'s
@@ -242,7 +267,7 @@ void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
     return;
   }
   std::vector<double> xy;
-  new_frame->collectPoints(xy);
+  if (is_foreign) xy.swap(foreign); else new_frame->collectPoints(xy);
   const uint32_t n = (uint32_t)(xy.size() / 2);
   if (n == 0) return;
   std::vector<int32_t> idx(n);
@@ -256,7 +281,9 @@ void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
 // north star's addScan(): loadLaser() into a one-cell per-scan frame + update() with it (see ndtframe.h)
 void NDTFrame::addScan(const Vector3d& pose, const vector<float>& laser_data, const float& min_angle,
                        const float& angle_increment, const float& max_range) {
+  ndtpso_host::Use use(dev());  // (the scratch frame below binds to the active context: this frame's)
   NDTFrame scan(Vector3d::Zero(), width, height, (double)std::max(width, height), false, s_config);  // ndtpso_slam_node.cpp:229-230
+  scan.s_dev = dev();
   scan.loadLaser(laser_data, min_angle, angle_increment, max_range);
   update(pose, &scan);
 }
@@ -271,6 +298,7 @@ int NDTFrame::getCellIndex(Vector2d point, int grid_width, double cell_side_) {
 
 // reference: addPoint, ndtframe.cpp:215-235
 void NDTFrame::addPoint(Vector2d& point) {
+  ndtpso_host::Use use(dev());
   if (s_resident) {
     if (getCellIndex(point, widthNumOfCells, cell_side) == -1) return;  // outside the frame: dropped, `built` untouched
     const double p[2] = {point.x(), point.y()};
@@ -284,6 +312,7 @@ void NDTFrame::addPoint(Vector2d& point) {
 
 // reference: build, ndtframe.cpp:68-117 -- NDTCell::build for every created cell, batched into one device call
 void NDTFrame::build() {
+  ndtpso_host::Use use(dev());
   if (s_resident) {
     if (ndtpso_host::check(ndtpso_map_build(ensureMap()), "build")) built = true;
     return;
@@ -404,6 +433,7 @@ void NDTFrame::fetchOccupancy() const {
 }
 
 const vector<int8_t>& NDTFrame::occupancyGrid(uint32_t* og_width, uint32_t* og_height, uint32_t extent[4]) const {
+  ndtpso_host::Use use(dev());
   fetchOccupancy();
   if (og_width) *og_width = s_occupancy_grid.width;
   if (og_height) *og_height = s_occupancy_grid.height;
@@ -443,16 +473,20 @@ bool NDTFrame::uploadTable() {
 // quantity the reference consumes it (3 + 3P + 6PI), so srand() by the caller has the reference's meaning.
 Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, const Vector3d& deviation,
                             const PSOConfig& cfg) {
+  std::vector<double> foreign;  // (a frame of another thread's context: its points through the host, see update())
+  const bool is_foreign = new_frame->dev() != dev();
+  if (is_foreign) new_frame->collectPoints(foreign);
+  ndtpso_host::Use use(dev());
   if (s_resident) {
     ndtpso_map* m = ensureMap();  // ndtpso_map_align builds first if need be (cost_function's lazy build, core.cpp:27-28)
     const ndtpso_points* pts = nullptr;
     ndtpso_points* tmp = nullptr;
     uint32_t tmp_cap = 0;
-    if (new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {
+    if (!is_foreign && new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {
       pts = new_frame->d_scan_;
     } else {
       std::vector<double> xy;
-      new_frame->collectPoints(xy);
+      if (is_foreign) xy.swap(foreign); else new_frame->collectPoints(xy);
       tmp_cap = std::max(kScanCapacity, (uint32_t)(xy.size() / 2));
       tmp = ndtpso_host::acquire_scan(tmp_cap);
       ndtpso_host::check(ndtpso_points_set(tmp, xy.data(), (uint32_t)(xy.size() / 2)), "align");
@@ -474,7 +508,7 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
   if (!built) build();  // core.cpp:27-28 (lazy build inside cost_function)
   const bool table_ok = uploadTable();
   std::vector<double> xy;
-  new_frame->collectPoints(xy);
+  if (is_foreign) xy.swap(foreign); else new_frame->collectPoints(xy);
   const ndtpso_pso_config abi = to_abi(cfg);
   std::vector<int32_t> draws(ndtpso_rand_draws(&abi));
   ndtpso_host::draw_rand(draws.data(), draws.size());
@@ -488,6 +522,10 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
 }
 
 double NDTFrame::cost(const Vector3d& trans, const NDTFrame* new_frame) {
+  std::vector<double> foreign;
+  const bool is_foreign = new_frame->dev() != dev();
+  if (is_foreign) new_frame->collectPoints(foreign);
+  ndtpso_host::Use use(dev());
   const double pose[3] = {trans.x(), trans.y(), trans.z()};
   double c = 0.;
   if (s_resident) {
@@ -495,11 +533,11 @@ double NDTFrame::cost(const Vector3d& trans, const NDTFrame* new_frame) {
     ndtpso_points* tmp = nullptr;
     uint32_t tmp_cap = 0;
     ndtpso_points* pts = nullptr;
-    if (new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {
+    if (!is_foreign && new_frame->s_resident && new_frame->d_scan_ && !new_frame->d_map_) {
       pts = new_frame->d_scan_;
     } else {
       std::vector<double> xy;
-      new_frame->collectPoints(xy);
+      if (is_foreign) xy.swap(foreign); else new_frame->collectPoints(xy);
       tmp_cap = std::max(kScanCapacity, (uint32_t)(xy.size() / 2));
       tmp = ndtpso_host::acquire_scan(tmp_cap);
       ndtpso_host::check(ndtpso_points_set(tmp, xy.data(), (uint32_t)(xy.size() / 2)), "cost_function");
@@ -515,7 +553,7 @@ double NDTFrame::cost(const Vector3d& trans, const NDTFrame* new_frame) {
   if (!built) build();
   if (!uploadTable()) return 0.;
   std::vector<double> xy;
-  new_frame->collectPoints(xy);
+  if (is_foreign) xy.swap(foreign); else new_frame->collectPoints(xy);
   if (!ndtpso_host::check(ndtpso_cost_batch(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), pose, 1,
                                             NDTPSO_SCORE_F64, &c, nullptr), "cost_function"))
     return 0.;
@@ -550,6 +588,7 @@ void NDTFrame::addPose(double timestamp, const Vector3d& pose, const Vector3d& o
 }
 
 void NDTFrame::resetCells() {
+  ndtpso_host::Use use(dev());
   for (NDTCell& c : cells) c.reset();
   if (d_map_) ndtpso_host::check(ndtpso_map_reset(d_map_), "resetCells");
   if (d_scan_) {
@@ -561,6 +600,7 @@ void NDTFrame::resetCells() {
 
 // reference: transform, ndtframe.cpp:119-140 (never called by the node; re-bins every stored point)
 void NDTFrame::transform(Vector3d trans) {
+  ndtpso_host::Use use(dev());
   if (trans.isZero(1e-6)) return;
   if (s_resident) {
     std::vector<double> pts;
@@ -610,6 +650,7 @@ void NDTFrame::dumpMap(const char* filename, bool save_poses, bool save_points, 
 ) {
   using ndtpso_host::Raster;
   using ndtpso_host::Rgb;
+  ndtpso_host::Use use(dev());
   FILE *poses = nullptr, *points = nullptr;
   char name[1280];
   if (save_poses) {

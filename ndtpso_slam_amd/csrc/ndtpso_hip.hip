@@ -3,6 +3,7 @@
 #include "ndtpso_kernels.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -946,6 +947,7 @@ struct ndtpso_ctx {
   // single alignments (align_once) are numbered; the kernel writes its number behind its result in the pinned slot
   unsigned long long align_issued = 0, align_seen = 0;
   uint32_t cluster_nonce = 0;
+  int xcd_pref = 0;                   // the XCD this context's lone clusters sit on: contexts take the eight in turn
   bool inputs_pinned = false;         // `inputs` is a pinned host slot (the kernel fetches the table from there itself)
   const void* inputs = nullptr;       // [guess | deviation | pad to kGuessBytes | rand() table] of the alignment about to be launched:
                                       // `table` (uploaded) or a pinned slot the kernel reads in place (ndtpso_map_align)
@@ -1228,6 +1230,10 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
     return NDTPSO_E_HIP;
   }
   c->stream = c->own_stream;
+  {
+    static std::atomic<unsigned> n_contexts{0};
+    c->xcd_pref = (int)(n_contexts.fetch_add(1) & 7u);
+  }
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->n_cus = cus;
@@ -1891,7 +1897,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), 1, -1, nullptr};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd() ? 1 + c->xcd_pref : 0, 1, -1, nullptr};
   int lds_total = L.total;
   // (one XCD holds an eighth of the compute units; a cluster it cannot hold -- a forced K, a partitioned part -- is spread as
   // the dispatcher spreads it instead of spinning to the exchange's timeout, as launch_pairs does)

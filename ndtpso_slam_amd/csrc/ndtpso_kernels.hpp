@@ -2785,7 +2785,7 @@ struct ClusterP {
   // by the XCD's own L2 instead of the fabric.  So cluster c of a launch is the workgroups whose index is c mod 8 modulo 8
   // -- rank r of cluster c is workgroup ((c / 8) K + r) 8 + c mod 8 -- and a lone cluster launches 8 K workgroups of which
   // seven in eight leave on their first instruction.  Placement only: the exchange is correct wherever the workgroups land.
-  int one_xcd;          // 1: that mapping; 0: K consecutive workgroups per cluster (NDTPSO_CLUSTER_SPREAD=1, for comparison)
+  int one_xcd;          // 1 + p: that mapping, cluster 0 on XCD p; 0: K consecutive workgroups per cluster (NDTPSO_CLUSTER_SPREAD=1, for comparison)
   int n;                // clusters in this launch
   int spec_off;         // LDS byte offset of the speculation scratch (16 (P + 1) doubles, SpecP), -1: none
   double* spec;         // ... as a pointer (set by the kernel)
@@ -2813,7 +2813,9 @@ __device__ __forceinline__ double* spec_cs(double* buf, int S, int c, int which)
 // (cluster, rank) of this workgroup; false: it has no part in the launch
 __device__ __forceinline__ bool cluster_place(const ClusterP& cl, size_t* c, int* rank) {
   if (cl.one_xcd) {
-    const unsigned x = blockIdx.x & 7u, q = blockIdx.x >> 3;
+    // (one_xcd - 1: the XCD the launch's first cluster takes -- a lone cluster of context i sits on XCD i mod 8, so that
+    // replicas of the live sequence in one process do not all queue for XCD 0's thirty-two compute units)
+    const unsigned x = (blockIdx.x - (unsigned)(cl.one_xcd - 1)) & 7u, q = blockIdx.x >> 3;
     *rank = (int)(q % (unsigned)cl.K);
     *c = (size_t)(q / (unsigned)cl.K) * 8u + x;
   } else {

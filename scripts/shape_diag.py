@@ -1,4 +1,4 @@
-"""Why a shape of scripts/shape_sweep.py is slow: the first launch's flags (NDTPSO_NO_REDO=1 keeps the gated redo launches out)
+"""Why a shape of tests/campaigns/shape_sweep.py is slow: the first launch's flags (NDTPSO_NO_REDO=1 keeps the gated redo launches out)
 and the time with and without them.   python scripts/shape_diag.py beams cell frame [mode]"""
 import json, os, subprocess, sys
 import numpy as np

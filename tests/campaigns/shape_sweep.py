@@ -1,6 +1,6 @@
 """Throughput of the fused pairs kernel OFF the benchmark's shapes (512 pairs, 70 x 70 PSO, every score mode asked for).
 
-    python scripts/shape_sweep.py [--out profiles/r05_shape_sweep.json] [--modes exact,f64] [--quick]
+    python tests/campaigns/shape_sweep.py [--out profiles/r05_shape_sweep.json] [--modes exact,f64] [--quick]
 
 For beams in {361, 541, 721, 1080, 1081, 1441, 2048} x cell side in {0.25, 0.3, 0.5, 1.0} m x frame in {60, 100, 300} m
 (100 m: the node's default, include/ndtpso_slam_node.hpp:26; 300 m: launch/scan.launch:14): alignments per second (HIP
@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 BEAMS = [361, 541, 721, 1080, 1081, 1441, 2048]
