@@ -181,7 +181,10 @@ static void cell_add_point(orc_cell *c, v2 p) {
  *   EigenSolver::compute: T10 == 0 -> eigenvalue i = T_ii (real); otherwise the pair (T11 + p, +-z) with
  *                         z = maxval * sqrt|p0 p0 + t0 t1|
  *   pseudoEigenvalueMatrix: real eigenvalues land on the diagonal; a complex pair puts its real part on both.
- * `variant`: 0 = as above (3.3.7; also what 3.4.0 does for a 2x2); 1 = the same without the scale / unscale steps of
+ * `variant`: 0 = as above, with considerAsZero = DBL_MIN; 3 = the same with considerAsZero = max(norm eps^2, DBL_MIN), which
+ * is how this builder and the round-4 review remember later 3.3.x / 3.4.0 (neither can be checked offline: Eigen is not in
+ * the image) -- the two give identical results on every positive semi-definite input (see findSmallSubdiagEntry below), so
+ * which of them the deployed Eigen runs does not matter here; 1 = the same without the scale / unscale steps of
  * RealSchur::compute and without the DBL_MIN floor in findSmallSubdiagEntry (RealSchur.h before those were added --
  * which 3.3.x release first carried them cannot be established offline, 3.3.4 is the other version the reference's
  * README leads to); 2 = the closed form mid +- sqrt(hp^2 + c01 c10) that rounds 1 and 2 of this repository used.
@@ -237,7 +240,7 @@ void orc_eigen_eigenvalues_2x2(const double m[4], int variant, double ev[2]) {
     ev[1] = mid - q;
     return;
   }
-  if (variant == 0) { /* RealSchur::compute: scale = matrix.cwiseAbs().maxCoeff() */
+  if (variant == 0 || variant == 3) { /* RealSchur::compute: scale = matrix.cwiseAbs().maxCoeff() */
     scale = fabs(m[0]);
     for (k = 1; k < 4; ++k)
       if (fabs(m[k]) > scale) scale = fabs(m[k]);
@@ -258,9 +261,19 @@ void orc_eigen_eigenvalues_2x2(const double m[4], int variant, double ev[2]) {
       /* findSmallSubdiagEntry(iu = 1) */
       double s = fabs(T[0]) + fabs(T[3]);
       int small;
-      if (variant == 0) {
+      if (variant == 0 || variant == 3) {
+        /* considerAsZero: DBL_MIN (variant 0), or max(norm * eps^2, DBL_MIN) as later 3.3.x / 3.4.0 compute it (variant 3).
+         * For the matrices this function ever sees the two cannot differ: a covariance is positive semi-definite, so its
+         * largest |coefficient| lies on the diagonal, scaling makes that 1, hence s >= 1 and s * eps >= 2.2e-16, while
+         * norm <= 4 puts norm * eps^2 below 2e-31 -- the floor is never the larger operand (tests/test_oracle.py checks
+         * variant 3 == variant 0 bit for bit over the same 1e6 covariances). */
+        double floor_ = 2.2250738585072014e-308;
+        if (variant == 3) {
+          const double ne2 = norm * (2.220446049250313e-16 * 2.220446049250313e-16);
+          if (ne2 > floor_) floor_ = ne2;
+        }
         s = s * 2.220446049250313e-16;
-        if (!(s > 2.2250738585072014e-308)) s = 2.2250738585072014e-308; /* numext::maxi(s * eps, considerAsZero) */
+        if (!(s > floor_)) s = floor_; /* numext::maxi(s * eps, considerAsZero) */
         small = fabs(T[2]) <= s;
       } else {
         small = fabs(T[2]) <= 2.220446049250313e-16 * s;
@@ -287,7 +300,7 @@ void orc_eigen_eigenvalues_2x2(const double m[4], int variant, double ev[2]) {
       }
     }
   }
-  if (variant == 0)
+  if (variant == 0 || variant == 3)
     for (k = 0; k < 4; ++k) T[k] *= scale; /* m_matT *= scale */
   /* EigenSolver::compute + pseudoEigenvalueMatrix().diagonal() */
   if (T[2] == 0.) {

@@ -407,6 +407,11 @@ def test_eigen_variants_ulp_distribution(oracle, capsys):
                      % (name, 100 * deg.mean(), 100 * (ul > 0).mean(), ul.max(), np.percentile(ul, 99), ud.max(), ui.max(), dt.max()))
         assert ul.max() <= 16 and ud.max() <= 40 and ui.max() <= 48
         assert dt.max() < 5e-12             # per-point Gaussian term (q = d^T inv d reaches hundreds in a thin cell)
+    # variant 3 (considerAsZero floored at norm * eps^2 instead of DBL_MIN, as later Eigen releases have it): the floor is
+    # never the larger operand for a positive semi-definite input, so nothing moves -- which of the two the deployed Eigen
+    # runs cannot matter here
+    o3 = oracle.covar_inverse_batch(M, 3)
+    assert np.array_equal(o3, o[0], equal_nan=True)
     with capsys.disabled():
         print()
         for ln in lines:
