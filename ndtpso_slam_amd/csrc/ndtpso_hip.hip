@@ -1788,9 +1788,9 @@ static int cluster_slots(ndtpso_ctx* c, size_t xc_bytes, uint4** xc) {
   return NDTPSO_OK;
 }
 
-// tags of a launch's exchange slots carry this number (ClusterP::nonce): 1 .. 65535, then around
+// tags of a launch's exchange slots carry this number (ClusterP::nonce, all 32 bits of it: xslot_tag_a / _b)
 static uint32_t next_cluster_nonce(ndtpso_ctx* c) {
-  c->cluster_nonce = c->cluster_nonce % 65535u + 1u;
+  if (++c->cluster_nonce == 0u) c->cluster_nonce = 1u;
   return c->cluster_nonce;
 }
 

@@ -2778,7 +2778,7 @@ struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, slots per exchange buffer
   int absent;           // test hook: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout
   uint4* xc;            // [2][stride] exchange slots {cost lo, tag, cost hi, tag}
-  uint32_t nonce;       // upper half of the tags of this launch (the slots keep whatever earlier launches left there)
+  uint32_t nonce;       // of this launch, in the tags of its slots (which keep whatever earlier launches left there)
   // A cluster on ONE XCD.  Workgroups go to the eight XCDs in turn (workgroup i to XCD i mod 8: HW_REG_XCC_ID read back by
   // scripts/ubench_xcd_exchange.hip), and the same 16-byte `sc1` store and loads cost 0.50 us per exchange between eight
   // workgroups of one XCD against 0.93 us between eight consecutive ones (1.27 -> 0.76 us for sixteen): the slots are served
@@ -2833,12 +2833,18 @@ __host__ inline unsigned cluster_grid(const ClusterP& cl) {
 // so a value is never paired with a stale or half-written neighbour.  No fence on either side: nothing but the slot itself
 // is communicated.
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void xslot_store(uint4* slot, double cost, uint32_t tag) {
+// The tag is 64 bits in two words that BOTH depend on the launch's 32-bit nonce and the round's 32-bit number (round 5; it
+// was a 16-bit nonce and a 16-bit round number, the same word twice: at 2 800 scans a second the nonce came round every
+// 24 s, and a slot a launch with a wider layout had left behind could in principle be taken for a current one).  Each half
+// of the slot carries one of them next to its half of the cost, so a slot torn between two stores would still not pass.
+__device__ __forceinline__ uint32_t xslot_tag_a(uint32_t nonce, uint32_t round) { return nonce ^ (round * 0x9E3779B9u); }
+__device__ __forceinline__ uint32_t xslot_tag_b(uint32_t nonce, uint32_t round) { return nonce + round * 0x85EBCA6Bu + 0x27D4EB2Fu; }
+__device__ __forceinline__ void xslot_store(uint4* slot, double cost, uint32_t tag_a, uint32_t tag_b) {
   u32x4 v;
   v.x = (uint32_t)__double2loint(cost);
-  v.y = tag;
+  v.y = tag_a;
   v.z = (uint32_t)__double2hiint(cost);
-  v.w = tag;
+  v.w = tag_b;
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(slot), "v"(v) : "memory");
 }
 __device__ __forceinline__ u32x4 xslot_load(const uint4* slot) {
@@ -2864,7 +2870,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
     uint4* buf = cl.xc + (size_t)(epoch & 1u) * cl.stride;
-    const uint32_t tag = (cl.nonce << 16) | ((epoch + 1u) & 0xffffu);
+    const uint32_t tag_a = xslot_tag_a(cl.nonce, epoch + 1u), tag_b = xslot_tag_b(cl.nonce, epoch + 1u);
     for (int j = first + cl.rank * n_waves + wave_id(); j < last; j += total_waves) {
       const double c = sw.it[4 * j], s = sw.it[4 * j + 1];
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
@@ -2873,7 +2879,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
         cost = eval_pose_wave_dense<false, true, PATH == 3>(E.g, E.dn, E.lds0, pts, n, c, s, tx, ty, nullptr);
       else
         cost = eval_pose_wave<MODE, (PATH & 3) == 1>(E.g, E.wn, E.T, pts, n, c, s, tx, ty);
-      if (lane_id() == 0) xslot_store(&buf[j], cost, tag);
+      if (lane_id() == 0) xslot_store(&buf[j], cost, tag_a, tag_b);
     }
     NDTPSO_PHASE_MARK(1);
     // behind the exchange (wave 0 polls, everybody else would idle): one wave of every workgroup draws the next
@@ -2915,7 +2921,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
           bool ok = true;
           if (mine) {
             const u32x4 v = xslot_load(&buf[j]);
-            ok = v.y == tag && v.w == tag;
+            ok = v.y == tag_a && v.w == tag_b;
             cost = __hiloint2double((int)v.z, (int)v.x);
           }
 #ifdef NDTPSO_PHASE_BUDGET

@@ -1,0 +1,51 @@
+"""Exchange slots of a cluster of workgroups (ndtpso_kernels.hpp: xslot_store / eval_round) under back-to-back launches
+whose layouts alternate -- two swarm sizes, hence two slot strides over the same buffer -- and that last a few exchanges each:
+every launch must return what its layout's first launch returned (a stale slot accepted would change a cost), and no cluster
+may run into the exchange's bounded wait (it would be logged).  The tags are 64 bits (launch nonce x round, both 32 bits in
+both words); before round 5 they were 16 + 16 bits and this loop passed the nonce's wrap 1.5 times per 100 000 launches.
+The suite runs 30 000 launches; NDTPSO_TAG_STRESS=200000 makes it the campaign of tests/campaigns/README.md."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from ndtpso_slam_amd import capi, synth
+N = %d
+p = synth.make_pairs(1, n_beams=181, seed=5)
+geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+ctx = capi.Context(0)
+xy = ctx.scan_to_points(p.new_ranges[0], geom)
+ctx.ref_from_scan(capi.Grid(60, 60, 0.5), p.ref_ranges[0], geom)
+cfgs = [capi.PSOConfig.make(1, 24), capi.PSOConfig.make(1, 57)]      # one iteration each; slot strides 32 and 64
+refs, bad = {}, 0
+for k in range(N):
+    i = k & 1
+    pose, cost, st = ctx.align(xy, (0, 0, 0), (0.1, 0.1, 3.1415e-3), cfgs[i], seed=7, mode=capi.SCORE_EXACT if (k >> 1) & 1 else capi.SCORE_F32)
+    key = (i, (k >> 1) & 1)
+    val = (pose.tobytes(), float(cost), int(st["status"]))
+    if key not in refs:
+        refs[key] = val
+    elif refs[key] != val:
+        bad += 1
+print(json.dumps(dict(launches=N, differing=bad, rounds=int(st["rounds"]))))
+"""
+
+
+def test_back_to_back_cluster_launches_with_alternating_layouts():
+    n = int(os.environ.get("NDTPSO_TAG_STRESS", "30000"))
+    env = {k: v for k, v in os.environ.items() if k not in ("NDTPSO_LIB", "NDTPSO_CLUSTER", "NDTPSO_CLUSTER_WAVES")}
+    r = subprocess.run([sys.executable, "-c", CHILD % (ROOT, n)], capture_output=True, text=True, timeout=3000, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["launches"] == n and d["differing"] == 0, d
+    assert d["rounds"] >= 2, d                                     # the swarm's initialisation + one iteration: a few exchanges each
+    assert "did not meet within" not in r.stderr, r.stderr[-600:]  # no cluster ran into the bounded wait
