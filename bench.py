@@ -225,7 +225,7 @@ def main():
                                if world > 1 else "single GPU",
                 "batches_in_flight": depth,
             },
-            "roofline": _roofline(stats, evals_nominal, kern_ms, algo_bytes, achieved, 1e3 * elapsed / max(args.steps, 1), depth),
+            "roofline": _roofline(stats, evals_nominal, kern_ms, algo_bytes, achieved, 1e3 * elapsed / max(args.steps, 1), depth, args.score),
             "extra": {
                 "mean_cost_evals_per_alignment": float(stats["cost_evals"].mean()),
                 "mean_replay_overhead": float(stats["cost_evals"].mean()) / evals_nominal - 1.0,
@@ -468,7 +468,7 @@ VEC_FP64_TFLOPS = 78.6
 FLOP_FP64, FLOP_FP32, FLOP_EXP = 16.0, 34.0, 1.0
 
 
-def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms, depth):
+def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms, depth, score="exact"):
     """The kernel keeps table, points and swarm in LDS: HBM sees 8.7 KB per alignment and no matrix instruction applies
     (DESIGN 5), so the roof is the VECTOR ALU of the chip.  Work of a launch = the reference's 1 + P + P*I cost
     evaluations per alignment x the points each scores (replays of the exact-order scheme not counted) x the flops of
@@ -478,7 +478,12 @@ def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms,
     v_exp_f32 is charged as ONE fp32 flop although it issues at a quarter of the fp32 rate (frac_exp_at_quarter_rate
     charges it 4).  `floor` keeps round 2's instruction-level figure: the issue time of the score loop's actual
     instruction mix (scripts/isa_mix.py x scripts/ubench_valu.hip) -- useful for tuning, not a roofline."""
-    mix_name = "r04_isa_mix.json" if _load_json("r04_isa_mix.json") else "r02_isa_mix.json"
+    # (--score f64: the same 51 flops per point evaluation, ALL of them fp64 -- the kernel executes exactly that many: 8
+    # transform, 4 index, 2 differences, 9 quadratic form, 27 in the exponential's reduction and polynomial, 1 accumulate)
+    f64 = score == "f64"
+    FLOP_FP64, FLOP_FP32, FLOP_EXP = (51.0, 0.0, 0.0) if f64 else (16.0, 34.0, 1.0)
+    cands = ("r05_isa_mix_f64.json", "r04_isa_mix_f64.json") if f64 else ("r05_isa_mix.json", "r04_isa_mix.json", "r02_isa_mix.json")
+    mix_name = next((n for n in cands if _load_json(n)), cands[-1])
     mix = _load_json(mix_name)
     point_evals = float(stats["n_points"].astype(np.float64).sum()) * evals_nominal
     flops = point_evals * (FLOP_FP64 + FLOP_FP32 + FLOP_EXP)
@@ -493,7 +498,7 @@ def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms,
     r = {"bound": "valu", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
          "regime": "%d batch(es) in flight: flops of one step / ms_per_step (%.3f ms), the regime of `value`" % (depth, step_ms),
          "achieved_per_launch": achieved_launch, "frac_per_launch": achieved_launch / peak,
-         "traffic": _pmc_traffic_bytes(), "kernel": "k_align_pairs (fused scan ingest + cell statistics + PSO)",
+         "traffic": _pmc_traffic_bytes(f64), "kernel": "k_align_pairs (fused scan ingest + cell statistics + PSO)",
          "kernel_ms": kern_ms, "algorithmic_point_evals_per_launch": point_evals,
          "flops_per_point_eval": {"fp64": FLOP_FP64, "fp32": FLOP_FP32, "exp": FLOP_EXP},
          "vector_peaks_tflops": {"fp32": VEC_FP32_TFLOPS, "fp64": VEC_FP64_TFLOPS},
@@ -522,11 +527,13 @@ def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms,
     return r
 
 
-def _pmc_traffic_bytes():
+def _pmc_traffic_bytes(f64=False):
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 per the
     gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE; separate --pmc runs, scripts/pmc.sh).  A profile of
     THIS workload measured on MI355X, not collected live (rocprofv3 cannot wrap the timed run); null if absent."""
-    for name in ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
+    names = ("r05_pmc_summary_f64.json",) if f64 else ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json",
+                                                       "r02_pmc_summary.json", "r01_pmc_summary.json")
+    for name in names:
         d = _load_json(name)
         try:
             d = d["derived"]

@@ -958,7 +958,8 @@ struct ndtpso_ctx {
   uint32_t* pairs_fb = nullptr;
   uint32_t fb_seen = 0, fb_last_pairs = 0;
   uint64_t fb_key = 0;
-  bool fb_big_first = false;
+  bool fb_big_first = false, fb_overflowed = true;
+  int fb_overflowed_calls = 0;
   void* result_pinned = nullptr;      // pinned landing slot of one alignment's pose / cost / statistics (align_once)
   hipEvent_t result_event = nullptr;
 };
@@ -2293,9 +2294,16 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
     mix(geom->n_beams), mix((uint64_t)(geom->max_range * 1024.f)), mix(grid->width), mix(grid->height), mix((uint64_t)(grid->cell_side * 65536.));
     mix((uint64_t)cfg->population), mix((uint64_t)mode), mix(exact ? 1 : 0);
     const uint32_t now = __atomic_load_n(c->pairs_fb, __ATOMIC_RELAXED);
+    // (the gated largest-table launch below is issued only where tables have overflowed lately -- or nothing is known yet:
+    // a batch of 512 workgroups that all leave at once still costs the device 4 us, and the benchmark's shape never needs it.
+    // An overflow that comes as a surprise is still served, by the slower launches further down, and switches it on.)
+    c->fb_overflowed = key != c->fb_key || now != c->fb_seen || c->fb_overflowed_calls > 0;
+    if (key == c->fb_key && now != c->fb_seen) c->fb_overflowed_calls = 16;  // keep it on for the next calls
+    else if (c->fb_overflowed_calls > 0) --c->fb_overflowed_calls;
     if (key != c->fb_key) {
       c->fb_key = key;
       c->fb_big_first = false;
+      c->fb_overflowed_calls = 1;
     } else if (!c->fb_big_first && c->fb_last_pairs && (uint64_t)(now - c->fb_seen) * 4u > c->fb_last_pairs) {
       c->fb_big_first = true;
       static const bool log_plan = std::getenv("NDTPSO_LOG_PLAN") != nullptr;  // diagnostics
@@ -2316,7 +2324,7 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
   // dense forms size their cell table so that two workgroups share a compute unit; an alignment whose box -- scan A's
   // occupied cells -- outgrew that table gets the same kernel again with the largest table a workgroup can hold (0.25 m cells,
   // a room seen at an angle: 7 of 512 pairs; 1441 beams at 0.3 m: 370 of 512), before anything slower is considered
-  if (shrunk && (path == 2 || path >= 8) && !small_batch) {
+  if (shrunk && c->fb_overflowed && (path == 2 || path >= 8) && !small_batch) {
     rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
                       st, kStatusNeedsBitmap, true, nullptr, false, exact, true);
     if (rc != NDTPSO_OK && rc != NDTPSO_E_CAPACITY) return rc;

@@ -1063,18 +1063,14 @@ __device__ __forceinline__ double eval_pose_wave_d64(const GridP& g, const Dense
     const double hwi = uniform_f64(g.hw * g.inv_cs), hhi = uniform_f64(g.hh * g.inv_cs);  // wave-uniform: scalar registers
     const unsigned tab_a = d64_tab - 2u * ((unsigned)dn.oy * stride + (unsigned)dn.ox);
     // (entry 0 of the table -- the low border's corner -- is a null entry: the padding's lanes read it)
-    for (; base + U * kWave <= n_pad; base += U * kWave) {
-      if (base + U * kWave <= n)
-        score_trip_d64<POW2, U, false>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
-      else
-        score_trip_d64<POW2, U, true>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
-    }
-    for (; base < n_pad; base += kWave) {
-      if (base + kWave <= n)
-        score_trip_d64<POW2, 1, false>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
-      else
-        score_trip_d64<POW2, 1, true>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
-    }
+    for (; base + U * kWave <= n; base += U * kWave)  // (the steady state: whole groups of four chunks, no padding)
+      score_trip_d64<POW2, U, false>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
+    for (; base + U * kWave <= n_pad; base += U * kWave)  // (at most one: a group whose last chunk holds the padding)
+      score_trip_d64<POW2, U, true>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
+    for (; base + kWave <= n; base += kWave)
+      score_trip_d64<POW2, 1, false>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
+    for (; base < n_pad; base += kWave)
+      score_trip_d64<POW2, 1, true>(g, stride, tab_a, d64_tab, pts, base, n, c, s, tx, ty, hwi, hhi, acc);
   } else {
     for (; base + U * kWave <= n_pad; base += U * kWave)
       score_trip_d64_tested<POW2, U>(g, dn, stride, d64_tab, pts, base, c, s, tx, ty, acc);
@@ -2695,7 +2691,12 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
       bool ordinary = true;
       if (MODE == kScoreF32 && !(cost <= -kTinyCost)) {  // NaN, or the underflow regime (exact mode: NaN only, see eval_items)
         if (cost != cost || (!ARB && pbc_j > -kTinyCost)) {
-          __hip_atomic_fetch_min((lds_int_t)tiny, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (tiny: PsoShared::tiny_j here)
+          // (tiny: PsoShared::tiny_j here.  Exact mode: only a NaN gets here, and whether the fp64 kernel takes the alignment
+          // over or this one carries on changes nothing in what is returned -- the item's index need not be kept)
+          if constexpr (ARB)
+            *(lds_int_t)tiny = 0;
+          else
+            __hip_atomic_fetch_min((lds_int_t)tiny, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           ordinary = false;
         }
       }

@@ -45,7 +45,7 @@ def timed_launches(score, launches=12, config="config3"):
     p = synth.make_pairs(B, n_beams=cf["beams"], seed=cf["seed"])
     geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
     grid, cfg = capi.Grid(60, 60, cf["cs"]), capi.PSOConfig.make(I, P)
-    mode = {"exact": capi.SCORE_EXACT, "f32": capi.SCORE_F32}[score]
+    mode = {"exact": capi.SCORE_EXACT, "f32": capi.SCORE_F32, "f64": capi.SCORE_F64}[score]
     ctx = capi.Context(0)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
@@ -89,7 +89,7 @@ def timed_launches(score, launches=12, config="config3"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
-    ap.add_argument("--score", default="exact", choices=["exact", "f32"])
+    ap.add_argument("--score", default="exact", choices=["exact", "f32", "f64"])
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_phase_budget.json"))
     ap.add_argument("--config", default="config3", choices=list(CONFIGS))
     ap.add_argument("--plain", action="store_true", help="(internal) time the shipped library and print the mean launch time")
@@ -139,7 +139,8 @@ def main():
                                                     "wait at the round's barrier": float(rows[:, :, 14].mean())},
         "per_alignment": {"cost_evals_mean": float(st["cost_evals"].mean()), "rounds_mean": float(st["rounds"].mean()),
                           "arbitrated_mean": float(st["arbitrated"].mean())},
-        "slowest_workgroups": {"corr(duration, arbitrated)": float(np.corrcoef(wg_total[-1], st["arbitrated"].astype(float))[0, 1]),
+        "slowest_workgroups": {"corr(duration, arbitrated)": (float(np.corrcoef(wg_total[-1], st["arbitrated"].astype(float))[0, 1])
+                                                              if st["arbitrated"].any() else None),
                                "corr(duration, cost_evals)": float(np.corrcoef(wg_total[-1], st["cost_evals"].astype(float))[0, 1])},
     }
     os.makedirs(os.path.dirname(args.out), exist_ok=True)

@@ -10,7 +10,13 @@ import os
 # dense form with byte-address entries (what config 3 runs): the arbitrating kernel of the exact mode, the plain fp32-score
 # kernel, or the general dense form -- whichever the profiled run launched
 names = {r["Kernel_Name"] for r in csv.DictReader(open(f"{src}/p1/p_counter_collection.csv"))}
-KERNEL = next((k for k in ("k_align_pairs<0, 3, false, true, true", "k_align_pairs<0, 3, false, false, true",
+# (the launch that did the work: a run's gated redo launches are other instances of k_align_pairs whose workgroups exit at once)
+_valu = collections.defaultdict(list)
+for r in csv.DictReader(open(f"{src}/p1/p_counter_collection.csv")):
+    if "k_align_pairs<" in r["Kernel_Name"] and r["Counter_Name"] == "SQ_INSTS_VALU":
+        _valu[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(float(r["Counter_Value"]))
+_busiest = max(_valu, key=lambda k: max(_valu[k])) if _valu else None
+KERNEL = _busiest if _busiest else next((k for k in ("k_align_pairs<1, 9, false", "k_align_pairs<1, 8, false", "k_align_pairs<0, 3, false, true, true", "k_align_pairs<0, 3, false, false, true",
                            "k_align_pairs<0, 3, false, true, false", "k_align_pairs<0, 3, false, false, false",
                            "k_align_pairs<0, 3, false, true", "k_align_pairs<0, 3, false, false", "k_align_pairs<0, 3, false",
                            "k_align_pairs<0, 2, false") if any(k in n for n in names)), "k_align_pairs")
@@ -25,7 +31,8 @@ def describe(name):
     a += ["false"] * (5 - len(a)) + (["2"] if len(a) < 6 else [])
     mode = "fp32 Gaussian score" if a[0] == "0" else "fp64 score"
     form = {"0": "bitmap table, true division", "1": "bitmap table, power-of-two cells", "2": "dense u16 table (entries in 16-byte units)",
-            "3": "dense u16 table (entries are byte addresses)"}.get(a[1], a[1])
+            "3": "dense u16 table (entries are byte addresses)", "8": "dense u16 table, fp64 records, true division",
+            "9": "dense u16 table, fp64 records, power-of-two cells"}.get(a[1], a[1])
     arb = "EXACT mode: near-tie comparisons arbitrated with the fp64 score" if a[3] == "true" else "plain (no arbitration)"
     swarm = {"0": "swarm in LDS", "1": "swarm in its HBM workspace", "2": "both swarm homes compiled in"}.get(a[5], a[5])
     return "%s, %s, %s, %s, %s%s" % (mode, form, arb, "cluster of workgroups per pair" if a[2] == "true" else "one workgroup per pair",
@@ -57,18 +64,35 @@ def code_object_resources(name):
     except Exception as e:  # noqa: BLE001
         return {"error": str(e)}
     return {"error": "kernel not found in the code object"}
-vals = collections.defaultdict(list)
-disp = {}
+# A gated redo launch can be the SAME kernel with another workgroup size (the fp64 dense form's largest-table launch: 1024
+# threads against 512; every workgroup exits at once): the working launches are the ones of the smaller workgroup size.
+rows_by_wg = collections.defaultdict(list)
 for p in ("p1", "p2", "p3", "p4", "p5"):
     for r in csv.DictReader(open(f"{src}/{p}/p_counter_collection.csv")):
-        if KERNEL not in r["Kernel_Name"]:
-            continue
-        vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        disp = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size")}
+        # (Grid_Size = threads: the bench's launches are `pairs` workgroups -- the exact mode's start-up check runs the same
+        # kernel on 520 small pairs once per process and must not be averaged in)
+        if KERNEL in r["Kernel_Name"] and int(float(r["Grid_Size"])) == pairs * int(float(r["Workgroup_Size"])):
+            rows_by_wg[int(float(r["Workgroup_Size"]))].append(r)
+def _wg_valu(w):
+    v = [float(r["Counter_Value"]) for r in rows_by_wg[w] if r["Counter_Name"] == "SQ_INSTS_VALU"]
+    return max(v) if v else 0.
+WG = max(rows_by_wg, key=_wg_valu) if rows_by_wg else 0
+vals = collections.defaultdict(list)
+disp = {}
+for r in rows_by_wg.get(WG, []):
+    vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    disp = {k: r[k] for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Workgroup_Size", "Grid_Size")}
 mean = {k: sum(v) / len(v) for k, v in vals.items()}
-stats = [r for r in csv.DictReader(open(f"{src}/trace/t_kernel_stats.csv")) if KERNEL in r["Name"]]
-kern_ns = float(stats[0]["AverageNs"]) if stats else float("nan")
-kern_calls = int(float(stats[0]["Calls"])) if stats else 0
+trace_path = f"{src}/trace/t_kernel_trace.csv"
+if os.path.exists(trace_path):   # per dispatch: the working launches only, warm ones (the second half)
+    d = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(trace_path))
+         if KERNEL in r["Kernel_Name"] and int(float(r["Workgroup_Size_X"])) == WG and int(float(r["Grid_Size_X"])) == pairs * WG]
+    d = d[len(d) // 2:] if len(d) >= 4 else d
+    kern_ns, kern_calls = (sum(d) / len(d) if d else float("nan")), len(d)
+else:
+    stats = [r for r in csv.DictReader(open(f"{src}/trace/t_kernel_stats.csv")) if KERNEL in r["Name"]]
+    kern_ns = float(stats[0]["AverageNs"]) if stats else float("nan")
+    kern_calls = int(float(stats[0]["Calls"])) if stats else 0
 evals = 1 + P + P * I
 # cost evaluations include the replays of the exact-order scheme (measured mean of the bench workload: +2.3 %)
 chunks = pairs * evals * 1.0228 * math.ceil(beams / 64)

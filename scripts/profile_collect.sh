@@ -8,6 +8,7 @@ for sc in f64 f32; do [ -f $SRC/bench_$sc.json ] && cp $SRC/bench_$sc.json ${P}_
 cp $SRC/ubench_valu.txt ${P}_ubench_valu.txt
 cp $SRC/isa_mix.json ${P}_isa_mix.json
 cp $SRC/score_loop_isa.txt ${P}_score_loop_isa.txt
+[ -f $SRC/isa_mix_f64.json ] && cp $SRC/isa_mix_f64.json ${P}_isa_mix_f64.json && cp $SRC/score_loop_isa_f64.txt ${P}_score_loop_isa_f64.txt
 cp $SRC/trace1/t_kernel_stats.csv ${P}_kernel_stats.csv                 # one batch at a time
 cp $SRC/trace2/t_kernel_stats.csv ${P}_kernel_stats_two_in_flight.csv
 for k in 1 2 3 4 5; do
@@ -16,6 +17,17 @@ for k in 1 2 3 4 5; do
   grep "k_align_pairs" $SRC/pmc/p$k/p_counter_collection.csv >> ${P}_pmc/p${k}_k_align_pairs.csv
 done
 cp $SRC/pmc_summary.json ${P}_pmc_summary.json
+if [ -f $SRC/pmc_summary_f64.json ]; then
+  cp $SRC/pmc_summary_f64.json ${P}_pmc_summary_f64.json
+  mkdir -p ${P}_pmc_f64
+  for k in 1 2 3 4 5; do
+    head -1 $SRC/pmc_f64/p$k/p_counter_collection.csv > ${P}_pmc_f64/p${k}_k_align_pairs.csv
+    grep "k_align_pairs" $SRC/pmc_f64/p$k/p_counter_collection.csv >> ${P}_pmc_f64/p${k}_k_align_pairs.csv
+  done
+  grep -h "Name\|k_align_pairs" $SRC/pmc_f64/trace/t_kernel_stats.csv > ${P}_kernel_stats_f64.csv
+fi
+[ -f $SRC/phase_budget_f64.json ] && cp $SRC/phase_budget_f64.json ${P}_phase_budget_f64.json
+[ -f $SRC/shard_timing_g1.json ] && cp $SRC/shard_timing_g1.json ${P}_shard_timing_g1.json
 cp $SRC/phase_budget.json ${P}_phase_budget.json
 cp $SRC/phase_budget_f32.json ${P}_phase_budget_f32.json
 cp $SRC/phase_budget_config5.json ${P}_phase_budget_config5.json

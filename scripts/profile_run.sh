@@ -9,7 +9,9 @@ mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/ubench_valu.hip -o /tmp/ubench_valu 2>/dev/null && /tmp/ubench_valu > $OUT/ubench_valu.txt 2>&1
 python scripts/isa_mix.py --kernel "k_align_pairs<0, 3, false, true, true, 0>" --ubench $OUT/ubench_valu.txt --out $OUT/isa_mix.json --dump $OUT/score_loop_isa.txt > /dev/null
-cp $OUT/isa_mix.json profiles/r04_isa_mix.json   # the bench line's roofline.floor reads it
+python scripts/isa_mix.py --kernel "k_align_pairs<1, 9, false, false, false, 2>" --marker v_rndne_f64 --marker-span 90 --ubench $OUT/ubench_valu.txt --out $OUT/isa_mix_f64.json --dump $OUT/score_loop_isa_f64.txt > /dev/null
+cp $OUT/isa_mix.json profiles/r05_isa_mix.json   # the bench line's roofline.floor reads them
+cp $OUT/isa_mix_f64.json profiles/r05_isa_mix_f64.json
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python bench.py --pipeline 1 --no-latency --cpu-sample 0 > $OUT/bench_one_at_a_time.json 2>> $OUT/bench.err
 # the other two score modes of the same workload (fp64 score throughout; plain fp32 score), two batches in flight and one at a time
@@ -19,6 +21,10 @@ for sc in f64 f32; do timeout 300 python bench.py --score $sc --no-latency --cpu
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -o t -- python $GRAFT_REPO_ROOT/bench.py --pipeline 2 --steps 40 --warmup 20 --cpu-sample 0 --no-latency > $OUT/trace2.log 2>&1)
 bash scripts/pmc.sh $D/pmc --pipeline 1 > $OUT/pmc.log 2>&1
 python scripts/pmc_summary.py $OUT/pmc $OUT/pmc_summary.json > $OUT/pmc_summary.log 2>&1
+bash scripts/pmc.sh $D/pmc_f64 --pipeline 1 --score f64 > $OUT/pmc_f64.log 2>&1
+python scripts/pmc_summary.py $OUT/pmc_f64 $OUT/pmc_summary_f64.json > $OUT/pmc_summary_f64.log 2>&1
+timeout 300 python scripts/phase_budget.py --config config3 --score f64 --out $OUT/phase_budget_f64.json > $OUT/budget_f64.log 2>&1
+timeout 300 python scripts/shard_timing.py --out $OUT/shard_timing_g1.json > $OUT/shard_timing.log 2>&1
 timeout 300 python scripts/phase_budget.py --config config3 --score exact --out $OUT/phase_budget.json > $OUT/budget.log 2>&1
 timeout 300 python scripts/phase_budget.py --config config3 --score f32 --out $OUT/phase_budget_f32.json >> $OUT/budget.log 2>&1
 timeout 400 python scripts/phase_budget.py --config config5 --score exact --out $OUT/phase_budget_config5.json >> $OUT/budget.log 2>&1
