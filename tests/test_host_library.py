@@ -70,6 +70,9 @@ def test_node_call_sequence_links_and_survives_a_missing_device(tmp_path):
     assert last[0] == "pose" and [float(v) for v in last[1:4]] == [0.0, 0.0, 0.0] and int(last[5]) > 0
     assert "align failed" in r.stderr and "the call is skipped" in r.stderr
     assert r.stderr.count("align failed") == 1                          # logged once per call site
+    # the node update()s the map at whatever pose align() returned (ndtpso_slam_node.cpp:194-198): after a failed align that
+    # is the unrefined guess, and the merge is refused rather than allowed to corrupt the map
+    assert "update after a failed align (scan not merged)" in r.stderr
     assert os.path.exists(str(tmp_path / "node_api.pose.csv"))         # the shutdown export still ran
     # NDTPSO_ABORT_ON_ERROR=1: the old behaviour for tests and debugging
     r = subprocess.run([exe, str(tmp_path)], text=True, capture_output=True,
