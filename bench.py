@@ -106,6 +106,8 @@ def main():
     ctx = capi.Context(local_rank)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
+    # the exact mode's once-per-process self check (ndtpso_exact_check, ~30 ms) now, whatever --warmup is: never inside the timed region
+    exact_check = ctx.exact_check() if mode == capi.SCORE_EXACT else None
 
     d_ref = torch.from_numpy(pairs.ref_ranges).to(dev)
     d_new = torch.from_numpy(pairs.new_ranges).to(dev)
@@ -236,6 +238,7 @@ def main():
                 "n_built_min_max": [int(stats["n_built"].min()), int(stats["n_built"].max())],
                 "n_points_min_max": [int(stats["n_points"].min()), int(stats["n_points"].max())],
                 "comparisons_arbitrated_in_f64_per_alignment": float(stats["arbitrated"].mean()),
+                "exact_mode_start_up_check": exact_check,   # state 1: passed (ndtpso_exact_check; before the warm-up)
                 "timed_region_s": elapsed,
                 "batches_in_flight": {
                     "depth": depth,
