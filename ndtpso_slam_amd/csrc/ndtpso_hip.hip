@@ -576,7 +576,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   size_t b = blockIdx.x;
   if constexpr (CLUSTER) {
     if (!cluster_place(cl, &b, &cl.rank)) return;
-    cl.xc += b * 2 * (size_t)cl.stride;
+    cl.xc += b * (2 * (size_t)cl.stride + (size_t)round_up(cl.K, 8));  // two slot buffers + the workgroups' heartbeats
     cl.spec = cl.spec_off >= 0 ? reinterpret_cast<double*>(g_lds + cl.spec_off) : nullptr;
   }
   const bool writer = !CLUSTER || cl.rank == 0;
@@ -1809,7 +1809,7 @@ static void cluster_spec_room(int P, int* lds_total, ClusterP* cl) {
   const int at = round_up(*lds_total, 16), bytes = 16 * (P + 1) * 8 + (ddraws ? 12 * P * 8 : 0);
   if (P > kWave || at + bytes > kMaxLds) return;
   cl->spec_off = at;
-  cl->ddraws = ddraws ? 1 : 0;
+  cl->ddraws |= ddraws ? 1 : 0;
   *lds_total = at + bytes;
 }
 // NDTPSO_CLUSTER_SPREAD=1: a cluster's workgroups where the dispatcher puts consecutive ones (all eight XCDs) instead of on
@@ -1820,7 +1820,16 @@ static int cluster_one_xcd() {
 }
 // NDTPSO_CLUSTER_TEST_ABSENT=r (tests only): rank r of every cluster leaves immediately, so the others run into the
 // bounded wait and the one-workgroup rerun is exercised
+static int cluster_flags() {  // ClusterP::ddraws, bit 1
+  static const int f = [] {
+    const char* e = std::getenv("NDTPSO_CLUSTER_HEARTBEAT");  // =0: no flow control between the exchange's rounds (as before round 5)
+    return (e && e[0] == '0') ? 2 : 0;
+  }();
+  return f;
+}
 static int cluster_test_absent() {
+  // NDTPSO_CLUSTER_TEST_LAG=r (tests only): rank r dawdles 60 us in every round in which it has no item (ClusterP::absent = -(2 + r))
+  if (const char* l = std::getenv("NDTPSO_CLUSTER_TEST_LAG")) return -(2 + std::max(0, std::atoi(l)));
   const char* e = std::getenv("NDTPSO_CLUSTER_TEST_ABSENT");
   return e ? std::atoi(e) : -1;
 }
@@ -1904,7 +1913,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (L.swarm_global) HIP_TRY(c, c->ws.reserve((size_t)swarm_bytes(cfg->population, true, true) * (size_t)K));
   const int waves = K > 1 ? cw : pick_waves(cfg->population, L.total, 1);
   PsoP ps = make_pso(cfg, waves, mode, L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd() ? 1 + c->xcd_pref : 0, 1, -1, nullptr};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd() ? 1 + c->xcd_pref : 0, 1, -1, nullptr, cluster_flags()};
   int lds_total = L.total;
   // (one XCD holds an eighth of the compute units; a cluster it cannot hold -- a forced K, a partitioned part -- is spread as
   // the dispatcher spreads it instead of spinning to the exchange's timeout, as launch_pairs does)
@@ -1913,7 +1922,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     cluster_spec_room(cfg->population, &lds_total, &cl);
     ps.G = std::min(std::max(cfg->population, 1), K * waves);  // one item per wave and round
     cl.stride = round_up(cfg->population + 1, 8);
-    if (int rc = cluster_slots(c, (size_t)2 * cl.stride * sizeof(uint4), &cl.xc)) return rc;
+    if (int rc = cluster_slots(c, ((size_t)2 * cl.stride + (size_t)round_up(K, 8)) * sizeof(uint4), &cl.xc)) return rc;
     cl.nonce = next_cluster_nonce(c);
   }
 #define LAUNCH_ALIGN_CA(MODE, PATH, CL, ARB)                                                                       \
@@ -2136,7 +2145,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (int rc = make_scan(c, geom, &sp, &dirs)) return rc;
   if (K > 1) waves = cw;
   PsoP ps = make_pso(cfg, waves, mode, plan.L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), (int)n_pairs, -1, nullptr};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), (int)n_pairs, -1, nullptr, cluster_flags()};
   int lds_total = plan.L.total;
   if (K > 1) cluster_spec_room(cfg->population, &lds_total, &cl);
   // (one XCD per cluster only while an XCD's share of the clusters finds a compute unit per workgroup there; a batch that
@@ -2145,7 +2154,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);
     cl.stride = round_up(cfg->population + 1, 8);
-    if (int rc = cluster_slots(c, (size_t)n_pairs * 2 * cl.stride * sizeof(uint4), &cl.xc)) return rc;
+    if (int rc = cluster_slots(c, (size_t)n_pairs * (2 * cl.stride + round_up(K, 8)) * sizeof(uint4), &cl.xc)) return rc;
     cl.nonce = next_cluster_nonce(c);
   }
   const size_t stride = ndtpso_rand_draws(cfg);

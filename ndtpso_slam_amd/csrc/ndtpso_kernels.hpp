@@ -2777,7 +2777,8 @@ __device__ unsigned g_polls;  // a cluster's first workgroup: sweeps of the exch
 
 struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, slots per exchange buffer
-  int absent;           // test hook: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout
+  int absent;           // test hooks: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout; -(2 + r): rank r
+                        // dawdles in the rounds in which it has no item (eval_round's flow control)
   uint4* xc;            // [2][stride] exchange slots {cost lo, tag, cost hi, tag}
   uint32_t nonce;       // of this launch, in the tags of its slots (which keep whatever earlier launches left there)
   // A cluster on ONE XCD.  Workgroups go to the eight XCDs in turn (workgroup i to XCD i mod 8: HW_REG_XCC_ID read back by
@@ -2790,7 +2791,8 @@ struct ClusterP {
   int n;                // clusters in this launch
   int spec_off;         // LDS byte offset of the speculation scratch (16 (P + 1) doubles, SpecP), -1: none
   double* spec;         // ... as a pointer (set by the kernel)
-  int ddraws;           // 1: 12 P more doubles behind it -- the two draw buffers' |uniform_pm1| (pso_run_wg); NDTPSO_CLUSTER_DDRAWS=0: none
+  int ddraws;           // bit 0: 12 P more doubles behind it -- the two draw buffers' |uniform_pm1| (pso_run_wg); NDTPSO_CLUSTER_DDRAWS=0: none
+                        // bit 1: the exchange does not wait for heartbeats (NDTPSO_CLUSTER_HEARTBEAT=0: tests, comparison)
 };
 
 // ---- a cluster's next proposals, made while its costs travel ---------------------------------------------------------
@@ -2873,7 +2875,13 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
     uint4* buf = cl.xc + (size_t)(epoch & 1u) * cl.stride;
+    uint4* hb = cl.xc + 2 * (size_t)cl.stride;  // heartbeats, one slot per workgroup of the cluster (below)
     const uint32_t tag_a = xslot_tag_a(cl.nonce, epoch + 1u), tag_b = xslot_tag_b(cl.nonce, epoch + 1u);
+    if (cl.absent <= -2 && cl.rank == -(cl.absent + 2) && first + cl.rank * n_waves >= last) {
+      // test hook (NDTPSO_CLUSTER_TEST_LAG=r): the workgroup of rank r dawdles 60 us in every round in which it has no item
+      const unsigned long long t_lag = wall_clock64();
+      while (wall_clock64() - t_lag < 6000ull) __builtin_amdgcn_s_sleep(8);
+    }
     for (int j = first + cl.rank * n_waves + wave_id(); j < last; j += total_waves) {
       const double c = sw.it[4 * j], s = sw.it[4 * j + 1];
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
@@ -2914,11 +2922,19 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     // among them), a lane per item, and does the round's detection on what it read.  One trip of the cost to memory and
     // one back: the first scheme -- costs, a fence, an arrival counter, a poll, a fence, the costs read back -- was four,
     // with the L2 written back and invalidated twice per round (3.4 us a round of the live sequence's 60).
+    // Flow control (round 5).  The two slot buffers alternate, so round r + 1 overwrites what round r - 1 left; a workgroup
+    // with items in round r has read round r - 1 by then, but one WITHOUT items in rounds r and r + 1 (two partial rounds in a
+    // row: the tails behind two gbest moves) is waited for by nobody and could still be reading -- it would find its slots
+    // retagged and sit out the bounded wait.  So every workgroup also keeps a heartbeat slot {rounds it has read, launch
+    // nonce}, written behind its read of a round, and the read of round r waits, in the SAME sweep as the costs (the lanes
+    // behind the items: no extra trip), until every workgroup's heartbeat says r: everybody has read round r - 1 before
+    // anybody stores round r + 1.
     if (wave_id() == 0) {
       const unsigned long long t0 = wall_clock64();
-      for (int j0 = first; j0 < last; j0 += kWave) {
-        const int j = j0 + lane_id();
-        const bool mine = j < last;
+      const int n_it = last - first, n_hb = (epoch > 0u && !(cl.ddraws & 2)) ? cl.K : 0;
+      for (int v0 = 0; v0 < n_it + n_hb; v0 += kWave) {
+        const int vi = v0 + lane_id(), j = first + vi;
+        const bool mine = vi < n_it, mine_hb = !mine && vi < n_it + n_hb;
         double cost = 0.;
         for (;;) {
           bool ok = true;
@@ -2926,6 +2942,9 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
             const u32x4 v = xslot_load(&buf[j]);
             ok = v.y == tag_a && v.w == tag_b;
             cost = __hiloint2double((int)v.z, (int)v.x);
+          } else if (mine_hb) {
+            const u32x4 v = xslot_load(&hb[vi - n_it]);
+            ok = v.y == cl.nonce && v.w == (cl.nonce ^ 0x5bd1e995u) && v.z == ~v.x && v.x >= epoch;
           }
 #ifdef NDTPSO_PHASE_BUDGET
           if (cl.rank == 0 && lane_id() == 0) atomicAdd(&g_polls, 1u);
@@ -2949,6 +2968,14 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
             }
           }
         }
+      }
+      if (lane_id() == 0) {  // this workgroup has read round `epoch`: epoch + 1 rounds in all
+        u32x4 v;
+        v.x = epoch + 1u;
+        v.y = cl.nonce;
+        v.z = ~(epoch + 1u);
+        v.w = cl.nonce ^ 0x5bd1e995u;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(&hb[cl.rank]), "v"(v) : "memory");
       }
     }
     NDTPSO_PHASE_MARK(2);
@@ -3153,7 +3180,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // the proposal chain uses them: |uniform_pm1(draw)| -- a conversion, two multiplications and two FMAs per draw, made by the
   // thread that fetches the draw instead of in front of every proposal, where one or two waves work and the cluster waits
   // (round 5; the same function of the same integer: bit-identical)
-  [[maybe_unused]] double* const dd0 = (CLUSTER && prefetch && cl.spec && cl.ddraws) ? cl.spec + 16 * S : nullptr;
+  [[maybe_unused]] double* const dd0 = (CLUSTER && prefetch && cl.spec && (cl.ddraws & 1)) ? cl.spec + 16 * S : nullptr;
   [[maybe_unused]] double* const dd1 = dd0 ? dd0 + 6 * P : nullptr;
   int32_t pre0 = 0, pre1 = 0;
   if (prefetch) {

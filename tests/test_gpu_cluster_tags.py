@@ -49,3 +49,46 @@ def test_back_to_back_cluster_launches_with_alternating_layouts():
     assert d["launches"] == n and d["differing"] == 0, d
     assert d["rounds"] >= 2, d                                     # the swarm's initialisation + one iteration: a few exchanges each
     assert "did not meet within" not in r.stderr, r.stderr[-600:]  # no cluster ran into the bounded wait
+
+
+LAG_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from ndtpso_slam_amd import capi, synth
+p = synth.make_pairs(4, seed=11)
+geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+ctx = capi.Context(0)
+out = []
+for b in range(4):
+    xy = ctx.scan_to_points(p.new_ranges[b], geom)
+    ctx.ref_from_scan(capi.Grid(60, 60, 0.5), p.ref_ranges[b], geom)
+    pose, cost, st = ctx.align(xy, (0, 0, 0), (0.1, 0.1, 3.1415e-3), capi.PSOConfig.make(50, 30), seed=int(p.seeds[b]), mode=capi.SCORE_EXACT)
+    out.append([pose.tolist(), float(cost), int(st["gbest_updates"])])
+print(json.dumps(out))
+"""
+
+
+def _lag_run(**env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("NDTPSO_LIB", "NDTPSO_CLUSTER", "NDTPSO_CLUSTER_WAVES")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", LAG_CHILD % ROOT], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads(r.stdout.strip().splitlines()[-1]), r.stderr
+
+
+def test_a_workgroup_that_lags_through_partial_rounds_is_waited_for():
+    """Flow control of the exchange (eval_round): the two slot buffers alternate, and a workgroup without items in two
+    consecutive partial rounds -- the re-proposed tails behind gbest moves -- used to be waited for by nobody; if it lagged it
+    found its slots retagged and sat out the 20 ms bounded wait (then the one-workgroup rerun: correct, a latency spike).  With
+    the heartbeats every round waits until everybody has read the round before the last.  The test hook makes the last
+    workgroup dawdle 60 us -- a dozen rounds -- whenever it has no item: with the heartbeats nothing is noticed, without them
+    (NDTPSO_CLUSTER_HEARTBEAT=0, the pre-round-5 behaviour) the cluster runs into the wait; the results are the same all three ways."""
+    want, err0 = _lag_run()
+    assert "did not meet within" not in err0
+    got, err1 = _lag_run(NDTPSO_CLUSTER_TEST_LAG="7")
+    assert got == want
+    assert "did not meet within" not in err1, err1[-400:]
+    old, err2 = _lag_run(NDTPSO_CLUSTER_TEST_LAG="7", NDTPSO_CLUSTER_HEARTBEAT="0")
+    assert old == want                                   # the rerun on one workgroup is correct
+    assert "did not meet within" in err2                 # ... but that is what it took
