@@ -1809,7 +1809,7 @@ static void cluster_spec_room(int P, int* lds_total, ClusterP* cl) {
   const int at = round_up(*lds_total, 16), bytes = 16 * (P + 1) * 8 + (ddraws ? 12 * P * 8 : 0);
   if (P > kWave || at + bytes > kMaxLds) return;
   cl->spec_off = at;
-  cl->ddraws |= ddraws ? 1 : 0;
+  cl->flags |= ddraws ? kClusterDDraws : 0;
   *lds_total = at + bytes;
 }
 // NDTPSO_CLUSTER_SPREAD=1: a cluster's workgroups where the dispatcher puts consecutive ones (all eight XCDs) instead of on
@@ -1820,10 +1820,10 @@ static int cluster_one_xcd() {
 }
 // NDTPSO_CLUSTER_TEST_ABSENT=r (tests only): rank r of every cluster leaves immediately, so the others run into the
 // bounded wait and the one-workgroup rerun is exercised
-static int cluster_flags() {  // ClusterP::ddraws, bit 1
+static int cluster_flags() {  // ClusterP::flags from the environment
   static const int f = [] {
     const char* e = std::getenv("NDTPSO_CLUSTER_HEARTBEAT");  // =0: no flow control between the exchange's rounds (as before round 5)
-    return (e && e[0] == '0') ? 2 : 0;
+    return (e && e[0] == '0') ? kClusterNoHeartbeat : 0;
   }();
   return f;
 }

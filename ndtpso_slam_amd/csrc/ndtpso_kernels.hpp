@@ -2775,6 +2775,7 @@ __device__ unsigned g_polls;  // a cluster's first workgroup: sweeps of the exch
 #define NDTPSO_PB(k) do { } while (0)
 #endif
 
+constexpr int kClusterDDraws = 1, kClusterNoHeartbeat = 2;  // ClusterP::flags
 struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, slots per exchange buffer
   int absent;           // test hooks: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout; -(2 + r): rank r
@@ -2791,8 +2792,9 @@ struct ClusterP {
   int n;                // clusters in this launch
   int spec_off;         // LDS byte offset of the speculation scratch (16 (P + 1) doubles, SpecP), -1: none
   double* spec;         // ... as a pointer (set by the kernel)
-  int ddraws;           // bit 0: 12 P more doubles behind it -- the two draw buffers' |uniform_pm1| (pso_run_wg); NDTPSO_CLUSTER_DDRAWS=0: none
-                        // bit 1: the exchange does not wait for heartbeats (NDTPSO_CLUSTER_HEARTBEAT=0: tests, comparison)
+  int flags;            // kClusterDDraws: 12 P more doubles behind the scratch -- the two draw buffers' |uniform_pm1| (pso_run_wg;
+                        // NDTPSO_CLUSTER_DDRAWS=0: none); kClusterNoHeartbeat: the exchange does not wait for heartbeats
+                        // (NDTPSO_CLUSTER_HEARTBEAT=0: tests, comparison)
 };
 
 // ---- a cluster's next proposals, made while its costs travel ---------------------------------------------------------
@@ -2931,7 +2933,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     // anybody stores round r + 1.
     if (wave_id() == 0) {
       const unsigned long long t0 = wall_clock64();
-      const int n_it = last - first, n_hb = (epoch > 0u && !(cl.ddraws & 2)) ? cl.K : 0;
+      const int n_it = last - first, n_hb = (epoch > 0u && !(cl.flags & kClusterNoHeartbeat)) ? cl.K : 0;
       for (int v0 = 0; v0 < n_it + n_hb; v0 += kWave) {
         const int vi = v0 + lane_id(), j = first + vi;
         const bool mine = vi < n_it, mine_hb = !mine && vi < n_it + n_hb;
@@ -3180,7 +3182,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // the proposal chain uses them: |uniform_pm1(draw)| -- a conversion, two multiplications and two FMAs per draw, made by the
   // thread that fetches the draw instead of in front of every proposal, where one or two waves work and the cluster waits
   // (round 5; the same function of the same integer: bit-identical)
-  [[maybe_unused]] double* const dd0 = (CLUSTER && prefetch && cl.spec && (cl.ddraws & 1)) ? cl.spec + 16 * S : nullptr;
+  [[maybe_unused]] double* const dd0 = (CLUSTER && prefetch && cl.spec && (cl.flags & kClusterDDraws)) ? cl.spec + 16 * S : nullptr;
   [[maybe_unused]] double* const dd1 = dd0 ? dd0 + 6 * P : nullptr;
   int32_t pre0 = 0, pre1 = 0;
   if (prefetch) {
