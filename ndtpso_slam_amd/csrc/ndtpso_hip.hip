@@ -1801,15 +1801,9 @@ static uint32_t next_cluster_nonce(ndtpso_ctx* c) {
 static void cluster_spec_room(int P, int* lds_total, ClusterP* cl) {
   const char* e = std::getenv("NDTPSO_CLUSTER_SPEC");
   if (e && e[0] == '0') return;
-  // (16 (P + 1) doubles of ready-made proposals + 2 x 6 P doubles: the two draw buffers' |uniform_pm1|, pso_run_wg)
-  static const bool ddraws = [] {
-    const char* d = std::getenv("NDTPSO_CLUSTER_DDRAWS");  // =0: the proposal chain converts its draws itself (same results)
-    return !(d && d[0] == '0');
-  }();
-  const int at = round_up(*lds_total, 16), bytes = 16 * (P + 1) * 8 + (ddraws ? 12 * P * 8 : 0);
+  const int at = round_up(*lds_total, 16), bytes = 16 * (P + 1) * 8;
   if (P > kWave || at + bytes > kMaxLds) return;
   cl->spec_off = at;
-  cl->flags |= ddraws ? kClusterDDraws : 0;
   *lds_total = at + bytes;
 }
 // NDTPSO_CLUSTER_SPREAD=1: a cluster's workgroups where the dispatcher puts consecutive ones (all eight XCDs) instead of on

@@ -2775,7 +2775,7 @@ __device__ unsigned g_polls;  // a cluster's first workgroup: sweeps of the exch
 #define NDTPSO_PB(k) do { } while (0)
 #endif
 
-constexpr int kClusterDDraws = 1, kClusterNoHeartbeat = 2;  // ClusterP::flags
+constexpr int kClusterNoHeartbeat = 2;  // ClusterP::flags
 struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, slots per exchange buffer
   int absent;           // test hooks: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout; -(2 + r): rank r
@@ -2792,9 +2792,7 @@ struct ClusterP {
   int n;                // clusters in this launch
   int spec_off;         // LDS byte offset of the speculation scratch (16 (P + 1) doubles, SpecP), -1: none
   double* spec;         // ... as a pointer (set by the kernel)
-  int flags;            // kClusterDDraws: 12 P more doubles behind the scratch -- the two draw buffers' |uniform_pm1| (pso_run_wg;
-                        // NDTPSO_CLUSTER_DDRAWS=0: none); kClusterNoHeartbeat: the exchange does not wait for heartbeats
-                        // (NDTPSO_CLUSTER_HEARTBEAT=0: tests, comparison)
+  int flags;            // kClusterNoHeartbeat: the exchange does not wait for heartbeats (NDTPSO_CLUSTER_HEARTBEAT=0: tests, comparison)
 };
 
 // ---- a cluster's next proposals, made while its costs travel ---------------------------------------------------------
@@ -2812,7 +2810,6 @@ struct SpecP {
   const int32_t* draws;    // the next iteration's draws (6 per particle), readable now; nullptr: no speculation this round
   double w, c1, c2;        // the next iteration's inertia weight, c1, c2
   const double* gb;        // gbest position
-  const double* ddraws;    // the same draws as |uniform_pm1(.)|, made when they were fetched (nullptr: made here)
 };
 __device__ __forceinline__ double* spec_vel(double* buf, int S, int c, int k) { return buf + (c * 3 + k) * S; }
 __device__ __forceinline__ double* spec_pos(double* buf, int S, int c, int k) { return buf + (6 + c * 3 + k) * S; }
@@ -2904,8 +2901,8 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
       for (int t = (int)threadIdx.x - kWave; t < 6 * P; t += nt) {
         const int c = t & 1, jk = t >> 1;  // headings first, as in the proposal step
         const int j = jk < P ? jk : (jk - P) >> 1, k = jk < P ? 2 : ((jk - P) & 1);
-        const double r1 = sp->ddraws ? sp->ddraws[6 * j + 2 * k] : fabs(uniform_pm1(sp->draws[6 * j + 2 * k]));
-        const double r2 = sp->ddraws ? sp->ddraws[6 * j + 2 * k + 1] : fabs(uniform_pm1(sp->draws[6 * j + 2 * k + 1]));
+        const double r1 = fabs(uniform_pm1(sp->draws[6 * j + 2 * k]));
+        const double r2 = fabs(uniform_pm1(sp->draws[6 * j + 2 * k + 1]));
         const double p = sw.tpos[k * S + j];  // the position the commit will make current
         const double pbk = c == 0 ? p : sw.pb[k * S + j];  // pbest: the same position (new pbest) or the old one
         const double v = sp->w * sw.tvel[k * S + j] + sp->c1 * r1 * (pbk - p) + sp->c2 * r2 * (sp->gb[k] - p);
@@ -2929,11 +2926,14 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
     // row: the tails behind two gbest moves) is waited for by nobody and could still be reading -- it would find its slots
     // retagged and sit out the bounded wait.  So every workgroup also keeps a heartbeat slot {rounds it has read, launch
     // nonce}, written behind its read of a round, and the read of round r waits, in the SAME sweep as the costs (the lanes
-    // behind the items: no extra trip), until every workgroup's heartbeat says r: everybody has read round r - 1 before
-    // anybody stores round r + 1.
+    // behind the items: no extra trip), until the heartbeat of every workgroup that has no item in round r says r: everybody
+    // has read round r - 1 before anybody stores round r + 1.
     if (wave_id() == 0) {
       const unsigned long long t0 = wall_clock64();
-      const int n_it = last - first, n_hb = (epoch > 0u && !(cl.flags & kClusterNoHeartbeat)) ? cl.K : 0;
+      // (a workgroup WITH items in this round has read the round before: its slots of this round say so.  Only the ranks
+      // without items -- none in a full round, five rounds in six of the live sequence -- are asked for their heartbeat.)
+      const int n_it = last - first, hb0 = min(cl.K, (n_it + n_waves - 1) / n_waves);
+      const int n_hb = (epoch > 0u && !(cl.flags & kClusterNoHeartbeat)) ? cl.K - hb0 : 0;
       for (int v0 = 0; v0 < n_it + n_hb; v0 += kWave) {
         const int vi = v0 + lane_id(), j = first + vi;
         const bool mine = vi < n_it, mine_hb = !mine && vi < n_it + n_hb;
@@ -2945,7 +2945,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
             ok = v.y == tag_a && v.w == tag_b;
             cost = __hiloint2double((int)v.z, (int)v.x);
           } else if (mine_hb) {
-            const u32x4 v = xslot_load(&hb[vi - n_it]);
+            const u32x4 v = xslot_load(&hb[hb0 + vi - n_it]);
             ok = v.y == cl.nonce && v.w == (cl.nonce ^ 0x5bd1e995u) && v.z == ~v.x && v.x >= epoch;
           }
 #ifdef NDTPSO_PHASE_BUDGET
@@ -3178,24 +3178,12 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
   // (a cluster's kernels only -- the live node's: two more registers live through every iteration are two more spilled
   // in the batch kernels)
   const bool prefetch = CLUSTER && !gen && ps.I > 0 && 6 * P <= 2 * (int)blockDim.x && sw.raw2 != nullptr;
-  // ... and next to each of those two buffers, where the launch has room for it (behind the speculation scratch), the draws as
-  // the proposal chain uses them: |uniform_pm1(draw)| -- a conversion, two multiplications and two FMAs per draw, made by the
-  // thread that fetches the draw instead of in front of every proposal, where one or two waves work and the cluster waits
-  // (round 5; the same function of the same integer: bit-identical)
-  [[maybe_unused]] double* const dd0 = (CLUSTER && prefetch && cl.spec && (cl.flags & kClusterDDraws)) ? cl.spec + 16 * S : nullptr;
-  [[maybe_unused]] double* const dd1 = dd0 ? dd0 + 6 * P : nullptr;
   int32_t pre0 = 0, pre1 = 0;
   if (prefetch) {
     const int32_t* first = table + 3 * S;
     for (int q = tid; q < 6 * P; q += blockDim.x) {
-      const int32_t a = first[q];
-      sw.raw[q] = a;
-      if (dd0) dd0[q] = fabs(uniform_pm1(a));
-      if (ps.I > 1) {
-        const int32_t b = first[6 * P + q];
-        sw.raw2[q] = b;
-        if (dd0) dd1[q] = fabs(uniform_pm1(b));
-      }
+      sw.raw[q] = first[q];
+      if (ps.I > 1) sw.raw2[q] = first[6 * P + q];
     }
   }
   __syncthreads();
@@ -3248,7 +3236,6 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     NDTPSO_PSO_MARK(0);
     NDTPSO_PB(2);
     int32_t* const pbuf = (it & 1) ? sw.raw2 : sw.raw;  // (prefetch) this iteration's draws; refilled at its end for it + 2
-    [[maybe_unused]] double* const dbuf = (it & 1) ? dd1 : dd0;  // ... and their |uniform_pm1| (nullptr: none)
     const int32_t* draws = gen ? dcur : (prefetch ? pbuf : (table + 3 * S + (size_t)it * 6 * P));
     if (prefetch && it + 2 < ps.I) {
       const int32_t* next = table + 3 * S + (size_t)(it + 2) * 6 * P;
@@ -3288,14 +3275,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         const int n_prop = P - lo;
         for (int q = tid; q < 3 * n_prop; q += blockDim.x) {
           const int j = lo + (q < n_prop ? q : (q - n_prop) >> 1), k = q < n_prop ? 2 : ((q - n_prop) & 1);
-          double r1, r2;
-          if constexpr (CLUSTER) {
-            r1 = dbuf ? dbuf[6 * j + 2 * k] : fabs(uniform_pm1(draws[6 * j + 2 * k]));
-            r2 = dbuf ? dbuf[6 * j + 2 * k + 1] : fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
-          } else {
-            r1 = fabs(uniform_pm1(draws[6 * j + 2 * k]));
-            r2 = fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
-          }
+          const double r1 = fabs(uniform_pm1(draws[6 * j + 2 * k]));
+          const double r2 = fabs(uniform_pm1(draws[6 * j + 2 * k + 1]));
           const double p = sw.pos[k * S + j];
           const double v = sh->k_w * sw.vel[k * S + j] + sh->k_c1 * r1 * (sw.pb[k * S + j] - p) + sh->k_c2 * r2 * (sh->gb[k] - p);
           const double np = p + v;
@@ -3431,12 +3412,12 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         const bool gen_here = CLUSTER && overlapped && it + 1 < ps.I && next_filled < n_draw;
         // a cluster whose round is the whole iteration, with the next draws in its table: both next proposals of every
         // coordinate are made during the exchange (SpecP)
-        [[maybe_unused]] SpecP spec{nullptr, nullptr, 0., 0., 0., nullptr, nullptr};
+        [[maybe_unused]] SpecP spec{nullptr, nullptr, 0., 0., 0., nullptr};
         if constexpr (CLUSTER) {
           if (cl.spec && !gen && lo == 0 && hi_g == P && it + 1 < ps.I && blockDim.x > (unsigned)kWave) {
             // (the next iteration's draws: in the other LDS buffer when the table is prefetched, else where the table lies)
             spec = SpecP{cl.spec, prefetch ? ((it & 1) ? sw.raw : sw.raw2) : table + 3 * S + (size_t)(it + 1) * 6 * P,
-                         sh->k_w * ps.wdamp, sh->k_c1, sh->k_c2, sh->gb, (it & 1) ? dd0 : dd1};
+                         sh->k_w * ps.wdamp, sh->k_c1, sh->k_c2, sh->gb};
             spec_made = true;
           }
         }
@@ -3566,14 +3547,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             }
           }
           if (prefetch && it + 2 < ps.I) {  // this iteration's buffer is free: the draws of the one after the next
-            if (tid < 6 * P) {
-              pbuf[tid] = pre0;
-              if (dbuf) dbuf[tid] = fabs(uniform_pm1(pre0));
-            }
-            if (tid + (int)blockDim.x < 6 * P) {
-              pbuf[tid + blockDim.x] = pre1;
-              if (dbuf) dbuf[tid + blockDim.x] = fabs(uniform_pm1(pre1));
-            }
+            if (tid < 6 * P) pbuf[tid] = pre0;
+            if (tid + (int)blockDim.x < 6 * P) pbuf[tid + blockDim.x] = pre1;
           }
           if (tid == 0) sh->k_w *= ps.wdamp;  // core.cpp:108
           __syncthreads();
@@ -3660,14 +3635,8 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     NDTPSO_PB(5);
     if (pre_proposed) continue;  // (a cluster's round that committed and proposed in one step has done all of this)
     if (prefetch && it + 2 < ps.I) {  // every proposal of this iteration has read its draws (barriers above)
-      if (tid < 6 * P) {
-        pbuf[tid] = pre0;
-        if (dbuf) dbuf[tid] = fabs(uniform_pm1(pre0));
-      }
-      if (tid + (int)blockDim.x < 6 * P) {
-        pbuf[tid + blockDim.x] = pre1;
-        if (dbuf) dbuf[tid + blockDim.x] = fabs(uniform_pm1(pre1));
-      }
+      if (tid < 6 * P) pbuf[tid] = pre0;
+      if (tid + (int)blockDim.x < 6 * P) pbuf[tid + blockDim.x] = pre1;
     }
     if (tid == 0) sh->k_w *= ps.wdamp;  // core.cpp:108 (every proposal of this iteration has read it: barriers above)
     __syncthreads();  // all commits of this iteration done before the next draws/proposals
