@@ -260,9 +260,17 @@ def test_parallel_shape_timing_mode_is_the_same_algorithm(oracle, pairs8):
     libc.srand(1234)
     got, got_cost = ref1.pso_omp((0, 0, 0), new1, DEVIATION, cfg, n_threads=1)
     assert np.array_equal(got, want) and got_cost == want_cost
-    ref4, new4 = oracle_frames(oracle, pairs8, 0)
-    many, many_cost = ref4.pso_omp((0, 0, 0), new4, DEVIATION, cfg, n_threads=4)
-    assert np.abs(many - want).max() < 0.05 and many_cost < 0.8 * want_cost  # costs are negative: a comparable optimum
+    # (racy by construction -- unsynchronised gbest, rand() called from four threads: a run can land on a poorer optimum.  One
+    # run in a few hundred did and failed the suite; five attempts make that one in 1e12.  Timing mode only: never a checker.)
+    tries = []
+    for _ in range(5):
+        ref4, new4 = oracle_frames(oracle, pairs8, 0)
+        many, many_cost = ref4.pso_omp((0, 0, 0), new4, DEVIATION, cfg, n_threads=4)
+        tries.append((float(np.abs(many - want).max()), float(many_cost)))
+        if tries[-1][0] < 0.05 and many_cost < 0.8 * want_cost:  # costs are negative: a comparable optimum
+            break
+    else:
+        raise AssertionError("the four-thread runs never landed near the sequential optimum: %r (want cost %g)" % (tries, want_cost))
 
 
 def test_golden_node_sequence(oracle):
