@@ -1138,9 +1138,22 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         for (int limit : {kMaxLds / 2, kMaxLds}) {
           if (big_table && limit != kMaxLds) continue;
           bool found = false;
+          auto fits = [&](int side, Layout* out) {
+            *out = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0, exact, dynamic_window);
+            return out->total <= limit;
+          };
           for (int side = (int)std::sqrt((double)(full_w * full_h)); side >= 64; side -= 4) {
-            const Layout Lt = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0, exact, dynamic_window);
-            if (Lt.total <= limit) {
+            Layout Lt;
+            if (fits(side, &Lt)) {
+              // (to the cell: a room at 0.25 m is ~18 000 cells, the table of the four-cell step below ended 4 % short of it)
+              for (int up = 3; up >= 1; --up) {
+                Layout Lu;
+                if (fits(side + up, &Lu)) {
+                  Lt = Lu;
+                  side += up;
+                  break;
+                }
+              }
               Ld = Lt;
               cap = dense_entries(side, side);
               found = true;
