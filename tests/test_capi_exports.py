@@ -48,6 +48,16 @@ def test_rand_draws_and_footprint_without_gpu():
     big = capi.PSOConfig.make(200, 2048)
     rc, lds, thr = capi.align_pairs_footprint(capi.ScanGeom(2048, -2.3, 0.002, 30.0, 0.1), capi.Grid(60, 60, 0.25), big)
     assert rc == 0 and 80 * 1024 < lds <= 160 * 1024 and thr == 1024
+    # a table that must shrink to leave two workgroups per CU is sized to the cell: one more row and column would not fit
+    # (in steps of four cells a side it ended 4 % short of a room's box at 0.25 m cells -- the same in the 60 and the 100 m frame)
+    plans = []
+    for frame in (60, 100):
+        rc, plan = capi.align_pairs_describe(geom, capi.Grid(frame, frame, 0.25), cfg, capi.SCORE_EXACT, 512)
+        assert rc == 0 and plan["workgroups_per_cu"] == 2 and plan["table_form"] == 2
+        side = int((plan["table_bytes"] // 2) ** 0.5)          # u16 entries, (side + 1)^2 of them + the records
+        assert 80 * 1024 - plan["lds_bytes"] < 2 * (2 * side + 3) + 16
+        plans.append((plan["lds_bytes"], plan["table_bytes"]))
+    assert plans[0] == plans[1]
     # a scan whose points alone exceed LDS is refused, loudly
     rc, lds, _ = capi.align_pairs_footprint(capi.ScanGeom(12000, -2.3, 0.0004, 30.0, 0.1), capi.Grid(60, 60, 0.25), big)
     assert rc == capi.E_CAPACITY and lds == 0
