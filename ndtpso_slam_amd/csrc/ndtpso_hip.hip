@@ -635,7 +635,17 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
             wn.h = uh;
             wn.n_words = (uw * uh + 31) / 32;
             // table coordinates run over [0, dw + 1), dw = w + 1 (low border column, window, null high column)
-            guard = DenseGuard{rc, (double)(uw + 2) - rc, rc, (double)(uh + 2) - rc};
+            double gx_hi = (double)(uw + 2) - rc, gy_hi = (double)(uh + 2) - rc;
+            if constexpr (!NOCLIP) {
+              // a grid whose last cells overhang the frame (DenseP::clip): the disc stays below the frame's upper bounds too
+              // (DenseItem::XMAX / YMAX in the coordinates of this table), so a pose under the guard cannot hold a point the
+              // clip test would reject and its trips go without the test
+              if (dn.clip) {
+                gx_hi = fmin(gx_hi, (2. * g.hw) * g.inv_cs - (double)(ux0 - 1) - rc);
+                gy_hi = fmin(gy_hi, (2. * g.hh) * g.inv_cs - (double)(uy0 - 1) - rc);
+              }
+            }
+            guard = DenseGuard{rc, gx_hi, rc, gy_hi};
           }
         }
       }

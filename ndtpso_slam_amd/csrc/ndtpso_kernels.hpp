@@ -709,12 +709,9 @@ __device__ __forceinline__ double eval_item_wave_dense(const GridP& g, const Den
   int base = 0;
   if constexpr (NOCLAMP) {
     static_assert(U == 4 && !WIDE, "the no-clamp form is the one-workgroup kernels'");
-    if constexpr (NOCLIP)
-      noclamp_trips<false, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
-    else if (dn.clip)
-      noclamp_trips<true, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
-    else
-      noclamp_trips<false, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
+    // (a grid whose last cells overhang the frame: the guard keeps scan B's disc below the frame's upper bounds as well --
+    // k_align_pairs --, so no point of a pose under it can fail the clip test and the trips need not make it)
+    noclamp_trips<false, BYTE>(g, dn, lds0, pts, n, n_pad, it, acc);
     return -wave_sum(acc[0]);
   }
   // a 2048-beam list (BASELINE config 5; 32 chunks, entries in 16-byte units) in six-chunk trips, as the no-clamp loop
@@ -2522,11 +2519,13 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
     double cost;
     if constexpr (path_is_dense(PATH)) {
       const DenseItem it{c, s, sw.it[4 * j + 2], sw.it[4 * j + 3], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
-      if constexpr (PATH == 3 || (PATH == 2 && NOCLIP)) {  // (the fused pairs kernels: they set up the guard)
-        if (*reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)  // inside the guard both ways (proposal step)
+      if constexpr (PATH == 3 || PATH == 2) {  // (the fused pairs kernels: they set up the guard -- E.guard_lds says so for the
+                                               // one form k_align shares with them, PATH 2 on a grid that may overhang its frame)
+        if ((PATH == 3 || NOCLIP || E.guard_lds) &&
+            *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)  // inside the guard both ways (proposal step)
         {
 #ifdef NDTPSO_COUNT_NOCLAMP  // diagnostic builds: evaluations through the no-clamp loop, reported as `gbest_updates`
-          if (lane_id() == 0) atomicAdd(tiny + 1, 1);  // PsoShared::timed_out (unused by a single workgroup)
+          if (lane_id() == 0) atomicAdd(tiny + 2, 1);  // PsoShared::timed_out (unused by a single workgroup)
 #endif
           cost = eval_item_wave_dense<false, PATH == 3, true, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
         }
@@ -2656,9 +2655,16 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
     double cost;
     if constexpr (path_is_dense(PATH)) {
       const DenseItem it{c, s, sw.it[4 * j + 2], sw.it[4 * j + 3], E.dn.xmax, E.dn.ymax};  // folded where the proposal was made
-      if constexpr (PATH == 3 || (PATH == 2 && NOCLIP)) {  // (the fused pairs kernels: they set up the guard)
-        if (*reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)  // inside the guard both ways (proposal step)
+      if constexpr (PATH == 3 || PATH == 2) {  // (the fused pairs kernels: they set up the guard -- E.guard_lds says so for the
+                                               // one form k_align shares with them, PATH 2 on a grid that may overhang its frame)
+        if ((PATH == 3 || NOCLIP || E.guard_lds) &&
+            *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)  // inside the guard both ways (proposal step)
+        {
+#ifdef NDTPSO_COUNT_NOCLAMP
+          if (lane_id() == 0) atomicAdd(tiny + 1, 1);  // (`tiny` is PsoShared::tiny_j here) PsoShared::timed_out, as eval_items
+#endif
           cost = eval_item_wave_dense<false, PATH == 3, true, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
+        }
         else
           cost = eval_item_wave_dense<false, PATH == 3, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
       } else {

@@ -295,6 +295,89 @@ def test_no_clamp_loop_edges(ctx, oracle, pairs8):
         assert np.abs(res[capi.SCORE_F64][1] - wcost).max() < 1e-8
 
 
+def test_guard_on_grids_that_overhang_their_frame(ctx, oracle, pairs8, monkeypatch):
+    """A frame that is not a whole number of cells wide (NDTFrame takes whole metres, ndtframe.h:32; 0.3, 0.7, 0.75, 1.5 m
+    cells): the last cells overhang it and getCellIndex (ndtframe.cpp:242) rejects points beyond the frame although a cell
+    exists there.  The one-workgroup kernels' guard keeps scan B's disc below the frame's upper bounds as well, so that poses
+    under it score without the clip test.  The smallest frames that hold scan A's farthest wall (its cells are the overhanging
+    ones; scan B, shifted by the guess and the swarm's spread, crosses the border), one alignment at a time on one workgroup:
+    every mode against the oracle, exact == fp64.  Then a scene made for it (below), which a guard without the frame's bound fails."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    geom = _geom(p, capi)
+    P, I = 24, 12
+    cfg, ocfg = capi.PSOConfig.make(I, P), oracle.PSOConfig.make(I, P)
+    monkeypatch.setenv("NDTPSO_CLUSTER", "0")
+    ang = p.angle_min + p.angle_inc * np.arange(p.n_beams)
+    n_checked, bad = 0, []
+    for b in range(4):
+        ref, new = p.ref_ranges[b:b + 1], p.new_ranges[b:b + 1]
+        ok = (ref[0] > 0.1) & (ref[0] < p.range_max)
+        extent = float(max(np.abs(ref[0][ok] * np.cos(ang[ok])).max(), np.abs(ref[0][ok] * np.sin(ang[ok])).max()))
+        for cs in (0.3, 0.7, 0.75, 1.5):
+            for frame in (int(np.ceil(2 * extent)), int(np.ceil(2 * extent)) + 1):
+                if abs(frame / cs - round(frame / cs)) < 1e-6:           # (a whole number of cells after all)
+                    continue
+                for guess in ((0, 0, 0), (0.4, 0.45, 0.02), (-0.45, -0.4, -0.02)):
+                    dev = (0.3, 0.3, 0.01)
+                    want, wcost, _ = oracle.align_pairs(ref, new, p.angle_min, p.angle_inc, p.range_max, 0.1, frame, frame, cs,
+                                                        guess, dev, ocfg, p.seeds[b:b + 1])
+                    res = {}
+                    for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
+                        got, cost, stats = ctx.align_pairs(ref, new, geom, capi.Grid(frame, frame, cs), guess, dev, cfg,
+                                                           seeds=p.seeds[b:b + 1], mode=mode)
+                        assert (stats["status"] == 0).all(), (b, cs, frame, guess, mode, stats["status"])
+                        res[mode] = (got, cost)
+                        tol = 1e-9 if mode != capi.SCORE_F32 else 1e-3
+                        if not np.abs(got - want).max() < tol:
+                            bad.append((b, cs, frame, guess, mode, float(np.abs(got - want).max())))
+                    if not (np.array_equal(res[capi.SCORE_EXACT][0], res[capi.SCORE_F64][0]) and
+                            np.array_equal(res[capi.SCORE_EXACT][1], res[capi.SCORE_F64][1]) and
+                            np.abs(res[capi.SCORE_F64][1] - wcost).max() < 1e-8):
+                        bad.append((b, cs, frame, guess, "exact/f64/cost"))
+                    n_checked += 1
+    # ... and a scene made for it.  NDTFrame::cost_function takes scan B's points from B's own frame, i.e. clipped to the frame
+    # at B's pose; they cross the border only by what the pose moves them.  Two walls seen from x = 0 (scan A) and from
+    # x = 0.2 m (scan B, so the true pose is (0.2, 0, 0)): y = 3 m, and a slanted one through the frame's border, x from 0.3 m
+    # inside to 0.3 m outside.  A's points inside the frame build the overhanging cell; B keeps the wall up to 0.2 m beyond the
+    # border and at the true pose those points lie in that cell, beyond the frame: the reference rejects them.  (Without the
+    # frame's bound in the guard the poses around the optimum count as guarded and score them: different costs and poses.)
+    frame = 20
+
+    def seen_from(sx):
+        r = np.zeros(p.n_beams, np.float32)
+        far = np.abs(ang) < 0.6
+        rf = (frame / 2 - sx) / (np.cos(ang) - 0.5 * np.sin(ang))            # the line x = frame/2 + 0.5 y
+        yf = rf * np.sin(ang)
+        far &= np.abs(yf) < 0.6
+        r[far] = rf[far]
+        side = (ang > 0.35) & (ang < 2.3)
+        r[side] = (3.0 / np.sin(ang[side])).astype(np.float32)               # the line y = 3
+        return r[None, :]
+    ref, new = seen_from(0.0), seen_from(0.2)
+    assert ((ref[0] > 0.1) & (ref[0] < p.range_max)).sum() > 300
+    for cs in (0.3, 0.7, 0.75, 1.5):
+        assert abs(frame / cs - round(frame / cs)) > 1e-6
+        for guess in ((0, 0, 0), (0.3, -0.1, 0.004)):
+            dev = (0.3, 0.3, 0.01)
+            want, wcost, _ = oracle.align_pairs(ref, new, p.angle_min, p.angle_inc, p.range_max, 0.1, frame, frame, cs,
+                                                guess, dev, ocfg, p.seeds[:1])
+            res = {}
+            for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
+                got, cost, stats = ctx.align_pairs(ref, new, geom, capi.Grid(frame, frame, cs), guess, dev, cfg, seeds=p.seeds[:1], mode=mode)
+                assert (stats["status"] == 0).all(), (cs, guess, mode, stats["status"])
+                res[mode] = (got, cost)
+                tol = 1e-9 if mode != capi.SCORE_F32 else 1e-3
+                if not (np.abs(got - want).max() < tol and np.abs(cost - wcost).max() < (1e-8 if mode != capi.SCORE_F32 else 1e-3)):
+                    bad.append(("wall", cs, guess, mode, float(np.abs(got - want).max()), float(np.abs(cost - wcost).max())))
+            if not (np.array_equal(res[capi.SCORE_EXACT][0], res[capi.SCORE_F64][0]) and np.array_equal(res[capi.SCORE_EXACT][1], res[capi.SCORE_F64][1])):
+                bad.append(("wall", cs, guess, "exact != f64"))
+            n_checked += 1
+    print("cases", n_checked, "bad", len(bad), bad[:4])
+    assert n_checked >= 68
+    assert not bad, bad[:6]
+
+
 def test_randomised_configurations(ctx, oracle):
     """40 random configurations (frame 20..120 m, cell side 0.2..1.5 m incl. non power-of-two, 3..90 particles,
     0..25 iterations, 90..1500 beams, off-centre guesses, random deviations, dropped beams) against the oracle:
