@@ -550,6 +550,63 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
   }
 }
 
+// The guard of the one-workgroup dense kernels when the box of scan B's DISC does not fit the table beside scan A's (cells of
+// 0.25 - 0.3 m at two workgroups per CU: nine evaluations in ten took the clamped trips).  Scan B's own extent under the guess's
+// heading instead, grown by what a heading within `dth` of it moves a point (at most rho * dth): the box of the same room as scan
+// A's, a few cells wider.  The guard then holds for those headings only (DenseGuard::t_lo / t_hi, a third flag beside TX's and
+// TY's).  Every thread of the workgroup calls it; the result is left in LDS (`out`, valid after the call's last barrier).
+struct BoxGuardOut {
+  DenseGuard guard;
+  double t_lo, t_hi;
+  int x0, y0, w, h;
+  int ok;
+};
+static_assert(sizeof(BoxGuardOut) <= 24 * sizeof(int), "BoxGuardOut lives in the counters' first slots");
+__device__ __attribute__((noinline)) void box_guard_wg(const float* __restrict__ ranges, const ScanP* sp,
+                                                       const double2* __restrict__ dirs, const GridP* g, const double* guess,
+                                                       const double* dev, double rc, double cx, double cy, const WinP* wn,
+                                                       int dense_cap, int clip, int* slots, BoxGuardOut* out) {
+  constexpr double kMarginCells = 4.;
+  const double th0 = guess[2];
+  const double dth = fmin(0.1, fmax(0.02, 16. * fabs(dev[2])));
+  double s0, c0;
+  sincos(th0, &s0, &c0);
+  int e[4];
+  const bool have = scan_extent_wg(ranges, *sp, dirs, c0, s0, g->inv_cs, slots, e);
+  if (threadIdx.x == 0) {
+    out->ok = 0;
+    if (have && fabs(th0) < 1e6 && dth == dth) {
+      const double grow = rc * dth + 1e-6;  // cells (rc: rho in cells with the transform's rounding)
+      const double ex0 = (double)e[0] * (1. / 256.) - grow, ex1 = (double)e[1] * (1. / 256.) + grow;
+      const double ey0 = (double)e[2] * (1. / 256.) - grow, ey1 = (double)e[3] * (1. / 256.) + grow;
+      const int cx0 = max((int)floor(cx + ex0 - kMarginCells), 0), cx1 = min((int)floor(cx + ex1 + kMarginCells), g->W - 1);
+      const int cy0 = max((int)floor(cy + ey0 - kMarginCells), 0), cy1 = min((int)floor(cy + ey1 + kMarginCells), g->H - 1);
+      if (cx1 >= cx0 && cy1 >= cy0) {
+        const int vx0 = min(wn->x0, cx0), vy0 = min(wn->y0, cy0);
+        const int vw = max(wn->x0 + wn->w - 1, cx1) - vx0 + 1, vh = max(wn->y0 + wn->h - 1, cy1) - vy0 + 1;
+        if (dense_entries(vw + 1, vh + 1) <= dense_cap) {
+          // a point's table coordinate is TX + e, e in [ex0, ex1]: 0 <= TX + ex0 and TX + ex1 < w + 2 (and below the frame's
+          // upper bound where the last cells overhang it)
+          double hx = (double)(vw + 2) - ex1, hy = (double)(vh + 2) - ey1;
+          if (clip) {
+            hx = fmin(hx, (2. * g->hw) * g->inv_cs - (double)(vx0 - 1) - ex1);
+            hy = fmin(hy, (2. * g->hh) * g->inv_cs - (double)(vy0 - 1) - ey1);
+          }
+          out->guard = DenseGuard{-ex0, hx, -ey0, hy};
+          out->t_lo = th0 - dth;
+          out->t_hi = th0 + dth;
+          out->x0 = vx0;
+          out->y0 = vy0;
+          out->w = vw;
+          out->h = vh;
+          out->ok = 1;
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // ---- fused scan pairs: K3a(ref) + K3b + K3a(new) + K2, everything in LDS -------------------------
 //
 // gate == 0: every workgroup runs.  gate != 0: a redo launch -- only alignments an earlier launch flagged with
@@ -564,7 +621,7 @@ k_align(const unsigned char* __restrict__ image, const double2* __restrict__ xy,
 // 0 / 1 = only the LDS / only the HBM copy.  The NOCLIP kernels -- the ones the batches of the benchmark run -- exist as
 // 0 and 1: at 128 registers what is inlined beside the hot loop decides its allocation (fp32-score kernel of config 3:
 // 21 spills with both copies, none with its own).
-template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, int SWARM = 2>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, int SWARM = 2, bool BOX = false>
 __global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
@@ -598,6 +655,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   __syncthreads();
   NDTPSO_SETUP_MARK(1);
   DenseGuard guard{1., 0., 1., 0.};  // (empty: every pose takes the clamped loop)
+  [[maybe_unused]] double g_t_lo = -1.7976931348623157e308, g_t_hi = 1.7976931348623157e308;  // BOX: the headings it holds for
   if constexpr (MODE == kScoreF64 && !path_is_dense(PATH) && !path_is_dense64(PATH) && !CLUSTER) {
     // fp64 score, bitmap form: scan B's points lie within rho of the sensor, so a pose whose translation keeps that disc
     // strictly inside the frame AND inside the table's window needs none of the per-point frame / window / wrap tests
@@ -646,6 +704,24 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
               }
             }
             guard = DenseGuard{rc, gx_hi, rc, gy_hi};
+          } else if constexpr (BOX) {
+            // The disc's box does not fit beside scan A's: the box of scan B's own extent under the guess's heading (box_guard_wg).
+            // BOX: the kernels the host launches when the provisioned table is much smaller than the static window (Plan::boxy) -- a
+            // copy of their own: this branch's presence cost the benchmark's batches 2.3 % out of line and 4 % inline, the third flag 2 %
+            BoxGuardOut* bo = reinterpret_cast<BoxGuardOut*>(lds_cnt(L.ctrl_off));
+            box_guard_wg(new_ranges + b * sp.n_beams, &sp, beam_dirs, &g, guess + 3 * b, dev + 3 * b, rc, cx, cy, &wn, dense_cap,
+                         NOCLIP ? 0 : dn.clip, lds_cnt(L.ctrl_off) + 24, bo);
+            if (bo->ok) {
+              wn.x0 = bo->x0;
+              wn.y0 = bo->y0;
+              wn.w = bo->w;
+              wn.h = bo->h;
+              wn.n_words = (bo->w * bo->h + 31) / 32;
+              guard = bo->guard;
+              g_t_lo = bo->t_lo;
+              g_t_hi = bo->t_hi;
+            }
+            __syncthreads();  // (the counters' slots are free again)
           }
         }
       }
@@ -734,7 +810,13 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
                                       g.hw, g.hh);
   pad_points_wg(pts, n_new);
-  if (threadIdx.x == 0) lds_ctrl(L.ctrl_off)->guard = guard;
+  if (threadIdx.x == 0) {
+    lds_ctrl(L.ctrl_off)->guard = guard;
+    if constexpr (BOX) {
+      lds_ctrl(L.ctrl_off)->g_t_lo = g_t_lo;
+      lds_ctrl(L.ctrl_off)->g_t_hi = g_t_hi;
+    }
+  }
   __syncthreads();
   NDTPSO_SETUP_MARK(4);
 #ifdef NDTPSO_PROFILE_SETUP
@@ -759,7 +841,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
   if (SWARM == 1 || (SWARM == 2 && L.swarm_global)) {  // (two copies: see k_align)
     if constexpr (SWARM != 0) {
       const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P, ARB, true);
-      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, true>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, true, false, BOX>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                                            tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
                                            out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
     }
@@ -767,7 +849,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     if constexpr (SWARM != 1) {
       const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
       // (SWARM == 0: the batches' kernels, whose layout always carries the arbitration's unit scratch -- make_layout)
-      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, false, (SWARM == 0 && ARB && !CLUSTER)>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
+      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, false, (SWARM == 0 && ARB && !CLUSTER), BOX>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
                                            tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
                                            out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
     }
@@ -1115,6 +1197,8 @@ struct Plan {
   DenseP dn;
   int dense_cap;  // cell-table entries provisioned (fused kernel: the window is chosen per alignment)
   bool shrunk;    // ... fewer than the static window's: an alignment's box may not fit (kStatusNeedsBitmap)
+  bool boxy;      // ... fewer than 60 % of them: the box of scan B's disc will rarely fit beside scan A's -> the kernels that carry the
+                  // box guard (box_guard_wg).  (The benchmark's table is 86 % of its static window and every disc fits.)
 };
 // `wn` is the staging window: final for a prebuilt table; for the fused pairs kernel (dynamic_window) it is the
 // static range box -- the worst case the bitmap form must hold -- while the dense form sizes its window per
@@ -1129,6 +1213,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
                bool allow_dense = true, bool allow_global = false, bool exact = false, bool big_table = false) {
   const int bitmap_path = g.cs_pow2 ? 1 : 0;
   plan->shrunk = false;
+  plan->boxy = false;
   int force = -1;
   if (const char* e = std::getenv("NDTPSO_PATH")) force = std::atoi(e);  // tuning knob
   // (fp64 score: the dense form exists in the fused pairs kernel only -- dynamic_window -- and needs every record below 64 KB)
@@ -1179,6 +1264,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         plan->dn = make_dense(g, wn, Ld);
         plan->dense_cap = cap;
         plan->shrunk = cap < dense_entries(full_w, full_h);
+        plan->boxy = plan->shrunk && (long)cap * 5 < (long)dense_entries(full_w, full_h) * 3;
         return true;
       }
     }
@@ -1294,6 +1380,15 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, false, true, 1>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true, true, 1>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true, true, 1>);
+  // (the copies that carry the box guard: tables smaller than the static window)
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, false, true, 0, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, false, true, 0, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true, true, 0, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true, true, 0, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, false, false, 2, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, false, false, 2, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true, false, 2, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true, false, 2, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, false, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, true, true>);
 #define GLOBAL_PATHS(K, ...)                                                   \
@@ -2185,11 +2280,21 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     HIP_TRY(c, c->ximg.reserve(ximg_stride * n_pairs * (size_t)K));
   }
   unsigned char* d_ximg = ximg_stride ? (unsigned char*)c->ximg.p : nullptr;
-#define LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, SWARM)                                                      \
-  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM>), dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), lds_total, \
+#define LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX)                                                \
+  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX>), dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), lds_total, \
                      c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
                      d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
                      cl, dirs, d_ximg, ximg_stride, fb)
+// (a table much smaller than the static window -- Plan::boxy -- and the swarm in LDS: the copies that carry the box guard)
+#define LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, SWARM)                                                      \
+  do {                                                                                                             \
+    if constexpr ((PATH == 2 || PATH == 3) && !CL && SWARM != 1) {                                                 \
+      if (plan.boxy && !plan.L.swarm_global) LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, true);         \
+      else LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, false);                                          \
+    } else {                                                                                                       \
+      LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, false);                                               \
+    }                                                                                                              \
+  } while (0)
 // (the kernels without clipping trips exist per home of the swarm, the others carry both copies of the PSO)
 #define LAUNCH_PAIRS_CAN(MODE, PATH, CL, ARB, NOCLIP)                                    \
   do {                                                                                   \
@@ -2236,6 +2341,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
 #undef LAUNCH_PAIRS_CA
 #undef LAUNCH_PAIRS_CAN
 #undef LAUNCH_PAIRS_CANS
+#undef LAUNCH_PAIRS_CANSB
   HIP_TRY(c, hipGetLastError());
   return NDTPSO_OK;
 }

@@ -1209,6 +1209,53 @@ __device__ inline float scan_max_range_wg(const float* __restrict__ ranges, cons
   return __int_as_float(*slot);
 }
 
+// Extent of a scan's points under a heading, in 1/256 cells, rounded outwards: box[0..3] = x_lo, x_hi, y_lo, y_hi of
+// r_i (cos a_i, sin a_i) turned by (c0, s0) and scaled by inv_cs, over the beams laser_to_point keeps (ndtframe.cpp:165; the
+// list the score loop runs over is a subset: the new frame drops what leaves it).  Returns false for a scan without points.
+__device__ inline bool scan_extent_wg(const float* __restrict__ ranges, const ScanP& sp, const double2* __restrict__ dirs,
+                                      double c0, double s0, double inv_cs, int* box, int (&out)[4]) {
+  if (threadIdx.x == 0) {
+    box[0] = box[2] = 0x7fffffff;
+    box[1] = box[3] = -0x7fffffff;
+  }
+  __syncthreads();
+  int x_lo = 0x7fffffff, x_hi = -0x7fffffff, y_lo = 0x7fffffff, y_hi = -0x7fffffff;
+  for (int i = threadIdx.x; i < sp.n_beams; i += blockDim.x) {
+    const float r = ranges[i];
+    if (((double)r > 0.) && (r < sp.rmax) && (r > sp.eps)) {
+      const double2 d = dirs[i];
+      const double px = (double)r * d.x, py = (double)r * d.y;
+      const double qx = (px * c0 - py * s0) * (256. * inv_cs), qy = (px * s0 + py * c0) * (256. * inv_cs);
+      if (fabs(qx) < 1e9 && fabs(qy) < 1e9) {
+        x_lo = min(x_lo, (int)floor(qx) - 1);
+        x_hi = max(x_hi, (int)ceil(qx) + 1);
+        y_lo = min(y_lo, (int)floor(qy) - 1);
+        y_hi = max(y_hi, (int)ceil(qy) + 1);
+      } else {
+        x_lo = y_lo = -0x7fffffff;  // (no box can hold it)
+        x_hi = y_hi = 0x7fffffff;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = kWave / 2; d > 0; d >>= 1) {
+    x_lo = min(x_lo, __shfl_xor(x_lo, d, kWave));
+    x_hi = max(x_hi, __shfl_xor(x_hi, d, kWave));
+    y_lo = min(y_lo, __shfl_xor(y_lo, d, kWave));
+    y_hi = max(y_hi, __shfl_xor(y_hi, d, kWave));
+  }
+  if (lane_id() == 0 && x_hi >= x_lo) {
+    atomicMin(&box[0], x_lo);
+    atomicMax(&box[1], x_hi);
+    atomicMin(&box[2], y_lo);
+    atomicMax(&box[3], y_hi);
+  }
+  __syncthreads();
+  for (int k = 0; k < 4; ++k) out[k] = box[k];
+  __syncthreads();  // (the slots are free again)
+  return out[1] >= out[0] && out[0] > -0x7fffffff;
+}
+
 // ---- K3b: points -> reference cell table (fresh frame) ------------------------------------------
 //
 // NDTFrame::addPoint binning (ndtframe.cpp:215-235) + NDTCell::build for a cell whose window is
@@ -1772,7 +1819,7 @@ struct Swarm {  // SoA, stride = P+1 (slot P is the "initial guess" particle of 
                   //        {C, S, TX, TY} (DenseItem), computed once where the proposal is made instead of by every wave
                   //        that evaluates it; one record, so that an evaluation fetches it with two 16-byte reads off one address
   double* tcost;  // [S]
-  unsigned char* tgd;  // [S][2] fused pairs kernels: TX / TY of the proposal lie inside the DenseGuard (set with them; the
+  unsigned char* tgd;  // [S][2] ([S][4] in the BOX kernels: + heading, + a 1) fused pairs kernels: TX / TY of the proposal lie inside the DenseGuard (set with them; the
                        //        evaluating wave reads the pair as one 16-bit word instead of comparing four doubles)
   double* pcs;    // [2][S] plain cos, sin of the proposal's heading  } exact mode only: what the fp64 score of a
   double* bcs;    // [2][S] the same for the pbest position            } position takes (exact_tasks), so that the
@@ -1802,7 +1849,7 @@ __device__ inline Swarm swarm_carve(unsigned char* base, int P, bool exact, bool
   sw.tvel = d + 13 * S;
   sw.it = d + 16 * S;
   sw.tcost = d + 20 * S;
-  sw.tgd = reinterpret_cast<unsigned char*>(d + 21 * S);  // (2 S bytes of an S-double slot)
+  sw.tgd = reinterpret_cast<unsigned char*>(d + 21 * S);  // (4 S bytes of an S-double slot)
   sw.pcs = exact ? d + 22 * S : nullptr;
   sw.bcs = exact ? d + 24 * S : nullptr;
   sw.pex = exact ? reinterpret_cast<unsigned char*>(d + 26 * S) : nullptr;  // (S bytes of an S-double slot)
@@ -1878,6 +1925,10 @@ struct PsoShared {  // small control block in LDS
   double k_w, k_c1, k_c2;             // inertia weight of the current iteration (core.cpp:108), c1, c2
   double k_hw, k_hh, k_inv, k_ox, k_oy;  // dense form: the fold of a position into a DenseItem (dense_item)
   ExactArgs xa;
+  // BOX kernels (k_align_pairs): the headings `guard` holds for -- any (the box of scan B's disc) or a window around the guess's
+  // (the box of scan B's own extent under that heading, grown by what the window can turn it: scan_extent_wg, box_guard_wg).
+  // Behind everything else: the other kernels' offsets stay what they were.
+  double g_t_lo, g_t_hi;
 };
 
 // PATH: 0 = bitmap table, true division by cell_side; 1 = bitmap table, power-of-two cell side; 2 = dense fast path;
@@ -2489,7 +2540,7 @@ __device__ __forceinline__ void exact_tasks_wg(ExactArgs* ap, const unsigned sho
 // KGEN: the light-wave deal for any number k of items per wave (PsoP::light = k); without it k is two.  Only the copies of
 // the PSO that keep their swarm in HBM carry it (large swarms: make_pso) -- in the 70-particle kernels the general
 // deal's few extra instructions cost 2.4 % (exact) / 1 % (fp32) on config 3, same box.
-template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false, bool KGEN = false>
+template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false, bool KGEN = false, bool BOX = false>
 __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first,
                                   int last /*exclusive*/, double gbc, int* improver, int* tiny, int* near_cnt,
                                   unsigned short* near_list) {
@@ -2522,7 +2573,8 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       if constexpr (PATH == 3 || PATH == 2) {  // (the fused pairs kernels: they set up the guard -- E.guard_lds says so for the
                                                // one form k_align shares with them, PATH 2 on a grid that may overhang its frame)
         if ((PATH == 3 || NOCLIP || E.guard_lds) &&
-            *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)  // inside the guard both ways (proposal step)
+            (BOX ? *reinterpret_cast<const unsigned*>(sw.tgd + 4 * j) == 0x01010101u    // inside the guard: x, y, heading
+                 : *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u))  // inside the guard both ways (proposal step)
         {
 #ifdef NDTPSO_COUNT_NOCLAMP  // diagnostic builds: evaluations through the no-clamp loop, reported as `gbest_updates`
           if (lane_id() == 0) atomicAdd(tiny + 2, 1);  // PsoShared::timed_out (unused by a single workgroup)
@@ -2617,7 +2669,7 @@ __device__ __forceinline__ int take_ticket(int* counter, int* spare /* 32 words 
   return __builtin_amdgcn_readfirstlane(v);
 }
 
-template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false>
+template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false, bool BOX = false>
 __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int P, double gbc,
                                    int* ticket, int* spare, int* improver, int* jmax, int* tiny, int* near_cnt,
                                    unsigned short* near_list) {
@@ -2658,7 +2710,8 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
       if constexpr (PATH == 3 || PATH == 2) {  // (the fused pairs kernels: they set up the guard -- E.guard_lds says so for the
                                                // one form k_align shares with them, PATH 2 on a grid that may overhang its frame)
         if ((PATH == 3 || NOCLIP || E.guard_lds) &&
-            *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)  // inside the guard both ways (proposal step)
+            (BOX ? *reinterpret_cast<const unsigned*>(sw.tgd + 4 * j) == 0x01010101u    // inside the guard: x, y, heading
+                 : *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u))  // inside the guard both ways (proposal step)
         {
 #ifdef NDTPSO_COUNT_NOCLAMP
           if (lane_id() == 0) atomicAdd(tiny + 1, 1);  // (`tiny` is PsoShared::tiny_j here) PsoShared::timed_out, as eval_items
@@ -2868,14 +2921,14 @@ constexpr unsigned long long kClusterWaitTicks = 2000000ull;  // 20 ms of the 10
 
 // Evaluates items [first, last) of the swarm; on return (after the caller's barrier) sw.tcost holds their costs and
 // *improver / *tiny are set as eval_items sets them.  `epoch` counts the cluster's exchanges.
-template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, bool KGEN = false>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, bool KGEN = false, bool BOX = false>
 __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int first, int last,
                                   double gbc, int* improver, int* tiny, const ClusterP& cl, unsigned& epoch,
                                   int* timed_out, int* near_cnt, unsigned short* near_list,
                                   RngState* gen_st = nullptr, int* gen_t = nullptr, int32_t* gen_dst = nullptr,
                                   int gen_cnt = 0, int gen_wave = -1, const SpecP* sp = nullptr) {
   if constexpr (!CLUSTER) {
-    eval_items<MODE, PATH, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
+    eval_items<MODE, PATH, ARB, NOCLIP, KGEN, BOX>(E, pts, n, sw, S, first, last, gbc, improver, tiny, near_cnt, near_list);
   } else {
     NDTPSO_PHASE_MARK(0);
     const int n_waves = blockDim.x >> 6, total_waves = cl.K * n_waves;
@@ -2996,7 +3049,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
 // ARB: the exact mode (NDTPSO_SCORE_EXACT) of the fp32-score dense kernels.  A template parameter, not a run-time
 // switch: the arbitration code in the same kernel cost the plain fp32 mode 11 % (register pressure: spills in the
 // proposal / commit paths), see DESIGN.md.
-template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false, bool KGEN = false, bool UNITS = false>
+template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false, bool KGEN = false, bool UNITS = false, bool BOX = false>
 __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
@@ -3084,8 +3137,14 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         sw.it[4 * slot + 2] = TX;
         sw.it[4 * slot + 3] = TY;
         // (NaN translations fail the tests and take the clamped loop)
-        sw.tgd[2 * slot] = (TX >= sh->guard.x_lo && TX < sh->guard.x_hi) ? 1 : 0;
-        sw.tgd[2 * slot + 1] = (TY >= sh->guard.y_lo && TY < sh->guard.y_hi) ? 1 : 0;
+        if constexpr (BOX) {  // four bytes per particle: TX, TY, heading inside the guard, and a 1 -- read as one word
+          *reinterpret_cast<unsigned*>(sw.tgd + 4 * slot) = ((TX >= sh->guard.x_lo && TX < sh->guard.x_hi) ? 1u : 0u) |
+                                                            ((TY >= sh->guard.y_lo && TY < sh->guard.y_hi) ? 0x100u : 0u) |
+                                                            ((th >= sh->g_t_lo && th <= sh->g_t_hi) ? 0x10000u : 0u) | 0x1000000u;
+        } else {
+          sw.tgd[2 * slot] = (TX >= sh->guard.x_lo && TX < sh->guard.x_hi) ? 1 : 0;
+          sw.tgd[2 * slot + 1] = (TY >= sh->guard.y_lo && TY < sh->guard.y_hi) ? 1 : 0;
+        }
       } else {
         sw.it[4 * slot] = cn;
         sw.it[4 * slot + 1] = sn;
@@ -3098,7 +3157,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
     }
   }
   __syncthreads();
-  eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
+  eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN, BOX>(E, pts, n, sw, S, 0, S, 0., nullptr, &sh->tiny, cl, epoch, &sh->timed_out, nullptr,
                                   nullptr);
   n_evals += S;
   n_rounds += 1;
@@ -3297,12 +3356,12 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             if (k == 0) {
               const double TX = (np + sh->k_hw) * sh->k_inv - sh->k_ox;
               sw.it[4 * j + 2] = TX;
-              sw.tgd[2 * j] = (TX >= sh->guard.x_lo && TX < sh->guard.x_hi) ? 1 : 0;
+              sw.tgd[(BOX ? 4 : 2) * j] = (TX >= sh->guard.x_lo && TX < sh->guard.x_hi) ? 1 : 0;
             }
             if (k == 1) {
               const double TY = (np + sh->k_hh) * sh->k_inv - sh->k_oy;
               sw.it[4 * j + 3] = TY;
-              sw.tgd[2 * j + 1] = (TY >= sh->guard.y_lo && TY < sh->guard.y_hi) ? 1 : 0;
+              sw.tgd[(BOX ? 4 : 2) * j + 1] = (TY >= sh->guard.y_lo && TY < sh->guard.y_hi) ? 1 : 0;
             }
           }
           if (k == 2) {
@@ -3310,6 +3369,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             sincos(np, &sn, &cn);
             sw.it[4 * j] = fold ? cn * sh->k_inv : cn;
             sw.it[4 * j + 1] = fold ? sn * sh->k_inv : sn;
+            if constexpr (fold && BOX) sw.tgd[4 * j + 2] = (np >= sh->g_t_lo && np <= sh->g_t_hi) ? 1 : 0;
             if constexpr (ARB) {
               sw.pcs[j] = cn;
               sw.pcs[S + j] = sn;
@@ -3336,7 +3396,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           next_filled = n_draw;
         }
         NDTPSO_PB(5);
-        eval_stream<MODE, PATH, ARB, NOCLIP>(E, pts, n, sw, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny_j,
+        eval_stream<MODE, PATH, ARB, NOCLIP, BOX>(E, pts, n, sw, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny_j,
                                              &sh->near_cnt[slot], sh->near_list[slot]);
         NDTPSO_PB(4);
         __syncthreads();
@@ -3427,7 +3487,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
             spec_made = true;
           }
         }
-        eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
+        eval_round<MODE, PATH, CLUSTER, ARB, NOCLIP, KGEN, BOX>(E, pts, n, sw, S, lo, hi_g, sh->gbc, &sh->jstar[slot], &sh->tiny, cl, epoch,
                                         &sh->timed_out, &sh->near_cnt[slot], sh->near_list[slot], &sh->rng, &rng_t,
                                         dnext + next_filled, gen_here ? n_draw - next_filled : 0, rng_w, CLUSTER ? &spec : nullptr);
         if (gen_here) next_filled = n_draw;

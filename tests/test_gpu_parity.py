@@ -378,6 +378,46 @@ def test_guard_on_grids_that_overhang_their_frame(ctx, oracle, pairs8, monkeypat
     assert not bad, bad[:6]
 
 
+def test_box_guard_of_small_cell_tables(ctx, oracle, pairs8, monkeypatch):
+    """Cells of 0.25 / 0.3 m: the provisioned table is a fraction of the static window and the box of scan B's DISC rarely fits
+    beside scan A's, so the one-workgroup kernels take their guard from scan B's own extent under the guess's heading, valid for
+    headings within a window around it (box_guard_wg; a third flag per particle).  One alignment per workgroup; guesses with and
+    without a heading, a swarm spread far beyond the heading window (those particles take the clamped trips: the same sums), a
+    guess next to the frame's border: every mode against the oracle, exact == fp64."""
+    from ndtpso_slam_amd import capi
+    p = pairs8
+    geom = _geom(p, capi)
+    P, I = 24, 12
+    cfg, ocfg = capi.PSOConfig.make(I, P), oracle.PSOConfig.make(I, P)
+    monkeypatch.setenv("NDTPSO_CLUSTER", "0")
+    ref, new = p.ref_ranges[:6], p.new_ranges[:6]
+    n_checked = 0
+    for cs, frame in ((0.25, 60), (0.3, 60), (0.3, 100)):
+        rc, plan = capi.align_pairs_describe(geom, capi.Grid(frame, frame, cs), cfg, capi.SCORE_EXACT, 6)
+        assert rc == 0 and plan["table_form"] == 2
+        for guess, dev in (((0, 0, 0), DEVIATION), ((0.3, -0.2, 0.7), DEVIATION), ((0, 0, -2.9), (0.1, 0.1, 0.2)),
+                           ((0.1, 0.1, 0.05), (2.0, 2.0, 0.5)), ((frame / 2 - 2.5, -(frame / 2 - 2.0), 0.3), DEVIATION),
+                           # (headings that straddle the window's edge, 0.1 rad from the guess's, with the guard in force)
+                           ((0, 0, 0), (0.1, 0.1, 0.08)), ((0.2, -0.1, 0.3), (0.05, 0.05, 0.09)),
+                           # (most of the swarm far outside it, translations inside the box.  A build whose guard ignores the heading
+                           # still passes all of this: an index beyond the table reads past LDS -> 0 -> the null record, or a far
+                           # cell whose Gaussian is zero at that point; the window is what makes it certain, not what makes it work)
+                           ((0, 0, 0), (0.05, 0.05, 0.5))):
+            want, wcost, _ = oracle.align_pairs(ref, new, p.angle_min, p.angle_inc, p.range_max, 0.1, frame, frame, cs,
+                                                guess, dev, ocfg, p.seeds[:6])
+            res = {}
+            for mode in (capi.SCORE_F64, capi.SCORE_EXACT, capi.SCORE_F32):
+                got, cost, stats = ctx.align_pairs(ref, new, geom, capi.Grid(frame, frame, cs), guess, dev, cfg, seeds=p.seeds[:6], mode=mode)
+                assert (stats["status"] == 0).all(), (cs, frame, guess, mode, stats["status"])
+                res[mode] = (got, cost)
+                assert np.abs(got - want).max() < (1e-9 if mode != capi.SCORE_F32 else 1e-3), (cs, frame, guess, mode, np.abs(got - want).max())
+            assert np.array_equal(res[capi.SCORE_EXACT][0], res[capi.SCORE_F64][0]), (cs, frame, guess)
+            assert np.array_equal(res[capi.SCORE_EXACT][1], res[capi.SCORE_F64][1]), (cs, frame, guess)
+            assert np.abs(res[capi.SCORE_F64][1] - wcost).max() < 1e-8
+            n_checked += 1
+    assert n_checked == 24
+
+
 def test_randomised_configurations(ctx, oracle):
     """40 random configurations (frame 20..120 m, cell side 0.2..1.5 m incl. non power-of-two, 3..90 particles,
     0..25 iterations, 90..1500 beams, off-centre guesses, random deviations, dropped beams) against the oracle:
