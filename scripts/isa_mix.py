@@ -1,7 +1,7 @@
 """Instruction mix of the score loop of the fused pairs kernel, from the library that is actually shipped, and the issue-time
 floor that follows from it -- the `peak` of bench.py's roofline.
 
-    python scripts/isa_mix.py [--lib ndtpso_slam_amd/lib/libndtpso_hip.so] [--kernel "k_align_pairs<0, 3, false, true, true, 0>"]
+    python scripts/isa_mix.py [--lib ndtpso_slam_amd/lib/libndtpso_hip.so] [--kernel "k_align_pairs<0, 3, false, true, true, 0, false>"]
                               [--ubench profiles/r02_ubench_valu.txt] [--out profiles/r02_isa_mix.json]
                               [--dump profiles/r02_score_loop_isa.txt]
 
@@ -183,7 +183,7 @@ def classify(mn: str) -> str:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=os.path.join(ROOT, "ndtpso_slam_amd", "lib", "libndtpso_hip.so"))
-    ap.add_argument("--kernel", default="k_align_pairs<0, 3, false, true, true, 0>")
+    ap.add_argument("--kernel", default="k_align_pairs<0, 3, false, true, true, 0, false>")
     ap.add_argument("--ubench", default=os.path.join(ROOT, "profiles", "r02_ubench_valu.txt"))
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_isa_mix.json"))
     ap.add_argument("--dump", default=os.path.join(ROOT, "profiles", "r02_score_loop_isa.txt"))

@@ -8,8 +8,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$D
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/ubench_valu.hip -o /tmp/ubench_valu 2>/dev/null && /tmp/ubench_valu > $OUT/ubench_valu.txt 2>&1
-python scripts/isa_mix.py --kernel "k_align_pairs<0, 3, false, true, true, 0>" --ubench $OUT/ubench_valu.txt --out $OUT/isa_mix.json --dump $OUT/score_loop_isa.txt > /dev/null
-python scripts/isa_mix.py --kernel "k_align_pairs<1, 9, false, false, false, 2>" --marker v_rndne_f64 --marker-span 90 --ubench $OUT/ubench_valu.txt --out $OUT/isa_mix_f64.json --dump $OUT/score_loop_isa_f64.txt > /dev/null
+python scripts/isa_mix.py --kernel "k_align_pairs<0, 3, false, true, true, 0, false>" --ubench $OUT/ubench_valu.txt --out $OUT/isa_mix.json --dump $OUT/score_loop_isa.txt > /dev/null
+python scripts/isa_mix.py --kernel "k_align_pairs<1, 9, false, false, false, 2, false>" --marker v_rndne_f64 --marker-span 90 --ubench $OUT/ubench_valu.txt --out $OUT/isa_mix_f64.json --dump $OUT/score_loop_isa_f64.txt > /dev/null
 cp $OUT/isa_mix.json profiles/r05_isa_mix.json   # the bench line's roofline.floor reads them
 cp $OUT/isa_mix_f64.json profiles/r05_isa_mix_f64.json
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err
