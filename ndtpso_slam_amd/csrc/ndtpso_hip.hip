@@ -565,7 +565,8 @@ static_assert(sizeof(BoxGuardOut) <= 24 * sizeof(int), "BoxGuardOut lives in the
 __device__ __attribute__((noinline)) void box_guard_wg(const float* __restrict__ ranges, const ScanP* sp,
                                                        const double2* __restrict__ dirs, const GridP* g, const double* guess,
                                                        const double* dev, double rc, double cx, double cy, const WinP* wn,
-                                                       int dense_cap, int clip, int* slots, BoxGuardOut* out) {
+                                                       int dense_cap, int clip, int* slots, BoxGuardOut* out,
+                                                       int metres = 0 /* fp64 score: the guard is on the translation in metres */) {
   constexpr double kMarginCells = 4.;
   const double th0 = guess[2];
   const double dth = fmin(0.1, fmax(0.02, 16. * fabs(dev[2])));
@@ -593,6 +594,15 @@ __device__ __attribute__((noinline)) void box_guard_wg(const float* __restrict__
             hy = fmin(hy, (2. * g->hh) * g->inv_cs - (double)(vy0 - 1) - ey1);
           }
           out->guard = DenseGuard{-ex0, hx, -ey0, hy};
+          if (metres) {
+            // fp64 score (score_trip_d64 under the guard: no frame, wrap or window test, and an index that is the reference's
+            // only for a point inside the frame): every point strictly inside the frame AND inside the window.  A point is at
+            // t + e, e in [ex0, ex1] cells; the bounds as the disc's guard has them (k_align_pairs), the disc's radius replaced
+            const double cs = g->cs, sl = 1e-6 * cs;
+            const double xl = fmax(-g->hw, (double)vx0 * cs - g->hw) - ex0 * cs + sl, xh = fmin(g->hw, (double)(vx0 + vw) * cs - g->hw) - ex1 * cs - sl;
+            const double yl = fmax(-g->hh, (double)vy0 * cs - g->hh) - ey0 * cs + sl, yh = fmin(g->hh, (double)(vy0 + vh) * cs - g->hh) - ey1 * cs - sl;
+            out->guard = DenseGuard{xl, xh, yl, yh};
+          }
           out->t_lo = th0 - dth;
           out->t_hi = th0 + dth;
           out->x0 = vx0;
@@ -706,7 +716,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
             guard = DenseGuard{rc, gx_hi, rc, gy_hi};
           } else if constexpr (BOX) {
             // The disc's box does not fit beside scan A's: the box of scan B's own extent under the guess's heading (box_guard_wg).
-            // BOX: the kernels the host launches when the provisioned table is much smaller than the static window (Plan::boxy) -- a
+            // BOX: the kernels the host launches when the provisioned table is less than half the static window (Plan::boxy) -- a
             // copy of their own: this branch's presence cost the benchmark's batches 2.3 % out of line and 4 % inline, the third flag 2 %
             BoxGuardOut* bo = reinterpret_cast<BoxGuardOut*>(lds_cnt(L.ctrl_off));
             box_guard_wg(new_ranges + b * sp.n_beams, &sp, beam_dirs, &g, guess + 3 * b, dev + 3 * b, rc, cx, cy, &wn, dense_cap,
@@ -752,6 +762,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
     if (rho > 0.f && fabs(cx) < 1e6 && fabs(cy) < 1e6) {
       const int bx0 = max((int)floor(cx - rc - kMarginCells), 0), bx1 = min((int)floor(cx + rc + kMarginCells), g.W - 1);
       const int by0 = max((int)floor(cy - rc - kMarginCells), 0), by1 = min((int)floor(cy + rc + kMarginCells), g.H - 1);
+      [[maybe_unused]] bool boxed = false;
       if (bx1 >= bx0 && by1 >= by0) {
         const int ux0 = min(wn.x0, bx0), uy0 = min(wn.y0, by0);
         const int uw = max(wn.x0 + wn.w - 1, bx1) - ux0 + 1, uh = max(wn.y0 + wn.h - 1, by1) - uy0 + 1;
@@ -761,12 +772,33 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
           wn.w = uw;
           wn.h = uh;
           wn.n_words = (uw * uh + 31) / 32;
+        } else if constexpr (BOX) {
+          // (the disc's box does not fit beside scan A's: scan B's own extent under the guess's heading, box_guard_wg)
+          BoxGuardOut* bo = reinterpret_cast<BoxGuardOut*>(lds_cnt(L.ctrl_off));
+          box_guard_wg(new_ranges + b * sp.n_beams, &sp, beam_dirs, &g, guess + 3 * b, dev + 3 * b, rc, cx, cy, &wn, dense_cap,
+                       dn.clip, lds_cnt(L.ctrl_off) + 24, bo, 1);
+          if (bo->ok) {
+            wn.x0 = bo->x0;
+            wn.y0 = bo->y0;
+            wn.w = bo->w;
+            wn.h = bo->h;
+            wn.n_words = (bo->w * bo->h + 31) / 32;
+            if (bo->guard.x_lo < bo->guard.x_hi && bo->guard.y_lo < bo->guard.y_hi) {
+              guard = bo->guard;
+              g_t_lo = bo->t_lo;
+              g_t_hi = bo->t_hi;
+            }
+            boxed = true;
+          }
+          __syncthreads();  // (the counters' slots are free again)
         }
       }
-      const double rr = (double)rho * (1. + 1e-9) + 1e-6 * g.cs;  // rounding of the transform included
-      const double x_lo = fmax(-g.hw, (double)wn.x0 * g.cs - g.hw) + rr, x_hi = fmin(g.hw, (double)(wn.x0 + wn.w) * g.cs - g.hw) - rr;
-      const double y_lo = fmax(-g.hh, (double)wn.y0 * g.cs - g.hh) + rr, y_hi = fmin(g.hh, (double)(wn.y0 + wn.h) * g.cs - g.hh) - rr;
-      if (x_lo < x_hi && y_lo < y_hi) guard = DenseGuard{x_lo, x_hi, y_lo, y_hi};
+      if (!boxed) {
+        const double rr = (double)rho * (1. + 1e-9) + 1e-6 * g.cs;  // rounding of the transform included
+        const double x_lo = fmax(-g.hw, (double)wn.x0 * g.cs - g.hw) + rr, x_hi = fmin(g.hw, (double)(wn.x0 + wn.w) * g.cs - g.hw) - rr;
+        const double y_lo = fmax(-g.hh, (double)wn.y0 * g.cs - g.hh) + rr, y_hi = fmin(g.hh, (double)(wn.y0 + wn.h) * g.cs - g.hh) - rr;
+        if (x_lo < x_hi && y_lo < y_hi) guard = DenseGuard{x_lo, x_hi, y_lo, y_hi};
+      }
     }
     dn.dw = wn.w + 1;
     dn.dh = wn.h + 1;
@@ -1197,8 +1229,9 @@ struct Plan {
   DenseP dn;
   int dense_cap;  // cell-table entries provisioned (fused kernel: the window is chosen per alignment)
   bool shrunk;    // ... fewer than the static window's: an alignment's box may not fit (kStatusNeedsBitmap)
-  bool boxy;      // ... fewer than 60 % of them: the box of scan B's disc will rarely fit beside scan A's -> the kernels that carry the
-                  // box guard (box_guard_wg).  (The benchmark's table is 86 % of its static window and every disc fits.)
+  bool boxy;      // ... fewer than half of them: the box of scan B's disc will rarely fit beside scan A's -> the kernels that carry the
+                  // box guard (box_guard_wg).  (The benchmark's table is 86 % of its static window and every disc fits; at 52 - 57 %
+                  // -- 361 / 541 beams, 0.3 m cells -- most discs still fit and the copies' flags cost 3 - 7 %.)
 };
 // `wn` is the staging window: final for a prebuilt table; for the fused pairs kernel (dynamic_window) it is the
 // static range box -- the worst case the bitmap form must hold -- while the dense form sizes its window per
@@ -1264,7 +1297,10 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         plan->dn = make_dense(g, wn, Ld);
         plan->dense_cap = cap;
         plan->shrunk = cap < dense_entries(full_w, full_h);
-        plan->boxy = plan->shrunk && (long)cap * 5 < (long)dense_entries(full_w, full_h) * 3;
+        plan->boxy = plan->shrunk && (long)cap * 2 < (long)dense_entries(full_w, full_h);
+        // (fp64 score: its table, next to 48-byte records, is smaller still; below a quarter of the static window not even the
+        // room's own box fits it often enough to pay for the copies' flags -- measured: 0.3 m cells + 10-13 %, 0.25 m - 3 %)
+        if (d64_ok && (long)cap * 4 < (long)dense_entries(full_w, full_h)) plan->boxy = false;
         return true;
       }
     }
@@ -1389,6 +1425,8 @@ int ndtpso_ctx_create(int device, ndtpso_ctx** out) {
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, false, false, 2, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 2, false, true, false, 2, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF32, 3, false, true, false, 2, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF64, 8, false, false, false, 2, true>);
+  if (e == hipSuccess) e = allow_big_lds(k_align_pairs<kScoreF64, 9, false, false, false, 2, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, false, true>);
   if (e == hipSuccess) e = allow_big_lds(k_align<kScoreF32, 2, true, true>);
 #define GLOBAL_PATHS(K, ...)                                                   \
@@ -2331,8 +2369,8 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   } else if (mode == NDTPSO_SCORE_F32) {
     if (byte_entries) LAUNCH_PAIRS(kScoreF32, 3); else if (plan.path == 2) LAUNCH_PAIRS(kScoreF32, 2); else if (plan.path == 1) LAUNCH_PAIRS(kScoreF32, 1); else LAUNCH_PAIRS(kScoreF32, 0);
   } else {
-    if (plan.path == 9) LAUNCH_PAIRS_CANS(kScoreF64, 9, false, false, false, 2);
-    else if (plan.path == 8) LAUNCH_PAIRS_CANS(kScoreF64, 8, false, false, false, 2);
+    if (plan.path == 9) { if (plan.boxy) LAUNCH_PAIRS_CANSB(kScoreF64, 9, false, false, false, 2, true); else LAUNCH_PAIRS_CANSB(kScoreF64, 9, false, false, false, 2, false); }
+    else if (plan.path == 8) { if (plan.boxy) LAUNCH_PAIRS_CANSB(kScoreF64, 8, false, false, false, 2, true); else LAUNCH_PAIRS_CANSB(kScoreF64, 8, false, false, false, 2, false); }
     else if (plan.path == 1) LAUNCH_PAIRS(kScoreF64, 1); else LAUNCH_PAIRS(kScoreF64, 0);
   }
 #undef LAUNCH_PAIRS

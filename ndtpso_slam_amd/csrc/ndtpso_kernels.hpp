@@ -2590,7 +2590,8 @@ __device__ inline void eval_items(const EvalCtx& E, const double2* pts, int n, c
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       if constexpr (path_is_dense64(PATH)) {  // (fp64 score on the dense table: the same guard)
         static_assert(!path_is_dense64(PATH) || MODE == kScoreF64, "PATH 8 / 9 are the fp64 score's");
-        if (*reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
+        if (BOX ? *reinterpret_cast<const unsigned*>(sw.tgd + 4 * j) == 0x01010101u
+                : *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
           cost = eval_pose_wave_d64<(PATH & 3) == 1, true>(E.g, E.dn, E.d64_tab, pts, n, c, s, tx, ty);
         else
           cost = eval_pose_wave_d64<(PATH & 3) == 1, false>(E.g, E.dn, E.d64_tab, pts, n, c, s, tx, ty);
@@ -2727,7 +2728,8 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
       const double tx = sw.tpos[j], ty = sw.tpos[S + j];
       if constexpr (path_is_dense64(PATH)) {  // (fp64 score on the dense table: the same guard)
         static_assert(!path_is_dense64(PATH) || MODE == kScoreF64, "PATH 8 / 9 are the fp64 score's");
-        if (*reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
+        if (BOX ? *reinterpret_cast<const unsigned*>(sw.tgd + 4 * j) == 0x01010101u
+                : *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u)
           cost = eval_pose_wave_d64<(PATH & 3) == 1, true>(E.g, E.dn, E.d64_tab, pts, n, c, s, tx, ty);
         else
           cost = eval_pose_wave_d64<(PATH & 3) == 1, false>(E.g, E.dn, E.d64_tab, pts, n, c, s, tx, ty);
@@ -3150,8 +3152,14 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
         sw.it[4 * slot + 1] = sn;
         if constexpr (MODE == kScoreF64 && !CLUSTER) {  // (the fp64 score's guard, in metres: score_trip_guarded)
           const double px = sw.tpos[slot], py = sw.tpos[S + slot];
-          sw.tgd[2 * slot] = (px >= sh->guard.x_lo && px < sh->guard.x_hi) ? 1 : 0;
-          sw.tgd[2 * slot + 1] = (py >= sh->guard.y_lo && py < sh->guard.y_hi) ? 1 : 0;
+          if constexpr (BOX) {  // (as the dense form's: x, y, heading, 1 -- one word per particle)
+            *reinterpret_cast<unsigned*>(sw.tgd + 4 * slot) = ((px >= sh->guard.x_lo && px < sh->guard.x_hi) ? 1u : 0u) |
+                                                              ((py >= sh->guard.y_lo && py < sh->guard.y_hi) ? 0x100u : 0u) |
+                                                              ((th >= sh->g_t_lo && th <= sh->g_t_hi) ? 0x10000u : 0u) | 0x1000000u;
+          } else {
+            sw.tgd[2 * slot] = (px >= sh->guard.x_lo && px < sh->guard.x_hi) ? 1 : 0;
+            sw.tgd[2 * slot + 1] = (py >= sh->guard.y_lo && py < sh->guard.y_hi) ? 1 : 0;
+          }
         }
       }
     }
@@ -3349,8 +3357,10 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           sw.tpos[k * S + j] = np;
           constexpr bool fold = path_is_dense(PATH) && !CLUSTER;
           if constexpr (!fold && MODE == kScoreF64 && !CLUSTER) {  // (the fp64 score's guard, in metres)
-            if (k == 0) sw.tgd[2 * j] = (np >= sh->guard.x_lo && np < sh->guard.x_hi) ? 1 : 0;
-            if (k == 1) sw.tgd[2 * j + 1] = (np >= sh->guard.y_lo && np < sh->guard.y_hi) ? 1 : 0;
+            if (k == 0) sw.tgd[(BOX ? 4 : 2) * j] = (np >= sh->guard.x_lo && np < sh->guard.x_hi) ? 1 : 0;
+            if (k == 1) sw.tgd[(BOX ? 4 : 2) * j + 1] = (np >= sh->guard.y_lo && np < sh->guard.y_hi) ? 1 : 0;
+            if constexpr (BOX)
+              if (k == 2) sw.tgd[4 * j + 2] = (np >= sh->g_t_lo && np <= sh->g_t_hi) ? 1 : 0;
           }
           if constexpr (fold) {  // each coordinate's share of the proposal's DenseItem (dense_item)
             if (k == 0) {

@@ -75,13 +75,15 @@ def main():
                     for _ in range(3):
                         launch()
                     torch.cuda.synchronize()
-                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    a.record(stream)
-                    for _ in range(args.launches):
+                    # (the median of the launches' own times: one launch in a few hundred takes half as long again -- a host
+                    # hiccup, a clock step -- and used to decide a whole row)
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.launches + 1)]
+                    ev[0].record(stream)
+                    for q in range(args.launches):
                         launch()
-                    b.record(stream)
+                        ev[q + 1].record(stream)
                     torch.cuda.synchronize()
-                    ms = a.elapsed_time(b) / args.launches
+                    ms = float(np.median([ev[q].elapsed_time(ev[q + 1]) for q in range(args.launches)]))
                     st = d_stats.cpu().numpy().view(capi.STATS_DTYPE).reshape(B)
                     pose = d_pose.cpu().numpy()
                     E = 1 + P + P * I
@@ -93,7 +95,7 @@ def main():
                                      table_form=plan.get("table_form"), lds_bytes=plan.get("lds_bytes"), workgroups_per_cu=plan.get("workgroups_per_cu"),
                                      max_abs_dpose_vs_oracle=float(np.abs(pose[:k] - want).max())))
                     print(json.dumps(rows[-1]), flush=True)
-    out = {"what": "fused pairs kernel, %d pairs x (70 particles x 70 iterations), one launch at a time (HIP events, %d launches); "
+    out = {"what": "fused pairs kernel, %d pairs x (70 particles x 70 iterations), one launch at a time (HIP events, median of %d launches); "
                    "rel = point evaluations per second relative to the benchmark shape's (1081 beams, 0.5 m cells, 60 m frame) in the same mode"
                    % (B, args.launches), "rows": rows}
     for mname in args.modes.split(","):
