@@ -163,7 +163,10 @@ def main():
     if args.settle_ms > 0:
         t_s = time.perf_counter()
         while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
-            run_steps(4)
+            for k in range(4):   # (launches only: how many fit in the time differs from rank to rank, a collective here would hang)
+                launch(k)
+            if depth > 1:
+                ctx.pipeline_flush(0)
             torch.cuda.synchronize()
             settle_launches += 4
     run_steps(args.warmup)
