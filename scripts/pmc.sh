@@ -4,7 +4,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-latency $@"
+CMD="python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --settle-ms 0 --cpu-sample 0 --no-latency $@"   # (counters do not depend on the clocks: no settle launches)
 rocprofv3 -L > $OUT/counters.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 20 --cpu-sample 0 --no-latency $@ > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $OUT/p1 -o p -- $CMD > $OUT/p1.log 2>&1
