@@ -68,7 +68,24 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=512, help="pairs of this step timed on the host oracle (0 = skip the CPU baseline)")
     ap.add_argument("--no-latency", action="store_true", help="skip the extras (other score modes, config 5, latency, live sequence)")
     ap.add_argument("--identical", action="store_true", help="diagnostic: replicate pair 0 (no load imbalance)")
+    ap.add_argument("--sharded-capi", action="store_true",
+                    help="ONE process driving --gpus N devices through the C-ABI's ndtpso_align_pairs_sharded_dev (a host thread, "
+                         "context and stream per device, ncclCommInitAll, one ncclAllGather per step) instead of one process per GPU")
     args = ap.parse_args()
+
+    # How this process was started decides what it is (launch_plan): a rank of a launcher's group, the parent that has to
+    # start the group itself, the one process of --sharded-capi -- or a mistake, which ends here with a reason and exit code 2:
+    # a run that asks for N GPUs never prints a number measured on fewer.
+    import torch
+    kind, detail = launch_plan(args.gpus, args.sharded_capi, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0,
+                               sys.argv[1:])
+    if kind == "fail":
+        print("bench.py: " + detail, file=sys.stderr, flush=True)
+        raise SystemExit(2)
+    if kind == "relaunch":
+        print("bench.py: --gpus %d without a launcher: starting %s" % (args.gpus, " ".join(detail)), file=sys.stderr, flush=True)
+        os.environ["NDTPSO_BENCH_SELF_LAUNCHED"] = "1"
+        os.execv(detail[0], detail)
 
     # stdout carries exactly one line, the JSON result: everything else that may print there on the way (RCCL's
     # version banner, device-side printf of diagnostic builds) is sent to stderr at the file-descriptor level
@@ -76,8 +93,12 @@ def main():
     stdout_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
     import torch.distributed as dist
+
+    if kind == "sharded":
+        out = _main_sharded(args, torch)
+        _print_result(out, stdout_fd)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,6 +180,37 @@ def main():
     # 4-7 % slower than the steady state (measured: --steps 20 --warmup 5 read 232 k align/s one at a time where --steps 200
     # read 250 k, same box, same minute).  The same launches, untimed, for --settle-ms of wall time before the warm-up steps;
     # the timed region below is still exactly `steps` steps.  --settle-ms 0 switches it off.
+    # Before it, once: what rounds 1-4 measured -- `warmup` + `steps` launches at the configured depth straight after start-up,
+    # then min(steps, 60) one at a time -- so that the driver's line stays comparable across rounds (extra.without_clock_settle).
+    cold = None
+    if args.settle_ms > 0 and world == 1:
+        cold = {}
+        for k in range(args.warmup):
+            launch(k)
+        if depth > 1:
+            ctx.pipeline_flush(0)
+        torch.cuda.synchronize()
+        t_c = time.perf_counter()
+        for k in range(args.steps):
+            launch(k)
+        if depth > 1:
+            ctx.pipeline_flush(0)
+        torch.cuda.synchronize()
+        cold["alignments_per_s_at_depth_%d" % depth] = B * args.steps / (time.perf_counter() - t_c)
+        ctx.set_pipeline_depth(1)
+        for k in range(2):
+            launch(0)
+        torch.cuda.synchronize()
+        nc = max(1, min(args.steps, 60))
+        t_c = time.perf_counter()
+        for k in range(nc):
+            launch(0)
+        torch.cuda.synchronize()
+        cold["alignments_per_s_one_at_a_time"] = B * nc / (time.perf_counter() - t_c)
+        cold["untimed_launches_before"] = args.warmup
+        cold["note"] = "the procedure of rounds 1-4: warmup + steps launches right after start-up, no clock settle; then one at a time"
+        ctx.set_pipeline_depth(depth)
+    cold_launches = (args.warmup + args.steps + 2 + max(1, min(args.steps, 60))) if cold is not None else 0
     settle_launches = 0
     if args.settle_ms > 0:
         t_s = time.perf_counter()
@@ -240,6 +292,9 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            # every launch this process issued before the timed region: the cold measurement of extra.without_clock_settle, the
+            # clock settle (--settle-ms of wall time) and the `warmup` steps
+            "untimed_launches_total": cold_launches + settle_launches + args.warmup,
             "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "value_one_batch_at_a_time": B * world / (serial_ms * 1e-3) if world == 1 else None,
             "higher_is_better": True,
@@ -269,6 +324,7 @@ def main():
                 "n_points_min_max": [int(stats["n_points"].min()), int(stats["n_points"].max())],
                 "comparisons_arbitrated_in_f64_per_alignment": float(stats["arbitrated"].mean()),
                 "clock_settle": {"ms": args.settle_ms, "untimed_launches_before_the_warmup_steps": settle_launches},
+                "without_clock_settle": cold,
                 "exact_mode_start_up_check": exact_check,   # state 1: passed (ndtpso_exact_check; before the warm-up)
                 "timed_region_s": elapsed,
                 "batches_in_flight": {
@@ -378,9 +434,45 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
 
+    # Did RCCL see N ranks?  Answerable from the record: a real all_gather of the rank numbers (ranks_seen), the gathered
+    # poses held against every rank's own (block r of the gather == rank r's poses, checked by rank r, AND over ranks), the
+    # library's version, and the median duration of the step's one collective by events on the launch stream.
+    if use_dist:
+        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
+        ranks_seen = len({int(t.item()) for t in ids})
+        mine = outs[(args.steps - 1) & 1][0] if depth > 1 and args.steps > 0 else outs[0][0]
+        allp = sharding.gather_poses(mine, equal_sizes=True, force=True)
+        own = torch.tensor([1 if torch.equal(allp[rank * B:(rank + 1) * B], mine) and allp.shape[0] == world * B else 0], device=dev)
+        dist.all_reduce(own, op=dist.ReduceOp.MIN)
+        g_us = []
+        for _ in range(25):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            sharding.gather_poses(mine, equal_sizes=True, force=True)
+            b.record(stream)
+            torch.cuda.synchronize()
+            g_us.append(1e3 * a.elapsed_time(b))
+        if rank == 0:
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                ver = None
+            out["rccl"] = {"ranks_seen": ranks_seen, "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "version": ver, "gather_us_median": float(np.median(g_us[5:])),
+                           "gather_bytes_per_rank": int(B * 24), "every_rank_found_its_poses_in_the_gather": bool(int(own.item())),
+                           "launch": "one process per GPU (torch.distributed), %s" % ("started by bench.py itself" if os.environ.get("NDTPSO_BENCH_SELF_LAUNCHED") == "1" else "started by a launcher")}
+            assert ranks_seen == world == args.gpus, (ranks_seen, world, args.gpus)
+    elif rank == 0:
+        out["rccl"] = None   # one rank, no process group: nothing was gathered (NDTPSO_BENCH_FORCE_DIST=1 takes the RCCL path anyway)
+
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    _print_result(out if rank == 0 else None, stdout_fd)
+
+
+def _print_result(out, stdout_fd):
     sys.stdout.flush()
     try:  # libc's own stdout buffer (native libraries printf into it) must drain while fd 1 still points at stderr
         import ctypes
@@ -389,8 +481,168 @@ def main():
         pass
     os.dup2(stdout_fd, 1)
     os.close(stdout_fd)
-    if rank == 0:
+    if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return int(so.getsockname()[1])
+
+
+def relaunch_command(argv, n_gpus, port=None):
+    """What `bench.py --gpus N` (N > 1) started WITHOUT a launcher executes in its own place: the launcher line of the
+    task's contract, one rank per GPU over RCCL, rendezvous on 127.0.0.1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n_gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port) if port else _free_port()),
+            os.path.abspath(__file__)] + list(argv)
+
+
+def launch_plan(gpus, sharded, environ, n_devices, argv):
+    """-> (kind, detail).  kind: 'run' (this process is a rank -- or the only one), 'relaunch' (detail = the command to exec),
+    'sharded' (the one process of --sharded-capi), 'fail' (detail = the reason; the caller exits with code 2).
+    Rules: --gpus N must be what runs.  WORLD_SIZE set (a launcher started us): it must equal N, and LOCAL_RANK must name a
+    visible device.  WORLD_SIZE unset and N > 1: N devices must be visible and this process re-executes itself under
+    python -m torch.distributed.run.  --sharded-capi: one process, N devices visible -- unless NDTPSO_SHARD_VIRTUAL=N (the
+    shard group's test mode: N shards on the visible devices, gather staged through the host; flagged in the result)."""
+    if gpus < 1:
+        return "fail", "--gpus %d: at least one" % gpus
+    ws = environ.get("WORLD_SIZE")
+    if sharded:
+        if ws is not None and int(ws) != 1:
+            return "fail", "--sharded-capi is ONE process for all devices; started under a launcher with WORLD_SIZE=%s" % ws
+        virt = int(environ.get("NDTPSO_SHARD_VIRTUAL") or 0)
+        if virt and virt != gpus:
+            return "fail", "NDTPSO_SHARD_VIRTUAL=%d but --gpus %d" % (virt, gpus)
+        if n_devices < (1 if virt else gpus):
+            return "fail", "--sharded-capi --gpus %d but %d HIP device(s) visible" % (gpus, n_devices)
+        return "sharded", None
+    if ws is None:
+        if n_devices < gpus:
+            return "fail", "--gpus %d but %d HIP device(s) visible" % (gpus, n_devices)
+        if gpus == 1 and environ.get("NDTPSO_BENCH_FORCE_DIST") != "1":
+            return "run", None
+        # (NDTPSO_BENCH_FORCE_DIST=1 with --gpus 1: the same re-execution with one rank -- a one-GPU box runs the very path, exec
+        # included, that `--gpus 8` takes)
+        return "relaunch", relaunch_command(argv, gpus)
+    if int(ws) != gpus:
+        return "fail", "started with WORLD_SIZE=%s but --gpus %d: refusing to report a number for another number of GPUs" % (ws, gpus)
+    lr = int(environ.get("LOCAL_RANK", "0"))
+    if lr >= n_devices:
+        return "fail", "LOCAL_RANK=%d but %d HIP device(s) visible" % (lr, n_devices)
+    return "run", None
+
+
+def _main_sharded(args, torch):
+    """--sharded-capi: the SECOND launch convention for N GPUs.  ONE process; ndtpso_shard_group_create(devices 0 .. N-1)
+    (ncclCommInitAll inside the library, RCCL dlopen'ed), every device's shard of the weak-scaling workload (B pairs per
+    device, the same pairs the per-process ranks would hold) resident on its device, and one step =
+    ndtpso_align_pairs_sharded_dev: a host thread per device launches its shard, ONE ncclAllGather of pose + cost, every
+    stream waited for.  One batch at a time per device by construction (the call returns with the devices idle), so its
+    figure sits below the per-process path's two-in-flight `value`; no torch.distributed anywhere."""
+    from ndtpso_slam_amd import capi, sharding, synth
+    G, B, P, I = args.gpus, args.pairs, args.particles, args.iterations
+    mode = {"f32": capi.SCORE_F32, "f64": capi.SCORE_F64, "exact": capi.SCORE_EXACT}[args.score]
+    virt = int(os.environ.get("NDTPSO_SHARD_VIRTUAL") or 0)
+    n_dev = torch.cuda.device_count()
+    devices = list(range(min(n_dev, G))) if virt else list(range(G))
+    grp = capi.ShardGroup(devices)
+    info = grp.describe()
+    assert info["n_shards"] == G, info
+    geom = capi.ScanGeom(synth.N_BEAMS, float(synth.ANGLE_MIN), float(synth.ANGLE_INC), float(synth.RANGE_MAX), 0.1)
+    grid = capi.Grid(FRAME_M, FRAME_M, CELL_SIDE)
+    cfg = capi.PSOConfig.make(I, P)
+    keep, ptrs = [], {k: [] for k in ("ref", "new", "guess", "dev", "seeds")}
+    n_valid_total = 0
+    for r in range(G):
+        a, b = sharding.shard_range(G * B, r, G)
+        pr = synth.make_pairs(b - a, seed=2024, first_pair=a, total_pairs=G * B)
+        td = torch.device("cuda", info["devices"][r])
+        t = {"ref": torch.from_numpy(pr.ref_ranges).to(td), "new": torch.from_numpy(pr.new_ranges).to(td),
+             "guess": torch.zeros(b - a, 3, dtype=torch.float64, device=td),
+             "dev": torch.tensor(DEVIATION, dtype=torch.float64, device=td).repeat(b - a, 1).contiguous(),
+             "seeds": torch.from_numpy(pr.seeds.astype(np.int64)).to(td).to(torch.int32)}
+        keep.append(t)
+        for k in ptrs:
+            ptrs[k].append(t[k].data_ptr())
+        torch.cuda.synchronize(td)
+
+    def step(fetch=False):
+        return grp.align_pairs_dev(G * B, ptrs["ref"], ptrs["new"], geom, grid, ptrs["guess"], ptrs["dev"], cfg,
+                                   d_seeds=ptrs["seeds"], mode=mode, fetch=fetch)
+
+    settle = 0
+    t_s = time.perf_counter()
+    while args.settle_ms > 0 and (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+        step()
+        settle += 1
+    for _ in range(args.warmup):
+        step()
+    g_us, per_call = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        g_us.append(grp.last_gather_device_us())
+        per_call.append(grp.last_timing()[1].copy())
+    elapsed = time.perf_counter() - t0     # (every call returns with all the devices synchronised)
+    ranks_seen = grp.verify_gather()
+    pose, cost, stats = step(fetch=True)
+    per, _ = grp.last_timing()
+    assert (stats["status"] == 0).all(), "alignments flagged: %d" % int((stats["status"] != 0).sum())
+    assert ranks_seen == G, "the gather moved %d of %d shards' poses" % (ranks_seen, G)
+    # the same poses as the one-device entry on shard 0's pairs (bit for bit: the partition changes nothing)
+    c0 = capi.Context(info["devices"][0])
+    p0 = synth.make_pairs(B, seed=2024, first_pair=0, total_pairs=G * B)
+    want, _, _ = c0.align_pairs(p0.ref_ranges, p0.new_ranges, geom, grid, (0, 0, 0), DEVIATION, cfg, seeds=p0.seeds, mode=mode)
+    c0.close()
+    same = bool(np.array_equal(want, pose[:B]))
+    n_valid = stats["n_points"].astype(np.float64)
+    evals_nominal = 1 + P + P * I
+    step_ms = 1e3 * elapsed / max(args.steps, 1)
+    physical = len(set(info["devices"]))
+    flops = float(n_valid.sum()) / G * evals_nominal * (FLOP_FP64 + FLOP_FP32 + FLOP_EXP) if args.score != "f64" else float(n_valid.sum()) / G * evals_nominal * 51.
+    t_peak_s = (float(n_valid.sum()) / G * evals_nominal * (51. / (VEC_FP64_TFLOPS * 1e12)) if args.score == "f64" else
+                float(n_valid.sum()) / G * evals_nominal * (FLOP_FP64 / (VEC_FP64_TFLOPS * 1e12) + (FLOP_FP32 + FLOP_EXP) / (VEC_FP32_TFLOPS * 1e12)))
+    calls = np.array(per_call) if per_call else np.zeros((1, 3))
+    grp.close()
+    return {
+        "metric": "scan alignments/sec (1081-beam, 70 particles x 70 iters)",
+        "value": G * B * args.steps / elapsed, "unit": "alignments/s",
+        "n_gpus": physical, "steps": args.steps, "warmup": args.warmup, "untimed_launches_total": settle + args.warmup,
+        "ms_per_step": step_ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"exact": "f64 transform/index + f32 score, undecidable comparisons arbitrated in f64 (= the f64 mode's poses)",
+                  "f32": "f64 transform/index + f32 score", "f64": "f64"}[args.score],
+        "data": "synthetic",
+        "config": {"workload": "BASELINE config 3/4: %d scan pairs per device per step over %d shard(s), %d beams, %.2f m cells, %d m frame, "
+                               "PSO %d particles x %d iterations, exact reference order + srand(seed) stream"
+                               % (B, G, synth.N_BEAMS, CELL_SIDE, FRAME_M, P, I),
+                   "pairs_per_gpu": B, "particles": P, "iterations": I, "score": args.score, "batches_in_flight": 1,
+                   "parallelism": "ONE process, ndtpso_align_pairs_sharded_dev: a host thread + context + stream per shard, pairs by "
+                                  "contiguous index range, ONE gather of pose + cost per step (%s)" % info["gather"],
+                   "shards": G, "shard_devices": info["devices"],
+                   "test_mode": ("NDTPSO_SHARD_VIRTUAL=%d: %d shards share %d physical device(s) and the gather is staged through the "
+                                 "host -- plumbing only, NOT a multi-GPU measurement" % (virt, G, physical)) if virt else None},
+        "rccl": {"ranks_seen": ranks_seen, "world_size": G, "comm_ranks": info["comm_ranks"], "version": info["rccl_version"],
+                 "gather": info["gather"], "gather_us_median": float(np.median(g_us)) if g_us else None,
+                 "gather_us_what": "events on shard 0's stream: end of its own launch -> end of its share of the collective (the wait "
+                                   "for the slowest shard included)",
+                 "gather_bytes_per_rank": int(B * 32), "every_rank_found_its_poses_in_the_gather": ranks_seen == G,
+                 "launch": "one process (--sharded-capi), ncclCommInitAll"},
+        "roofline": {"bound": "valu", "achieved": flops / (step_ms * 1e-3) / 1e12, "peak": flops / t_peak_s / 1e12, "unit": "TFLOP/s",
+                     "frac": t_peak_s * 1e3 / step_ms, "traffic": _pmc_traffic_bytes(args.score == "f64"),
+                     "regime": "per device: flop floor of one shard's launch / ms_per_step of the sharded call (host dispatch, the launch, "
+                               "the gather and the final synchronisation of every device included; one batch at a time)",
+                     "kernel": "k_align_pairs (fused scan ingest + cell statistics + PSO)", "kernel_ms": None},
+        "cpu_baseline": None,
+        "extra": {"shard0_poses_equal_ndtpso_align_pairs": same, "status_nonzero": int((stats["status"] != 0).sum()),
+                  "host_us_median": {"until_every_shard_was_enqueued": float(np.median(calls[:, 0])),
+                                     "collective_enqueue": float(np.median(calls[:, 1])), "call": float(np.median(calls[:, 2]))},
+                  "per_shard_host_us_last_call": {"start_after_entry": per[:, 0].tolist(), "uploads": per[:, 1].tolist(),
+                                                  "launches": per[:, 2].tolist()},
+                  "clock_settle": {"ms": args.settle_ms, "untimed_calls": settle}, "timed_region_s": elapsed},
+    }
 
 
 def _live_sequence(ctx, capi, synth, mode, n_scans=60):
@@ -577,17 +829,74 @@ def _pmc_traffic_bytes(f64=False):
     return None
 
 
+def _host_cpu_limits():
+    """What this process may actually use of the box's CPUs: logical CPUs, the affinity mask, the cgroup's quota, OpenMP's
+    environment, the load other tenants put on the box."""
+    d = {"logical_cpus": os.cpu_count() or 1, "cpu_model": _cpu_model()}
+    try:
+        d["affinity_cpus"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        d["affinity_cpus"] = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                d["cgroup_cpu_max"] = " ".join(txt)
+                if txt and txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    per = float(f.read().split()[0])
+                d["cgroup_cfs_quota_us"] = q
+                if q > 0:
+                    quota = q / per
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    d["cgroup_quota_cpus"] = quota
+    d["OMP_NUM_THREADS"] = os.environ.get("OMP_NUM_THREADS")
+    try:
+        with open("/proc/loadavg") as f:
+            d["loadavg_1min"] = float(f.read().split()[0])
+    except (OSError, ValueError):
+        d["loadavg_1min"] = None
+    try:   # physical cores: distinct (package, core) pairs
+        cores, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        d["physical_cores"] = len(cores) or None
+    except OSError:
+        d["physical_cores"] = None
+    return d
+
+
 def _cpu_baseline(pairs, S, P, I):
     """the repo's fp64 CPU restatement of the reference (oracle/ndtpso_oracle.c, `kind: "port"` -- the
     reference itself cannot be built in this image) on the GPU box's host cores:
-      c1  one scan pair (BASELINE config 1) in the reference's own parallel shape -- OpenMP over the particles of an
-          iteration, live rand(), racy gbest (core.cpp:72-109) -- median of 21 alignments, at 1, 8 and all threads
-          (the reference's default is all: num_threads = -1, config.h:30);
-      c3  all S pairs of this step, sequential alignments parallelised over pairs on all threads (the fairest CPU
-          figure: no synchronisation at all), best of two passes; this is `value`."""
+      c1       one scan pair (BASELINE config 1) in the reference's own parallel shape -- OpenMP over the particles of an
+               iteration, live rand(), racy gbest (core.cpp:72-109) -- median of 11 alignments, at 1, 8 and all threads
+               (the reference's default is all: num_threads = -1, config.h:30);
+      scaling  sequential alignments parallelised over PAIRS (no synchronisation at all: the fairest CPU figure) at
+               1, 2, 4, ... threads up to what the process may use, on 4 pairs per thread (16 ... S);
+      value    the best rate over all S pairs of this step; `cores` = the FEWEST threads that reach 90 % of the best rate
+               of the curve -- the cores the box really gives this process, whatever the number of logical CPUs it shows --,
+               and `efficiency` = value / (cores x the one-thread rate)."""
     from oracle import pyoracle
     ocfg = pyoracle.PSOConfig.make(I, P)
-    nproc = os.cpu_count() or 1
+    host = _host_cpu_limits()
+    nproc = host["logical_cpus"]
+    usable = host["affinity_cpus"] or nproc
     ref = pyoracle.Frame((0, 0, 0), FRAME_M, FRAME_M, CELL_SIDE)
     ref.load_laser(pairs.ref_ranges[0], pairs.angle_min, pairs.angle_inc, pairs.range_max)
     new = pyoracle.Frame((0, 0, 0), FRAME_M, FRAME_M, float(FRAME_M))
@@ -596,27 +905,59 @@ def _cpu_baseline(pairs, S, P, I):
     c1 = {}
     for label, nt in (("1_thread", 1), ("8_threads", 8), ("all_threads", 0)):
         ts = []
-        for _ in range(21):
+        for _ in range(11):
             t1 = time.perf_counter()
             ref.pso_omp((0, 0, 0), new, DEVIATION, ocfg, n_threads=nt)
             ts.append(time.perf_counter() - t1)
         c1[label] = {"alignments_per_s": 1.0 / float(np.median(ts)), "median_ms": 1e3 * float(np.median(ts)),
                      "threads": nt if nt else nproc, "runs": len(ts)}
-    best, used, opose = None, 1, None
-    for _ in range(2):
+
+    def run(n_pairs, threads):
         t1 = time.perf_counter()
-        opose, _, used = pyoracle.align_pairs(pairs.ref_ranges[:S], pairs.new_ranges[:S], pairs.angle_min, pairs.angle_inc,
-                                              pairs.range_max, 0.1, FRAME_M, FRAME_M, CELL_SIDE, (0, 0, 0), DEVIATION, ocfg,
-                                              pairs.seeds[:S], n_threads=0)
-        dt = time.perf_counter() - t1
-        best = dt if best is None else min(best, dt)
+        po, _, used = pyoracle.align_pairs(pairs.ref_ranges[:n_pairs], pairs.new_ranges[:n_pairs], pairs.angle_min, pairs.angle_inc,
+                                           pairs.range_max, 0.1, FRAME_M, FRAME_M, CELL_SIDE, (0, 0, 0), DEVIATION, ocfg,
+                                           pairs.seeds[:n_pairs], n_threads=threads)
+        return n_pairs / (time.perf_counter() - t1), po, int(used)
+
+    curve, t = [], 1
+    while True:
+        n = int(min(S, max(16, 4 * t)))
+        rate, _, used = run(n, t)
+        curve.append([used, rate, n])
+        if t >= usable:
+            break
+        t = min(2 * t, usable)
+    one = curve[0][1]
+    best_curve = max(r for _, r, _ in curve)
+    cores = min(u for u, r, _ in curve if r >= 0.9 * best_curve)
+    t_best = max(curve, key=lambda c: c[1])[0]
+    best, opose = None, None
+    for _ in range(2):
+        rate, opose, used = run(S, t_best)
+        best = rate if best is None else max(best, rate)
+    eff = best / (cores * one)
+    why = []
+    if host["cgroup_quota_cpus"]:
+        why.append("cgroup CPU quota of %.1f CPUs" % host["cgroup_quota_cpus"])
+    if host["affinity_cpus"] and host["affinity_cpus"] < nproc:
+        why.append("affinity mask of %d of %d logical CPUs" % (host["affinity_cpus"], nproc))
+    if host["loadavg_1min"] is not None and host["loadavg_1min"] > 0.25 * nproc:
+        why.append("1-minute load average %.0f on %d logical CPUs (other tenants)" % (host["loadavg_1min"], nproc))
+    if not why:
+        why.append("no quota, mask or foreign load visible from inside the container: the curve itself is the evidence (SMT siblings, "
+                   "all-core clocks and memory bandwidth shared with the box's other tenants)")
     return {
-        "value": S / best, "unit": "alignments/s", "cores": int(used), "kind": "port",
-        "sample": "all %d scan pairs of this step (BASELINE config 3), sequential alignments of oracle/ndtpso_oracle.c parallelised "
-                  "over pairs, %d OpenMP threads, best of 2 passes; %s, %d logical CPUs" % (S, used, _cpu_model(), nproc),
-        "seconds": best,
+        "value": best, "unit": "alignments/s", "cores": int(cores), "kind": "port",
+        "sample": "all %d scan pairs of this step (BASELINE config 3), sequential alignments of oracle/ndtpso_oracle.c parallelised over "
+                  "pairs on %d OpenMP threads (the best of the scaling curve), best of 2 passes; `cores` = %d: the fewest threads that "
+                  "reach 90 %% of the curve's best rate (%s); %s, %d logical CPUs" % (S, t_best, cores, "; ".join(why), host["cpu_model"], nproc),
+        "seconds": S / best, "threads_of_value": int(t_best),
+        "one_thread_alignments_per_s": one,
+        "efficiency": eff, "efficiency_what": "value / (cores x one-thread rate)",
+        "scaling": [[int(u), float(r)] for u, r, _ in curve], "scaling_pairs": [int(n) for _, _, n in curve],
+        "host": host,
         "c1_single_pair_omp_over_particles": c1,
-        "c3_pairs": S, "nproc": nproc, "cpu_model": _cpu_model(),
+        "c3_pairs": S, "nproc": nproc, "cpu_model": host["cpu_model"],
         "_poses": opose,
     }
 

@@ -368,7 +368,26 @@ int ndtpso_align_pairs_sharded_dev(ndtpso_shard_group *group, uint32_t n_pairs, 
                                    ndtpso_align_stats *stats);
 int ndtpso_shard_last_timing(const ndtpso_shard_group *group, double *per_device /* [G][3] or NULL */,
                              double *call /* [3] or NULL */);
+/* the last call's collective on shard 0's stream, by device events: from the end of shard 0's own launch to the end of its
+ * share of the gather (the wait for the slowest shard included); microseconds, 0 if the call failed */
+double ndtpso_shard_last_gather_device_us(const ndtpso_shard_group *group);
 const double *ndtpso_shard_gathered(const ndtpso_shard_group *group, int index);
+/* What the group is, for a caller's record: how many shards, over what the poses are gathered, which RCCL, how many ranks
+ * its communicator holds.  gather_kind 0: ONE ncclAllGather over RCCL (the product path); 1: staged through the host -- the
+ * TEST mode NDTPSO_SHARD_VIRTUAL=G in the environment, in which a group has G shards whatever the length of the device
+ * list (shard i on devices[i mod n], a context, stream and host thread each) so that a box with one device can run the
+ * partition, the thread-per-shard scatter and the error paths of a G-device call; never a measurement of the collective.
+ * ndtpso_shard_verify_gather (after a successful call): the number of shards whose send block is found bit for bit in
+ * EVERY shard's gathered copy, i.e. the ranks the collective has demonstrably moved; G when all is well. */
+typedef struct {
+  int32_t n_shards;
+  int32_t gather_kind;   /* 0 RCCL ncclAllGather, 1 host-staged (test mode) */
+  int32_t rccl_version;  /* ncclGetVersion's code, 0 if RCCL is not loaded */
+  int32_t comm_ranks;    /* ncclCommCount of the group's communicator, 0 in the test mode */
+  int32_t devices[64];   /* device of shard i */
+} ndtpso_shard_info;
+int ndtpso_shard_group_describe(const ndtpso_shard_group *group, ndtpso_shard_info *out);
+int ndtpso_shard_verify_gather(ndtpso_shard_group *group, int *ranks_seen);
 
 /* ---- probes of the device arithmetic the parity claims rest on (tests/test_gpu_exp.py) --------------------------
  * NDTCell::normalDistribution ends in exp() (ndtcell.cpp:76) and transform_point takes the cosine and sine of the pose's

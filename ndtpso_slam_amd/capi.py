@@ -83,6 +83,12 @@ class PairsPlan(C.Structure):
                 ("window_h", C.c_uint32), ("table_bytes", C.c_uint32)]
 
 
+class ShardInfo(C.Structure):
+    """ndtpso_shard_info (include/ndtpso_hip.h)"""
+    _fields_ = [("n_shards", C.c_int32), ("gather_kind", C.c_int32), ("rccl_version", C.c_int32), ("comm_ranks", C.c_int32),
+                ("devices", C.c_int32 * 64)]
+
+
 class MapInfo(C.Structure):
     _fields_ = [("n_created", C.c_uint32), ("n_built", C.c_uint32), ("status", C.c_uint32), ("n_words", C.c_uint32),
                 ("x0", C.c_int32), ("x1", C.c_int32), ("y0", C.c_int32), ("y1", C.c_int32),
@@ -108,7 +114,8 @@ EXPORTS = [
     "ndtpso_map_get_occupancy",
     "ndtpso_shard_group_create", "ndtpso_shard_group_destroy", "ndtpso_shard_group_size", "ndtpso_shard_last_error",
     "ndtpso_shard_range", "ndtpso_align_pairs_sharded", "ndtpso_align_pairs_sharded_dev", "ndtpso_shard_last_timing",
-    "ndtpso_shard_gathered",
+    "ndtpso_shard_gathered", "ndtpso_shard_group_describe", "ndtpso_shard_verify_gather",
+    "ndtpso_shard_last_gather_device_us",
     "ndtpso_selftest_exp", "ndtpso_device_math", "ndtpso_exact_check",
 ]
 
@@ -204,12 +211,16 @@ def load(build_if_missing: bool = True):
                                                  C.POINTER(PSOConfig), pp, pp, C.c_int, dp, dp, vp]
     L.ndtpso_shard_last_timing.argtypes = [vp, dp, dp]
     L.ndtpso_shard_gathered.argtypes = [vp, C.c_int]
+    L.ndtpso_shard_group_describe.argtypes = [vp, C.POINTER(ShardInfo)]
+    L.ndtpso_shard_verify_gather.argtypes = [vp, C.POINTER(C.c_int)]
+    L.ndtpso_shard_last_gather_device_us.argtypes = [vp]
+    L.ndtpso_shard_last_gather_device_us.restype = C.c_double
     L.ndtpso_shard_gathered.restype = C.c_void_p
     for name in EXPORTS:
         fn = getattr(L, name)
         if name not in ("ndtpso_ctx_destroy", "ndtpso_last_error", "ndtpso_rand_draws", "ndtpso_points_destroy",
                         "ndtpso_map_destroy", "ndtpso_shard_group_destroy", "ndtpso_shard_last_error", "ndtpso_shard_range",
-                        "ndtpso_shard_gathered"):
+                        "ndtpso_shard_gathered", "ndtpso_shard_last_gather_device_us"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -491,6 +502,28 @@ class ShardGroup:
         if rc != OK:
             raise NdtpsoError(rc, self._lib.ndtpso_shard_last_error(self._h).decode())
         return (pose, cost, stats) if fetch else (None, None, stats)
+
+    def describe(self) -> dict:
+        """ndtpso_shard_group_describe: shards, how the poses are gathered, RCCL's version, ranks of the communicator."""
+        info = ShardInfo()
+        rc = self._lib.ndtpso_shard_group_describe(self._h, C.byref(info))
+        if rc != OK:
+            raise NdtpsoError(rc, "ndtpso_shard_group_describe")
+        v = int(info.rccl_version)
+        return {"n_shards": int(info.n_shards), "gather": "host-staged (test)" if info.gather_kind else "ncclAllGather (RCCL)",
+                "rccl_version_code": v, "rccl_version": "%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v else None,
+                "comm_ranks": int(info.comm_ranks), "devices": [int(info.devices[i]) for i in range(int(info.n_shards))]}
+
+    def verify_gather(self) -> int:
+        """ndtpso_shard_verify_gather: shards whose poses every shard's gathered copy holds bit for bit (after a call)."""
+        n = C.c_int(0)
+        rc = self._lib.ndtpso_shard_verify_gather(self._h, C.byref(n))
+        if rc != OK:
+            raise NdtpsoError(rc, self._lib.ndtpso_shard_last_error(self._h).decode())
+        return int(n.value)
+
+    def last_gather_device_us(self) -> float:
+        return float(self._lib.ndtpso_shard_last_gather_device_us(self._h))
 
     def gathered(self, index: int) -> int:
         """Device pointer of device `index`'s copy of the gathered batch (G blocks of [pose M x 3 | cost M])."""

@@ -160,6 +160,26 @@ def test_bench_multi_rank_path_under_torch_distributed_run(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 10 and d["value"] > 1e4 and d["scaling"] == "weak"
     assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
+    assert d["rccl"]["ranks_seen"] == 1 and d["rccl"]["backend"] == "nccl" and d["rccl"]["every_rank_found_its_poses_in_the_gather"]
+    assert d["rccl"]["gather_us_median"] > 0 and "launcher" in d["rccl"]["launch"]
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks_when_no_launcher_did():
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run around it (how the driver starts the N = 1 line): for N > 1 it
+    re-executes itself under the launcher.  On the one-GPU box NDTPSO_BENCH_FORCE_DIST=1 sends --gpus 1 down the same road --
+    the exec, the rendezvous on 127.0.0.1, a process group of one rank over RCCL, the all_gather every step."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(NDTPSO_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "10", "--warmup", "3", "--cpu-sample", "0",
+                        "--no-latency"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "without a launcher: starting" in r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["rccl"]["ranks_seen"] == 1 and "bench.py itself" in d["rccl"]["launch"]
 
 
 # ---- one process, several devices: the C-ABI's sharded entry point (ndtpso_align_pairs_sharded) --------------------
@@ -313,3 +333,165 @@ def test_cpp_batch_driver_refuses_to_run_without_a_device(tmp_path):
     r = subprocess.run([exe, batch, str(tmp_path / "o.bin"), "all"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and "nothing is computed on the CPU" in r.stderr
     assert not os.path.exists(str(tmp_path / "o.bin"))
+
+
+# ---- launch conventions of bench.py: a run that asks for N GPUs never reports a number measured on fewer ------------------
+
+def test_bench_launch_plan_rules():
+    """bench.launch_plan: --gpus N without a launcher re-executes under torch.distributed.run (the contract's command line);
+    under a launcher WORLD_SIZE must equal N; too few devices, a stray launcher around --sharded-capi or a virtual shard count
+    that differs from N are refused with a reason."""
+    sys.path.insert(0, ROOT)
+    import bench
+    kind, cmd = bench.launch_plan(8, False, {}, 8, ["--gpus", "8", "--steps", "5"])
+    assert kind == "relaunch"
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5"]
+    assert bench.launch_plan(1, False, {}, 1, []) == ("run", None)
+    assert bench.launch_plan(8, False, {"WORLD_SIZE": "8", "LOCAL_RANK": "7"}, 8, []) == ("run", None)
+    for args in [(8, False, {}, 1, []),                                       # eight asked for, one visible
+                 (8, False, {"WORLD_SIZE": "1"}, 8, []),                      # `python bench.py --gpus 8` inside a one-rank launcher
+                 (1, False, {"WORLD_SIZE": "8", "LOCAL_RANK": "0"}, 8, []),   # eight ranks, --gpus forgotten
+                 (8, False, {"WORLD_SIZE": "8", "LOCAL_RANK": "7"}, 4, []),   # a rank without a device
+                 (0, False, {}, 1, []),
+                 (8, True, {}, 4, []),
+                 (8, True, {"WORLD_SIZE": "8"}, 8, []),
+                 (8, True, {"NDTPSO_SHARD_VIRTUAL": "4"}, 1, [])]:
+        kind, why = bench.launch_plan(*args)
+        assert kind == "fail" and isinstance(why, str) and why, args
+    assert bench.launch_plan(8, True, {}, 8, []) == ("sharded", None)
+    assert bench.launch_plan(8, True, {"NDTPSO_SHARD_VIRTUAL": "8"}, 1, []) == ("sharded", None)
+
+
+def test_bench_refuses_more_gpus_than_are_visible():
+    """`python bench.py --gpus N` on a box with fewer than N devices (here: whatever the box has + 1): exit code 2, a
+    one-line reason, no JSON line."""
+    import torch
+    n = (torch.cuda.device_count() if torch.cuda.is_available() else 0) + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for extra in ([], ["--sharded-capi"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1"] + extra,
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 2, (r.returncode, r.stderr[-500:])
+        assert "HIP device(s) visible" in r.stderr and not r.stdout.strip()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in r.stderr and not r.stdout.strip()
+
+
+# ---- the G-device call on a one-device box: NDTPSO_SHARD_VIRTUAL (the shard group's test mode) -----------------------------
+
+VIRTUAL_WORKER = r'''
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.environ["NDTPSO_ROOT"])
+from ndtpso_slam_amd import capi, synth
+G = int(os.environ["NDTPSO_SHARD_VIRTUAL"])
+B = int(os.environ["NDTPSO_TEST_PAIRS"])
+p = synth.make_pairs(B, n_beams=541, seed=77)
+geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+grid, cfg = capi.Grid(60, 60, 0.5), capi.PSOConfig.make(8, 16)
+dev = (0.1, 0.1, 3.1415e-3)
+ctx = capi.Context(0)
+want, wcost, wst = ctx.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+g = capi.ShardGroup([0])
+info = g.describe()
+assert info["n_shards"] == G and info["gather"] == "host-staged (test)" and info["devices"] == [0] * G and info["comm_ranks"] == 0, info
+res = {"info": info}
+got, cost, st = g.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+assert np.array_equal(got, want) and np.array_equal(cost, wcost) and np.array_equal(st["gbest_updates"], wst["gbest_updates"])
+assert g.verify_gather() == G
+per, call = g.last_timing()
+sizes = [capi.shard_range(B, r, G) for r in range(G)]
+assert (per[:, 1] > 0).sum() == sum(1 for a, b in sizes if b > a)      # every non-empty shard uploaded its own block
+# one shard failing fails the call -- with its reason, promptly, nothing hanging -- and the group stays usable
+os.environ["NDTPSO_SHARD_TEST_FAIL"] = str(G - 2 if G > 2 else 0)
+t0 = time.time()
+try:
+    g.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+    raise SystemExit("the injected failure was not reported")
+except capi.NdtpsoError as e:
+    assert "NDTPSO_SHARD_TEST_FAIL" in str(e), str(e)
+res["failed_call_s"] = time.time() - t0
+try:
+    g.verify_gather()
+    raise SystemExit("verify_gather after a failed call")
+except capi.NdtpsoError:
+    pass
+del os.environ["NDTPSO_SHARD_TEST_FAIL"]
+got, cost, st = g.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
+assert np.array_equal(got, want) and np.array_equal(cost, wcost) and g.verify_gather() == G
+# a null pointer for a non-empty shard of the resident flavour: an argument error, not a hang
+import torch
+keep, ptrs = [], {k: [] for k in ("ref", "new", "guess", "dev", "seeds")}
+td = torch.device("cuda", 0)
+for r in range(G):
+    a, b = sizes[r]
+    t = {"ref": torch.from_numpy(p.ref_ranges[a:b]).to(td), "new": torch.from_numpy(p.new_ranges[a:b]).to(td),
+         "guess": torch.zeros(b - a, 3, dtype=torch.float64, device=td),
+         "dev": torch.tensor(dev, dtype=torch.float64, device=td).repeat(b - a, 1).contiguous(),
+         "seeds": torch.from_numpy(p.seeds[a:b].astype(np.int64)).to(td).to(torch.int32)}
+    keep.append(t)
+    for k in ptrs:
+        ptrs[k].append(t[k].data_ptr() if b > a else 0)
+torch.cuda.synchronize()
+got, cost, st = g.align_pairs_dev(B, ptrs["ref"], ptrs["new"], geom, grid, ptrs["guess"], ptrs["dev"], cfg, d_seeds=ptrs["seeds"])
+assert np.array_equal(got, want) and np.array_equal(cost, wcost)
+bad = list(ptrs["new"])
+bad[0] = 0
+try:
+    g.align_pairs_dev(B, ptrs["ref"], bad, geom, grid, ptrs["guess"], ptrs["dev"], cfg, d_seeds=ptrs["seeds"])
+    raise SystemExit("a null shard pointer was accepted")
+except capi.NdtpsoError as e:
+    assert "null device pointer" in str(e), str(e)
+g.close()
+ctx.close()
+print(json.dumps(res))
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,n_pairs", [(8, 4099), (8, 5), (3, 301)])
+def test_virtual_shards_on_one_device(tmp_path, G, n_pairs):
+    """What the first G-device call will execute, on the box's one device: G shards (context, stream and host thread each)
+    over an UNEVEN partition (4096 + 3 pairs over 8; 5 pairs over 8: three shards empty), every shard's block scattered by
+    its own thread, the gathered batch found on every shard, poses bit for bit those of ndtpso_align_pairs; an injected
+    failure of one shard fails the call with its reason within seconds and leaves the group usable."""
+    import json
+    script = tmp_path / "virt.py"
+    script.write_text(VIRTUAL_WORKER)
+    env = dict(os.environ, NDTPSO_ROOT=ROOT, NDTPSO_SHARD_VIRTUAL=str(G), NDTPSO_TEST_PAIRS=str(n_pairs))
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["failed_call_s"] < 10.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("virtual", [0, 8])
+def test_bench_sharded_capi_mode(virtual):
+    """bench.py --sharded-capi: the one-process launch convention (ndtpso_align_pairs_sharded_dev), with the JSON contract
+    of the per-process runs.  virtual = 0: the box's one device through real RCCL (ncclCommInitAll of one rank);
+    virtual = 8: --gpus 8 as eight shards on the one device, flagged as a test mode and reported as n_gpus 1."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    n = 8 if virtual else 1
+    if virtual:
+        env["NDTPSO_SHARD_VIRTUAL"] = "8"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sharded-capi", "--gpus", str(n), "--steps", "6", "--warmup", "2",
+                        "--settle-ms", "50", "--pairs", "128" if virtual else "512"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["scaling"] == "weak" and d["value"] > 1e4
+    assert d["rccl"]["ranks_seen"] == n and d["rccl"]["every_rank_found_its_poses_in_the_gather"]
+    assert d["extra"]["shard0_poses_equal_ndtpso_align_pairs"] and d["extra"]["status_nonzero"] == 0
+    assert d["config"]["shards"] == n and 0 < d["roofline"]["frac"] < 1
+    if virtual:
+        assert "NOT a multi-GPU measurement" in d["config"]["test_mode"] and d["rccl"]["gather"] == "host-staged (test)"
+    else:
+        assert d["config"]["test_mode"] is None and d["rccl"]["gather"].startswith("ncclAllGather") and d["rccl"]["comm_ranks"] == 1
+        assert d["rccl"]["version"]
