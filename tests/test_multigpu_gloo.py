@@ -381,11 +381,17 @@ def test_bench_refuses_more_gpus_than_are_visible():
     assert r.returncode == 2 and "WORLD_SIZE=1 but --gpus 2" in r.stderr and not r.stdout.strip()
 
 
+@pytest.mark.gpu
+def test_bench_refuses_more_gpus_than_are_visible_on_a_gpu_box():
+    test_bench_refuses_more_gpus_than_are_visible()
+
+
 # ---- the G-device call on a one-device box: NDTPSO_SHARD_VIRTUAL (the shard group's test mode) -----------------------------
 
 VIRTUAL_WORKER = r'''
 import json, os, sys, time
 import numpy as np
+import torch   # before the library: the process must load torch's own HIP runtime first (torch finds no device in another one)
 sys.path.insert(0, os.environ["NDTPSO_ROOT"])
 from ndtpso_slam_amd import capi, synth
 G = int(os.environ["NDTPSO_SHARD_VIRTUAL"])
@@ -424,7 +430,6 @@ del os.environ["NDTPSO_SHARD_TEST_FAIL"]
 got, cost, st = g.align_pairs(p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds, mode=capi.SCORE_EXACT)
 assert np.array_equal(got, want) and np.array_equal(cost, wcost) and g.verify_gather() == G
 # a null pointer for a non-empty shard of the resident flavour: an argument error, not a hang
-import torch
 keep, ptrs = [], {k: [] for k in ("ref", "new", "guess", "dev", "seeds")}
 td = torch.device("cuda", 0)
 for r in range(G):
