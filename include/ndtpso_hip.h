@@ -402,13 +402,22 @@ int ndtpso_selftest_exp(ndtpso_ctx *ctx, int exp2_lo, int exp2_hi, uint32_t per_
                         uint64_t *checked, uint64_t *mismatched, double *first_bad);
 int ndtpso_device_math(ndtpso_ctx *ctx, int kind, const double *x, uint32_t n, double *out0, double *out1);
 /* The start-up known-answer check of NDTPSO_SCORE_EXACT.  The first request for the exact mode on a device (any entry
- * point, any context of the process) first runs a fixed small problem -- a batch through the 8-wave batch kernel, single
- * alignments on a cluster of workgroups and on one workgroup -- in the exact mode and in NDTPSO_SCORE_F64 and compares poses
- * and costs bit for bit (and checks that comparisons were in fact arbitrated).  If they differ the device is refused the
- * exact mode: every later request for it runs NDTPSO_SCORE_F64 (the same results by definition, at its speed), and
- * ndtpso_last_error explains.  ndtpso_exact_check runs the check if it has not run and reports: state 1 passed, 2 refused;
- * the comparisons the check arbitrated; its duration in ms.  NDTPSO_EXACT_CHECK=0 in the environment skips it. */
+ * point, any context of the process) first sends a fixed small problem through EVERY kernel instantiation that arbitrates
+ * and that the library's dispatchers can reach -- the fused pairs kernels over table-entry form x {one workgroup per
+ * alignment without / with clipping trips, clusters of workgroups} x swarm in LDS / in HBM x plain / box-guard copies, and the
+ * lone alignment's kernel (ndtpso_align, ndtpso_map_align) on one workgroup and on a cluster: 15 families, each forced by a
+ * plan override and confirmed by the instantiation its launch recorded -- in the exact mode and in NDTPSO_SCORE_F64, and
+ * compares poses and costs bit for bit (and checks, per family, that comparisons were in fact arbitrated).  If any family
+ * differs the device is refused the exact mode: every later request for it runs NDTPSO_SCORE_F64 (the same results by
+ * definition, at its speed), and ndtpso_last_error explains.  A check that could not run (no memory for its context, a HIP
+ * error) is no verdict: that request runs NDTPSO_SCORE_F64 and the next one runs the check again (three attempts).
+ * ndtpso_exact_check runs the check if it has not run and reports: state 1 passed, 2 refused; the comparisons the check
+ * arbitrated in the pairs / lone-alignment families; its duration in ms.  ndtpso_exact_check_report writes one JSON object
+ * with a line per family (name, passed / refused / not reachable on this device, alignments, arbitrated, mismatched) into
+ * buf (at most cap - 1 characters) and returns the length the whole text needs.  NDTPSO_EXACT_CHECK=0 in the environment
+ * skips the check. */
 int ndtpso_exact_check(ndtpso_ctx *ctx, int *state, uint32_t *arbitrated_batch, uint32_t *arbitrated_single, double *ms);
+int ndtpso_exact_check_report(ndtpso_ctx *ctx, char *buf, uint32_t cap);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "ndtpso_hip.hip")
 DEPS = [SRC, os.path.join(HERE, "csrc", "ndtpso_kernels.hpp"), os.path.join(HERE, "csrc", "ndtpso_map.inc"),
+        os.path.join(HERE, "csrc", "ndtpso_pairs_body.inc"),
         os.path.join(HERE, "csrc", "ndtpso_shard.inc"), os.path.join(HERE, "csrc", "ndtpso_selftest.inc"),
         os.path.join(os.path.dirname(HERE), "include", "ndtpso_hip.h")]
 LIB_DIR = os.path.join(HERE, "lib")

@@ -641,262 +641,70 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
               const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride,
               uint32_t* __restrict__ feedback /* counts the alignments whose box outgrew the cell table (pinned host word) */) {
   size_t b = blockIdx.x;
-  if constexpr (CLUSTER) {
-    if (!cluster_place(cl, &b, &cl.rank)) return;
-    cl.xc += b * (2 * (size_t)cl.stride + (size_t)round_up(cl.K, 8));  // two slot buffers + the workgroups' heartbeats
-    cl.spec = cl.spec_off >= 0 ? reinterpret_cast<double*>(g_lds + cl.spec_off) : nullptr;
-  }
-  const bool writer = !CLUSTER || cl.rank == 0;
-  if (CLUSTER && cl.rank == cl.absent) return;
-  if (gate && !(stats[b].status & gate)) return;
-  const uint32_t t_start = (uint32_t)wall_clock64();
-  double2* pts = reinterpret_cast<double2*>(g_lds + L.pts_off);
-  ImageHeader* hdr = reinterpret_cast<ImageHeader*>(g_lds + L.hdr_off);
+#include "ndtpso_pairs_body.inc"
+}
 
-  // reference frame <- scan A at identity (ndtpso_slam_node.cpp:186,198 for the first scan), then build
-#ifdef NDTPSO_PROFILE_SETUP
-  unsigned long long tk[6];
-  tk[0] = wall_clock64();
-#define NDTPSO_SETUP_MARK(i) tk[i] = wall_clock64()
-#else
-#define NDTPSO_SETUP_MARK(i) do { } while (0)
-#endif
-  const int n_ref = scan_to_points_wg(ref_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off));
-  __syncthreads();
-  NDTPSO_SETUP_MARK(1);
-  DenseGuard guard{1., 0., 1., 0.};  // (empty: every pose takes the clamped loop)
-  [[maybe_unused]] double g_t_lo = -1.7976931348623157e308, g_t_hi = 1.7976931348623157e308;  // BOX: the headings it holds for
-  if constexpr (MODE == kScoreF64 && !path_is_dense(PATH) && !path_is_dense64(PATH) && !CLUSTER) {
-    // fp64 score, bitmap form: scan B's points lie within rho of the sensor, so a pose whose translation keeps that disc
-    // strictly inside the frame AND inside the table's window needs none of the per-point frame / window / wrap tests
-    // (score_trip_guarded) -- the translations of such poses, in metres, are the guard's box (empty if there is none)
-    const float rho = scan_max_range_wg(new_ranges + b * sp.n_beams, sp, lds_cnt(L.ctrl_off) + 30);
-    if (rho > 0.f) {
-      const double rr = (double)rho * (1. + 1e-9) + 1e-6 * g.cs;  // rounding of the transform included
-      const double x_lo = fmax(-g.hw, (double)wn.x0 * g.cs - g.hw) + rr, x_hi = fmin(g.hw, (double)(wn.x0 + wn.w) * g.cs - g.hw) - rr;
-      const double y_lo = fmax(-g.hh, (double)wn.y0 * g.cs - g.hh) + rr, y_hi = fmin(g.hh, (double)(wn.y0 + wn.h) * g.cs - g.hh) - rr;
-      if (x_lo < x_hi && y_lo < y_hi) guard = DenseGuard{x_lo, x_hi, y_lo, y_hi};
-    }
-  }
-  if constexpr (path_is_dense(PATH)) {
-    wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
-    if constexpr (!CLUSTER) {
-      // Room in the table for scan B under any heading: all its points lie within rho of the sensor, so around the
-      // guess -- plus a margin for the translations the particles try -- a box of rho / cell_side cells either way
-      // holds every table coordinate the score loop can produce, and the loop may drop its clamps (DenseGuard).  The
-      // box is clipped to the grid and joined with scan A's occupied box; if the provisioned table cannot hold the
-      // union, the window stays A's box and the guard stays empty.
-      const float rho = scan_max_range_wg(new_ranges + b * sp.n_beams, sp, lds_cnt(L.ctrl_off) + 30);
-      const double rc = (double)rho * g.inv_cs * (1. + 1e-9) + 1e-6;  // cells, rounding of the transform included
-      const double cx = (guess[3 * b] + g.hw) * g.inv_cs, cy = (guess[3 * b + 1] + g.hh) * g.inv_cs;
-      constexpr double kMarginCells = 4.;
-      if (rho > 0.f && fabs(cx) < 1e6 && fabs(cy) < 1e6) {
-        const int bx0 = max((int)floor(cx - rc - kMarginCells), 0), bx1 = min((int)floor(cx + rc + kMarginCells), g.W - 1);
-        const int by0 = max((int)floor(cy - rc - kMarginCells), 0), by1 = min((int)floor(cy + rc + kMarginCells), g.H - 1);
-        if (bx1 >= bx0 && by1 >= by0) {
-          const int ux0 = min(wn.x0, bx0), uy0 = min(wn.y0, by0);
-          const int uw = max(wn.x0 + wn.w - 1, bx1) - ux0 + 1, uh = max(wn.y0 + wn.h - 1, by1) - uy0 + 1;
-          if (dense_entries(uw + 1, uh + 1) <= dense_cap) {
-            wn.x0 = ux0;
-            wn.y0 = uy0;
-            wn.w = uw;
-            wn.h = uh;
-            wn.n_words = (uw * uh + 31) / 32;
-            // table coordinates run over [0, dw + 1), dw = w + 1 (low border column, window, null high column)
-            double gx_hi = (double)(uw + 2) - rc, gy_hi = (double)(uh + 2) - rc;
-            if constexpr (!NOCLIP) {
-              // a grid whose last cells overhang the frame (DenseP::clip): the disc stays below the frame's upper bounds too
-              // (DenseItem::XMAX / YMAX in the coordinates of this table), so a pose under the guard cannot hold a point the
-              // clip test would reject and its trips go without the test
-              if (dn.clip) {
-                gx_hi = fmin(gx_hi, (2. * g.hw) * g.inv_cs - (double)(ux0 - 1) - rc);
-                gy_hi = fmin(gy_hi, (2. * g.hh) * g.inv_cs - (double)(uy0 - 1) - rc);
-              }
-            }
-            guard = DenseGuard{rc, gx_hi, rc, gy_hi};
-          } else if constexpr (BOX) {
-            // The disc's box does not fit beside scan A's: the box of scan B's own extent under the guess's heading (box_guard_wg).
-            // BOX: the kernels the host launches when the provisioned table is less than half the static window (Plan::boxy) -- a
-            // copy of their own: this branch's presence cost the benchmark's batches 2.3 % out of line and 4 % inline, the third flag 2 %
-            BoxGuardOut* bo = reinterpret_cast<BoxGuardOut*>(lds_cnt(L.ctrl_off));
-            box_guard_wg(new_ranges + b * sp.n_beams, &sp, beam_dirs, &g, guess + 3 * b, dev + 3 * b, rc, cx, cy, &wn, dense_cap,
-                         NOCLIP ? 0 : dn.clip, lds_cnt(L.ctrl_off) + 24, bo);
-            if (bo->ok) {
-              wn.x0 = bo->x0;
-              wn.y0 = bo->y0;
-              wn.w = bo->w;
-              wn.h = bo->h;
-              wn.n_words = (bo->w * bo->h + 31) / 32;
-              guard = bo->guard;
-              g_t_lo = bo->t_lo;
-              g_t_hi = bo->t_hi;
-            }
-            __syncthreads();  // (the counters' slots are free again)
-          }
-        }
-      }
-    }
-    dn.dw = wn.w + 1;
-    dn.dh = wn.h + 1;
-    dn.ox = wn.x0 - 1;
-    dn.oy = wn.y0 - 1;
-    dense_set_limits(dn, g.hw, g.hh, g.inv_cs);
-    if (dense_entries(dn.dw, dn.dh) > dense_cap) {  // uniform (and the same in every workgroup of a cluster)
-      if (threadIdx.x == 0 && writer) {
-        stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
-        if (feedback) __hip_atomic_fetch_add(feedback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      return;
-    }
-  }
-  if constexpr (path_is_dense64(PATH)) {
-    // fp64 score on the dense table: the window is scan A's occupied box joined, where the provisioned table has room, with
-    // the box scan B's points can reach around the guess (as above); the guard is the bitmap form's, in metres -- the
-    // translations that keep scan B's disc strictly inside the frame and inside the window
-    static_assert(!path_is_dense64(PATH) || !CLUSTER, "PATH 8 / 9 run one workgroup per alignment");
-    wn = dynamic_window_wg(g, pts, n_ref, lds_cnt(L.ctrl_off) + 24, wn.rec_cap);
-    const float rho = scan_max_range_wg(new_ranges + b * sp.n_beams, sp, lds_cnt(L.ctrl_off) + 30);
-    const double rc = (double)rho / g.cs * (1. + 1e-9) + 1e-6;
-    const double cx = (guess[3 * b] + g.hw) / g.cs, cy = (guess[3 * b + 1] + g.hh) / g.cs;
-    constexpr double kMarginCells = 4.;
-    if (rho > 0.f && fabs(cx) < 1e6 && fabs(cy) < 1e6) {
-      const int bx0 = max((int)floor(cx - rc - kMarginCells), 0), bx1 = min((int)floor(cx + rc + kMarginCells), g.W - 1);
-      const int by0 = max((int)floor(cy - rc - kMarginCells), 0), by1 = min((int)floor(cy + rc + kMarginCells), g.H - 1);
-      [[maybe_unused]] bool boxed = false;
-      if (bx1 >= bx0 && by1 >= by0) {
-        const int ux0 = min(wn.x0, bx0), uy0 = min(wn.y0, by0);
-        const int uw = max(wn.x0 + wn.w - 1, bx1) - ux0 + 1, uh = max(wn.y0 + wn.h - 1, by1) - uy0 + 1;
-        if (dense_entries(uw + 1, uh + 1) <= dense_cap) {
-          wn.x0 = ux0;
-          wn.y0 = uy0;
-          wn.w = uw;
-          wn.h = uh;
-          wn.n_words = (uw * uh + 31) / 32;
-        } else if constexpr (BOX) {
-          // (the disc's box does not fit beside scan A's: scan B's own extent under the guess's heading, box_guard_wg)
-          BoxGuardOut* bo = reinterpret_cast<BoxGuardOut*>(lds_cnt(L.ctrl_off));
-          box_guard_wg(new_ranges + b * sp.n_beams, &sp, beam_dirs, &g, guess + 3 * b, dev + 3 * b, rc, cx, cy, &wn, dense_cap,
-                       dn.clip, lds_cnt(L.ctrl_off) + 24, bo, 1);
-          if (bo->ok) {
-            wn.x0 = bo->x0;
-            wn.y0 = bo->y0;
-            wn.w = bo->w;
-            wn.h = bo->h;
-            wn.n_words = (bo->w * bo->h + 31) / 32;
-            if (bo->guard.x_lo < bo->guard.x_hi && bo->guard.y_lo < bo->guard.y_hi) {
-              guard = bo->guard;
-              g_t_lo = bo->t_lo;
-              g_t_hi = bo->t_hi;
-            }
-            boxed = true;
-          }
-          __syncthreads();  // (the counters' slots are free again)
-        }
-      }
-      if (!boxed) {
-        const double rr = (double)rho * (1. + 1e-9) + 1e-6 * g.cs;  // rounding of the transform included
-        const double x_lo = fmax(-g.hw, (double)wn.x0 * g.cs - g.hw) + rr, x_hi = fmin(g.hw, (double)(wn.x0 + wn.w) * g.cs - g.hw) - rr;
-        const double y_lo = fmax(-g.hh, (double)wn.y0 * g.cs - g.hh) + rr, y_hi = fmin(g.hh, (double)(wn.y0 + wn.h) * g.cs - g.hh) - rr;
-        if (x_lo < x_hi && y_lo < y_hi) guard = DenseGuard{x_lo, x_hi, y_lo, y_hi};
-      }
-    }
-    dn.dw = wn.w + 1;
-    dn.dh = wn.h + 1;
-    dn.ox = wn.x0 - 1;
-    dn.oy = wn.y0 - 1;
-    if (dense_entries(dn.dw, dn.dh) > dense_cap) {  // uniform
-      if (threadIdx.x == 0) {
-        stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
-        if (feedback) __hip_atomic_fetch_add(feedback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-      return;
-    }
-  }
-  NDTPSO_SETUP_MARK(2);
-  // exact mode (ximg): the bitmap-form fp64 table goes to this workgroup's image in HBM as well
-  unsigned char* my_ximg = nullptr;
-  TableOut xout{nullptr, nullptr, nullptr, nullptr, nullptr};
-  if constexpr (ARB) {
-    {
-      my_ximg = ximg + (CLUSTER ? b * (size_t)cl.K + (size_t)cl.rank : b) * ximg_stride;
-      xout.mean = reinterpret_cast<double2*>(my_ximg + image_mean_offset(wn.n_words));
-      xout.ab = reinterpret_cast<double2*>(my_ximg + image_ab_offset(wn.n_words, wn.rec_cap));
-      xout.cd = reinterpret_cast<double2*>(my_ximg + image_cd_offset(wn.n_words, wn.rec_cap));
-    }
-  }
-  build_table_wg(g, wn, pts, n_ref, hdr, lds_table_out(L), reinterpret_cast<int*>(g_lds + L.key_off),
-                 reinterpret_cast<int*>(g_lds + L.cellkey_off), reinterpret_cast<int*>(g_lds + L.cnt_off),
-                 reinterpret_cast<uint2*>(g_lds + L.bm2_off), reinterpret_cast<unsigned short*>(g_lds + L.plist_off),
-                 nullptr, nullptr, (path_is_dense(PATH) || path_is_dense64(PATH)) ? &dn : nullptr, g_lds, PATH == 3,
-                 my_ximg ? &xout : nullptr, path_is_dense64(PATH) ? L.dtab_off : -1);
-  if constexpr (path_is_dense64(PATH)) {
-    // a cell whose exponents exp_neg_half must not be trusted with (d64_cell_tame), or more built cells than records: the
-    // bitmap form's kernel, which calls the library's exp, takes the alignment
-    if (hdr->status & (kHdrWildCell | 2u)) {  // uniform (build_table_wg ends with a barrier)
-      if (threadIdx.x == 0) stats[b].status = (stats[b].status & ~gate) | kStatusNeedsBitmap;
-      return;
-    }
-  }
-  NDTPSO_SETUP_MARK(3);
-  // new frame <- scan B (one-cell frame of the same size: the point list inside the frame, ndtpso_slam_node.cpp:229-230)
-  const int n_new = scan_to_points_wg(new_ranges + b * sp.n_beams, sp, beam_dirs, false, 1., 0., 0., 0., pts, lds_cnt(L.ctrl_off),
-                                      g.hw, g.hh);
-  pad_points_wg(pts, n_new);
-  if (threadIdx.x == 0) {
-    lds_ctrl(L.ctrl_off)->guard = guard;
-    if constexpr (BOX) {
-      lds_ctrl(L.ctrl_off)->g_t_lo = g_t_lo;
-      lds_ctrl(L.ctrl_off)->g_t_hi = g_t_hi;
-    }
-  }
-  __syncthreads();
-  NDTPSO_SETUP_MARK(4);
-#ifdef NDTPSO_PROFILE_SETUP
-  if (threadIdx.x == 0 && blockIdx.x == 0)
-    printf("setup (us): scan A %.1f window %.1f table %.1f scan B %.1f\n", (tk[1] - tk[0]) * 0.01, (tk[2] - tk[1]) * 0.01,
-           (tk[3] - tk[2]) * 0.01, (tk[4] - tk[3]) * 0.01);
-#endif
+// the same alignment as a function of the pair, for the kernels that stride when gated (k_align_pairs_s below)
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, int SWARM = 2, bool BOX = false>
+__device__ __forceinline__ void
+align_pair_wg(size_t b, const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
+              Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
+              const double* __restrict__ dev, const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables,
+              size_t table_stride, unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
+              double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl,
+              const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride,
+              uint32_t* __restrict__ feedback) {
+#include "ndtpso_pairs_body.inc"
+}
 
-#ifdef NDTPSO_PHASE_BUDGET
-  const uint32_t t_setup_end = (uint32_t)wall_clock64();
-#endif
-  EvalCtx E = make_eval_ctx(g, wn, L, dn);
-  E.light = CLUSTER ? 0 : ps.light;
-  E.guard_lds = (unsigned)(uintptr_t)(const DenseGuard __attribute__((address_space(3)))*)&lds_ctrl(L.ctrl_off)->guard;
-  if constexpr (path_is_dense64(PATH))
-    E.d64_tab = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)(g_lds + L.dtab_off);
-  if constexpr (ARB) enable_arbitration<PATH == 3>(lds_ctrl(L.ctrl_off), g, wn, dn, my_ximg, L);
-#ifdef NDTPSO_VERIFY_MARGIN
-  if constexpr (ARB && !CLUSTER) E.xa = &lds_ctrl(L.ctrl_off)->xa;
-#endif
-  if (threadIdx.x == 0 && gate) stats[b].status &= ~gate;
-  if (SWARM == 1 || (SWARM == 2 && L.swarm_global)) {  // (two copies: see k_align)
-    if constexpr (SWARM != 0) {
-      const Swarm sw = swarm_carve(ws + (b * (CLUSTER ? (size_t)cl.K : 1) + (CLUSTER ? (size_t)cl.rank : 0)) * ws_stride, ps.P, ARB, true);
-      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, true, false, BOX>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                                           tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
-                                           out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
-    }
-  } else {
-    if constexpr (SWARM != 1) {
-      const Swarm sw = swarm_carve(g_lds + L.region_off, ps.P, ARB, swarm_has_raw2(ps.P, false));
-      // (SWARM == 0: the batches' kernels, whose layout always carries the arbitration's unit scratch -- make_layout)
-      pso_run_wg<MODE, PATH, CLUSTER, ARB, NOCLIP, false, (SWARM == 0 && ARB && !CLUSTER), BOX>(E, pts, n_new, ps, guess + 3 * b, dev + 3 * b, seeds ? seeds[b] : 1u,
-                                           tables ? tables + b * table_stride : nullptr, sw, lds_ctrl(L.ctrl_off),
-                                           out_pose + 3 * b, out_cost ? out_cost + b : nullptr, stats + b, cl);
-    }
+// Gated launches -- "redo the alignments whose status carries this flag" -- used to be a workgroup per pair, 511 in 512 of which
+// left on their first instruction.  Cheap on an idle device; but with two batches in flight every compute unit's LDS and
+// registers are held by the other lane's main kernel, a workgroup that only wants to look at a flag waits for one of ITS
+// workgroups to end like any other, and 512 of them trickled through the few free slots for 0.6 ms on average (a fifth of the
+// traced kernel time, profiles/r05_kernel_stats_two_in_flight.csv) while their lane's next main launch waited behind them.
+// The kernels that serve as redo kernels -- every one but the fp32 score's dense form, whose gated launch (largest table) is
+// issued only where tables have been overflowing -- therefore have a second kernel for their gated launches, k_align_pairs_s,
+// which STRIDES: a few workgroups (launch_pairs: 8, or twice what the previous call of the configuration found flagged) walk
+// over the pairs and run the flagged ones one after the other, and workgroup 0 leaves the number of flagged pairs in a pinned
+// word for the host's next choice of the grid.  (k_align_pairs itself -- every main launch -- is untouched.)
+template <int MODE, int PATH, bool CLUSTER>
+__host__ __device__ constexpr bool gate_strides() {
+  return !CLUSTER && !(MODE == kScoreF32 && path_is_dense(PATH));
+}
+
+template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false, int SWARM = 2, bool BOX = false>
+__global__ void __launch_bounds__(1024)
+k_align_pairs_s(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
+                Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
+                const double* __restrict__ dev, const uint32_t* __restrict__ seeds, const int32_t* __restrict__ tables,
+                size_t table_stride, unsigned char* __restrict__ ws, size_t ws_stride, double* __restrict__ out_pose,
+                double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl,
+                const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride,
+                uint32_t* __restrict__ feedback, uint32_t n_pairs, uint32_t* __restrict__ gate_count) {
+  if (gate_count && blockIdx.x == 0) {
+    unsigned* cnt = reinterpret_cast<unsigned*>(g_lds);
+    if (threadIdx.x == 0) *cnt = 0u;
+    __syncthreads();
+    unsigned mine = 0;
+    for (uint32_t i = threadIdx.x; i < n_pairs; i += blockDim.x) mine += (stats[i].status & gate) ? 1u : 0u;
+    if (mine) atomicAdd(cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(gate_count, *cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
   }
-  if (threadIdx.x == 0 && writer) {
-    stats[b].n_built = hdr->n_built;
-    stats[b].status |= hdr->status & 3u;
-    stats[b].t_start = t_start;
-    stats[b].t_end = (uint32_t)wall_clock64();
-#ifdef NDTPSO_PHASE_BUDGET
-    if (!CLUSTER && blockIdx.x < kBudgetMaxBlocks) {
-      g_budget[(size_t)blockIdx.x * 16 + 0] = t_setup_end - t_start;
-      g_budget[(size_t)blockIdx.x * 16 + 15] = stats[b].t_end - t_start;
+  // this workgroup's pairs are blockIdx.x, blockIdx.x + gridDim.x, ...: 64 of their flags per sweep, one per lane, in every wave
+  // alike (one after the other a workgroup's 64 loads took as long as 45 us of an otherwise empty launch)
+  for (size_t base = blockIdx.x; base < (size_t)n_pairs; base += (size_t)gridDim.x * kWave) {
+    const size_t mine = base + (size_t)lane_id() * gridDim.x;
+    unsigned long long todo = __ballot(mine < (size_t)n_pairs && (stats[mine].status & gate) != 0u);
+    while (todo) {  // (uniform: every wave has read the same flags, and a pair's flag changes only while that pair is run)
+      const int k = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      align_pair_wg<MODE, PATH, false, ARB, NOCLIP, SWARM, BOX>(base + (size_t)k * gridDim.x, ref_ranges, new_ranges, sp, g, wn, L, dn, dense_cap, ps,
+                                                               guess, dev, seeds, tables, table_stride, ws, ws_stride, out_pose, out_cost, stats,
+                                                               gate, cl, beam_dirs, ximg, ximg_stride, feedback);
+      __syncthreads();  // (the next alignment of this workgroup sets the same LDS up again)
     }
-#endif
   }
 }
 
@@ -1084,6 +892,7 @@ struct ndtpso_ctx {
   uint64_t fb_key = 0;
   bool fb_big_first = false, fb_overflowed = true;
   int fb_overflowed_calls = 0;
+  int fb_big_calls = 0;  // calls since the largest table was put first (it is tried without every 64 calls)
   void* result_pinned = nullptr;      // pinned landing slot of one alignment's pose / cost / statistics (align_once)
   hipEvent_t result_event = nullptr;
 };
@@ -1233,6 +1042,26 @@ struct Plan {
                   // box guard (box_guard_wg).  (The benchmark's table is 86 % of its static window and every disc fits; at 52 - 57 %
                   // -- 361 / 541 beams, 0.3 m cells -- most discs still fit and the copies' flags cost 3 - 7 %.)
 };
+// Plan overrides, per host thread: what the start-up check of the exact mode (ndtpso_selftest.inc) uses to send ONE small
+// problem through every kernel instantiation the dispatchers below can reach -- the swarm's home, the table entries' form, the
+// box-guard copies and the cluster form are otherwise picked by the problem's size.  -1 / 0: as planned.  Results never depend on
+// them (every form returns the same poses: that is what the check compares).
+struct PlanForce {
+  int swarm_hbm = -1;     // 1: the swarm in its HBM workspace although it would fit LDS
+  int byte_entries = -1;  // 0: table entries in 16-byte units (PATH 2) although the records lie below 64 KB (PATH 3)
+  int table_side = 0;     // > 0: the fused kernels' dense table provisioned as side x side entries (a shrunk table)
+  int boxy = -1;          // 1 / 0: the box-guard copies / the plain ones, whatever the table's share of the static window
+  int cluster = -1;       // 1 / 0: a batch as clusters of workgroups / one workgroup per alignment, whatever its size
+};
+thread_local PlanForce t_plan_force;
+// what the last main (ungated) launch of this thread was: k_align_pairs / k_align instantiation as
+// PATH | CL << 4 | ARB << 5 | NOCLIP << 6 | SWARM << 7 | BOX << 9 | (fused pairs kernel) << 10 | (fp64 score) << 11
+thread_local uint32_t t_last_launch = 0;
+constexpr uint32_t launch_code(bool f64, int path, bool cl, bool arb, bool noclip, int swarm, bool box, bool pairs) {
+  return (uint32_t)path | (uint32_t)cl << 4 | (uint32_t)arb << 5 | (uint32_t)noclip << 6 | (uint32_t)swarm << 7 | (uint32_t)box << 9 |
+         (uint32_t)pairs << 10 | (uint32_t)f64 << 11;
+}
+
 // `wn` is the staging window: final for a prebuilt table; for the fused pairs kernel (dynamic_window) it is the
 // static range box -- the worst case the bitmap form must hold -- while the dense form sizes its window per
 // alignment and its table is provisioned as large as still leaves two workgroups per CU (else as large as
@@ -1254,13 +1083,17 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
                       kCtrlBytes + d64_rec_bytes(wn.rec_cap + 1) <= 65536;
   const bool dense_ok = (allow_dense && mode == kScoreF32 && force != 0 && force != 1) || d64_ok;
   const bool force_global = allow_global && (force == 4 || force == 5);
-  for (int swarm_global = 0; swarm_global < 2 && !force_global; ++swarm_global) {
+  for (int swarm_global = (t_plan_force.swarm_hbm == 1 && P > 0) ? 1 : 0; swarm_global < 2 && !force_global; ++swarm_global) {
     if (swarm_global && P <= 0) break;
     if (dense_ok) {
       const int full_w = wn.w + 1, full_h = wn.h + 1;
       Layout Ld = make_layout(wn.n_words, wn.rec_cap, n_max, P, mode, full_w, full_h, swarm_global != 0, exact, dynamic_window);
       int cap = dense_entries(full_w, full_h);
-      if (dynamic_window && Ld.total > (big_table ? kMaxLds : kMaxLds / 2)) {
+      if (dynamic_window && !big_table && t_plan_force.table_side > 0 && t_plan_force.table_side * t_plan_force.table_side < full_w * full_h) {
+        const int side = t_plan_force.table_side;  // (the start-up check: a table of this size, see PlanForce)
+        Ld = make_layout((side * side + 31) / 32, wn.rec_cap, n_max, P, mode, side, side, swarm_global != 0, exact, dynamic_window);
+        cap = dense_entries(side, side);
+      } else if (dynamic_window && Ld.total > (big_table ? kMaxLds : kMaxLds / 2)) {
         // shrink the provisioned (square) table until two workgroups fit per CU, else until one does;
         // never below 64 x 64 cells
         for (int limit : {kMaxLds / 2, kMaxLds}) {
@@ -1301,6 +1134,7 @@ bool make_plan(int mode, const GridP& g, const WinP& wn, int n_max, int P, Plan*
         // (fp64 score: its table, next to 48-byte records, is smaller still; below a quarter of the static window not even the
         // room's own box fits it often enough to pay for the copies' flags -- measured: 0.3 m cells + 10-13 %, 0.25 m - 3 %)
         if (d64_ok && (long)cap * 4 < (long)dense_entries(full_w, full_h)) plan->boxy = false;
+        if (t_plan_force.boxy >= 0) plan->boxy = t_plan_force.boxy != 0;
         return true;
       }
     }
@@ -1351,6 +1185,16 @@ bool trans_is_zero(const double t[3]) {  // Vector3d::isZero(1e-6), ndtframe.cpp
 template <typename K>
 hipError_t allow_big_lds(K kernel) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+}
+
+// a gated launch of a kernel that strides (gate_strides): a function template, so that k_align_pairs_s exists only for those
+template <int MODE, int PATH, bool CL, bool ARB, bool NOCLIP, int SWARM, bool BOX, typename... Args>
+void launch_pairs_gated(dim3 grid, dim3 block, int lds, hipStream_t stream, Args... args) {
+  if constexpr (gate_strides<MODE, PATH, CL>()) {
+    static const hipError_t big = allow_big_lds(k_align_pairs_s<MODE, PATH, ARB, NOCLIP, SWARM, BOX>);  // once per instantiation
+    (void)big;
+    hipLaunchKernelGGL((k_align_pairs_s<MODE, PATH, ARB, NOCLIP, SWARM, BOX>), grid, block, lds, stream, args...);
+  }
 }
 
 int check_pso(ndtpso_ctx* ctx, const ndtpso_pso_config* cfg) {
@@ -2076,6 +1920,8 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     cl.nonce = next_cluster_nonce(c);
   }
 #define LAUNCH_ALIGN_CA(MODE, PATH, CL, ARB)                                                                       \
+  do {                                                                                                             \
+  t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, false, 0, false, false);                           \
   hipLaunchKernelGGL((k_align<MODE, PATH, CL, ARB>), dim3(CL ? cluster_grid(cl) : 1u), dim3(waves * 64), lds_total, c->stream, \
                      src.image, src.xy, (int)n, src.n_ptr, src.g, src.wn, L, plan.dn,                              \
                      ps, (const double*)c->inputs, (const double*)c->inputs + 3, seed,                             \
@@ -2085,7 +1931,8 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
                      staged_table ? (const int4*)((const unsigned char*)c->inputs + kGuessBytes) : nullptr,        \
                      (int4*)((unsigned char*)c->table.p + kGuessBytes), table_vec,                                 \
                      (plan.path == 2 ? src.late_hdr : nullptr), dense_entries(plan.dn.dw, plan.dn.dh), src.wn.rec_cap,  \
-                     (uint32_t)seq)
+                     (uint32_t)seq);                                                                               \
+  } while (0)
 #define LAUNCH_ALIGN_C(MODE, PATH, CL) LAUNCH_ALIGN_CA(MODE, PATH, CL, false)
 #define LAUNCH_ALIGN(MODE, PATH) \
   do { if (K > 1) LAUNCH_ALIGN_C(MODE, PATH, true); else LAUNCH_ALIGN_C(MODE, PATH, false); } while (0)
@@ -2276,6 +2123,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   if (!cfg || cfg->population < 1) return fail(c, NDTPSO_E_ARG, "bad scan/grid/PSO configuration");
   // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
   int K = 1, cw = 4;
+  if (t_plan_force.cluster >= 0) allow_cluster = t_plan_force.cluster != 0;
   cluster_shape(cfg->population, true, allow_cluster && gate == 0, &K, &cw);
   if (K > 1) K = std::min<int>(K, c->n_cus / (int)std::min<uint32_t>(n_pairs, (uint32_t)c->n_cus));
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
@@ -2318,11 +2166,32 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     HIP_TRY(c, c->ximg.reserve(ximg_stride * n_pairs * (size_t)K));
   }
   unsigned char* d_ximg = ximg_stride ? (unsigned char*)c->ximg.p : nullptr;
+  // a gated launch of a kernel that strides (gate_strides): eight workgroups, or twice the pairs the last gated launch of this
+  // kind found flagged (its workgroup 0 leaves the count in the context's pinned feedback block, words 4 .. 7 by kind); a stale
+  // or foreign count only changes how many workgroups share the flagged pairs
+  uint32_t* gate_fb = nullptr;
+  uint32_t gate_grid = n_pairs;
+  if (gate != 0 && c->pairs_fb) {
+    gate_fb = c->pairs_fb + 4 + ((mode == NDTPSO_SCORE_F64 ? 2 : 0) | (allow_dense ? 1 : 0));
+    const uint32_t seen = __atomic_load_n(gate_fb, __ATOMIC_RELAXED);
+    gate_grid = std::min<uint32_t>(n_pairs, std::max<uint32_t>(8u, 2u * seen));
+  }
 #define LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX)                                                \
-  hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX>), dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), lds_total, \
-                     c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev,     \
-                     d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
-                     cl, dirs, d_ximg, ximg_stride, fb)
+  do {                                                                                                             \
+    if (gate == 0) t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, NOCLIP, SWARM, BOX, true);        \
+    if (gate != 0 && gate_strides<MODE, PATH, CL>() && gate_fb) {                                                  \
+      launch_pairs_gated<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX>(dim3(gate_grid), dim3(waves * 64), lds_total, c->stream, d_ref, d_new, \
+                       sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev, d_seeds, d_tables, stride,   \
+                       (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, cl, dirs, d_ximg,        \
+                       ximg_stride, fb, n_pairs, gate_fb);                                                         \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX>),                                 \
+                         dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), lds_total,                       \
+                         c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev, \
+                         d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
+                         cl, dirs, d_ximg, ximg_stride, fb);                                                       \
+    }                                                                                                              \
+  } while (0)
 // (a table much smaller than the static window -- Plan::boxy -- and the swarm in LDS: the copies that carry the box guard)
 #define LAUNCH_PAIRS_CANS(MODE, PATH, CL, ARB, NOCLIP, SWARM)                                                      \
   do {                                                                                                             \
@@ -2363,7 +2232,8 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     const char* e = std::getenv("NDTPSO_BYTE_ENTRIES");
     return !(e && e[0] == '0');
   }();
-  const bool byte_entries = plan.path == 2 && allow_byte_entries && plan.dn.rec_off + dense_rec_bytes(wn.rec_cap + 1) <= 65536;
+  const bool byte_entries = plan.path == 2 && allow_byte_entries && t_plan_force.byte_entries != 0 &&
+                            plan.dn.rec_off + dense_rec_bytes(wn.rec_cap + 1) <= 65536;
   if (d_ximg) {  // exact mode on the dense form
     if (byte_entries) LAUNCH_PAIRS_X(3); else LAUNCH_PAIRS_X(2);
   } else if (mode == NDTPSO_SCORE_F32) {
@@ -2443,9 +2313,9 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
     HIP_TRY(c, c->gate.reserve(sizeof(AlignStats) * (size_t)n_pairs));
     st = reinterpret_cast<AlignStats*>(c->gate.p);
   }
-  HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(AlignStats) * (size_t)n_pairs, c->stream));
   int path = 0;
   const bool small_batch = n_pairs * 2u <= (uint32_t)c->n_cus;
+  HIP_TRY(c, hipMemsetAsync(st, 0, sizeof(AlignStats) * (size_t)n_pairs, c->stream));
   // exact mode: the fp32-score kernel arbitrating in fp64 (dense form) -- or, where the dense form is not available,
   // the fp64 score itself; flagged alignments are redone by the fp64-score kernel
   bool exact = mode == NDTPSO_SCORE_EXACT;
@@ -2462,7 +2332,7 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
   // (what the previous call of this configuration reported: see ndtpso_ctx::pairs_fb)
   if (!c->pairs_fb) {
     HIP_TRY(c, hipHostMalloc((void**)&c->pairs_fb, 64, hipHostMallocMapped | hipHostMallocCoherent));
-    *c->pairs_fb = 0;
+    std::memset(c->pairs_fb, 0, 64);
   }
   {
     uint64_t key = 1469598103934665603ull;
@@ -2479,6 +2349,7 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
     if (key != c->fb_key) {
       c->fb_key = key;
       c->fb_big_first = false;
+      c->fb_big_calls = 0;
       c->fb_overflowed_calls = 1;
     } else if (!c->fb_big_first && c->fb_last_pairs && (uint64_t)(now - c->fb_seen) * 4u > c->fb_last_pairs) {
       c->fb_big_first = true;
@@ -2486,6 +2357,13 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
       if (log_plan)
         std::fprintf(stderr, "ndtpso: %u of the last call's %u pairs outgrew the two-per-CU cell table: largest table first from now on\n",
                      now - c->fb_seen, c->fb_last_pairs);
+    }
+    // ... and not for ever: one burst of large rooms must not pin the configuration to one workgroup per compute unit for the
+    // life of the context -- every 64 calls the two-per-CU table is tried again (and, if a quarter of the pairs still
+    // outgrows it, the next call is back to the largest table)
+    if (c->fb_big_first && ++c->fb_big_calls >= 64) {
+      c->fb_big_first = false;
+      c->fb_big_calls = 0;
     }
     c->fb_seen = now;
     c->fb_last_pairs = n_pairs;
@@ -2505,15 +2383,18 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
                       st, kStatusNeedsBitmap, true, nullptr, false, exact, true);
     if (rc != NDTPSO_OK && rc != NDTPSO_E_CAPACITY) return rc;
   }
+  int path_redo = 0;
   if (small_batch) {  // a cluster that was not co-resident gave up (bounded wait): those alignments on one workgroup each
+    // (on one workgroup the fp64 score may take its dense form -- a cluster keeps the bitmap form --, which hands an alignment
+    // whose box outgrows its table on to the bitmap form: the gated launch below must then be issued for THIS launch's path too)
     rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, mode, d_pose, d_cost,
-                      st, kStatusClusterTimeout, true, nullptr, false, exact);
+                      st, kStatusClusterTimeout, true, &path_redo, false, exact);
     if (rc != NDTPSO_OK) return rc;
   }
   if (mode != NDTPSO_SCORE_F32) {
     // fp64 score on the dense table (path 8 / 9): an occupied box that outgrew the provisioned table, or a table holding a
     // cell whose exponents the spelt-out exponential must not be trusted with -> the bitmap form, gated
-    if (path >= 8) {
+    if (path >= 8 || path_redo >= 8) {
       rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose,
                         d_cost, st, kStatusNeedsBitmap, false, nullptr);
       if (rc == NDTPSO_E_CAPACITY) rc = NDTPSO_OK;
@@ -2588,14 +2469,14 @@ int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges,
 }
 
 #ifdef NDTPSO_VERIFY_MARGIN
-// diagnostic builds only (tests/test_gpu_margin.py): per alignment of the fused-pairs launches since the last reset, 16 doubles
+// diagnostic builds only (tests/test_gpu_margin.py): per alignment of the fused-pairs launches since the last reset, kVerifyRow (24) doubles
 int ndtpso_profile_verify_margin(double* out, uint32_t n_blocks, int reset) {
   if (n_blocks > kVerifyMaxBlocks) return NDTPSO_E_ARG;
   if (hipDeviceSynchronize() != hipSuccess) return NDTPSO_E_HIP;
-  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_verify), (size_t)n_blocks * 16 * sizeof(double)) != hipSuccess) return NDTPSO_E_HIP;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_verify), (size_t)n_blocks * kVerifyRow * sizeof(double)) != hipSuccess) return NDTPSO_E_HIP;
   if (reset) {
     void* p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_verify)) != hipSuccess || hipMemset(p, 0, sizeof(double) * 16 * kVerifyMaxBlocks) != hipSuccess)
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_verify)) != hipSuccess || hipMemset(p, 0, sizeof(double) * kVerifyRow * kVerifyMaxBlocks) != hipSuccess)
       return NDTPSO_E_HIP;
   }
   return NDTPSO_OK;

@@ -2170,15 +2170,22 @@ __device__ __forceinline__ double eval_pose_wave_exact(const ExactArgs* ap, doub
 // table entry than the reference's floor((x + w/2) / cs).  Per alignment (g_verify[blockIdx.x][8], doubles):
 //   0 max err   1 max err / B   2 max B / (tau / 2)   3 max err / (tau / 2)   4 evaluations checked
 //   5 points binned differently (entries differ)   6 max B   7 points checked
+//   15 points whose folded gx or gy lies within 1e-11 of an integer   16 ... within 1e-9   17 points whose folded CELL differs from
+//   the reference's (in frame and window; whatever the two cells hold)   18 max |folded - reference| table coordinate (cells)
+//   19 sum of it over both coordinates (18 / 19: points inside frame and window only)   20 coordinates summed
 #ifdef NDTPSO_VERIFY_MARGIN
 constexpr unsigned kVerifyMaxBlocks = 8192;
-__device__ double g_verify[kVerifyMaxBlocks * 16];
+constexpr unsigned kVerifyRow = 24;
+__device__ double g_verify[kVerifyMaxBlocks * kVerifyRow];
+struct VerifyBin {
+  double near11, near9, cell_differs, max_d, sum_d, n_d;
+};
 __device__ __forceinline__ void verify_max(double* slot, double v) {  // non-negative doubles order like their bit patterns
   atomicMax(reinterpret_cast<unsigned long long*>(slot), (unsigned long long)__double_as_longlong(v));
 }
 template <bool BYTE, bool POW2>
 __device__ __forceinline__ void verify_pose_wave(const ExactArgs* ap, double c, double s, double tx, double ty, double* bound_out,
-                                                 double* misbinned_out) {
+                                                 double* misbinned_out, VerifyBin* bin_out) {
   const GridP g = ap->g;
   const int dw = ap->dw, dh = ap->dh, ox = ap->ox, oy = ap->oy;
   const unsigned null_entry = ap->null_entry;
@@ -2192,6 +2199,7 @@ __device__ __forceinline__ void verify_pose_wave(const ExactArgs* ap, double c, 
   const double TX = (tx + g.hw) * g.inv_cs - (double)ox, TY = (ty + g.hh) * g.inv_cs - (double)oy;
   const double XMAX = (2. * g.hw) * g.inv_cs - (double)ox, YMAX = (2. * g.hh) * g.inv_cs - (double)oy;
   double bound = 0., mis = 0.;
+  VerifyBin vb{0., 0., 0., 0., 0., 0.};
   for (int i = lane; i < ap->n; i += kWave) {
     const v2d_t p = *(lds_d2_t)(uintptr_t)(ap->pts_lds + (unsigned)i * 16u);
     // reference binning (eval_pose_wave_exact)
@@ -2213,6 +2221,20 @@ __device__ __forceinline__ void verify_pose_wave(const ExactArgs* ap, double c, 
     if (!((int)(gx < XMAX) & (int)(gy < YMAX))) flin = 0u;  // (DenseP::clip; never true on a grid that does not overhang)
     const unsigned fe = *(lds_u16_t)(uintptr_t)(flin << 1);
     if (fe != e) mis += 1.;
+    {  // how close the folded coordinates come to a cell edge, and to the reference's own
+      const double ex = fabs(gx - rint(gx)), ey = fabs(gy - rint(gy));
+      if (ex < 1e-11 || ey < 1e-11) vb.near11 += 1.;
+      if (ex < 1e-9 || ey < 1e-9) vb.near9 += 1.;
+      if (inwin) {
+        if (flin != lin) vb.cell_differs += 1.;
+        // the reference's coordinate in this table's units: fl(q + w/2) / cs - window origin (cs a power of two: exact scaling)
+        const double rgx = (qx + g.hw) * g.inv_cs - (double)ox, rgy = (qy + g.hh) * g.inv_cs - (double)oy;
+        const double dx = fabs(gx - rgx), dy = fabs(gy - rgy);
+        vb.max_d = fmax(vb.max_d, fmax(dx, dy));
+        vb.sum_d += dx + dy;
+        vb.n_d += 2.;
+      }
+    }
     if (e != null_entry) {
       const unsigned slot = dense_rec_index(BYTE ? e - null_entry : (e - null_entry) << 4) - 1u;
       const double2 m = ap->xmean[slot], ab = ap->xab[slot], cd = ap->xcd[slot];
@@ -2229,20 +2251,35 @@ __device__ __forceinline__ void verify_pose_wave(const ExactArgs* ap, double c, 
   }
   *bound_out = 1.01 * wave_sum(bound) + (double)ap->n * 1.1754943508222875e-38;
   *misbinned_out = wave_sum(mis);
+  bin_out->near11 = wave_sum(vb.near11);
+  bin_out->near9 = wave_sum(vb.near9);
+  bin_out->cell_differs = wave_sum(vb.cell_differs);
+  bin_out->sum_d = wave_sum(vb.sum_d);
+  bin_out->n_d = wave_sum(vb.n_d);
+  double m = vb.max_d;
+  for (int off = 32; off >= 1; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+  bin_out->max_d = m;
 }
 template <bool BYTE>
 __device__ __forceinline__ void verify_item(const ExactArgs* ap, int j, double cost32, double ref_cost) {
   const double c = ap->pcs[j], s = ap->pcs[ap->S + j], tx = ap->tpos[j], ty = ap->tpos[ap->S + j];
   double cost64, bound, mis;
+  VerifyBin vb;
   if (ap->g.cs_pow2) {
     cost64 = eval_pose_wave_exact<BYTE, true>(ap, c, s, tx, ty);
-    verify_pose_wave<BYTE, true>(ap, c, s, tx, ty, &bound, &mis);
+    verify_pose_wave<BYTE, true>(ap, c, s, tx, ty, &bound, &mis, &vb);
   } else {
     cost64 = eval_pose_wave_exact<BYTE, false>(ap, c, s, tx, ty);
-    verify_pose_wave<BYTE, false>(ap, c, s, tx, ty, &bound, &mis);
+    verify_pose_wave<BYTE, false>(ap, c, s, tx, ty, &bound, &mis, &vb);
   }
   if (lane_id() == 0 && blockIdx.x < kVerifyMaxBlocks && cost32 == cost32 && cost64 == cost64) {
-    double* o = g_verify + (size_t)blockIdx.x * 16;
+    double* o = g_verify + (size_t)blockIdx.x * kVerifyRow;
+    atomicAdd(o + 15, vb.near11);
+    atomicAdd(o + 16, vb.near9);
+    atomicAdd(o + 17, vb.cell_differs);
+    verify_max(o + 18, vb.max_d);
+    atomicAdd(o + 19, vb.sum_d);
+    atomicAdd(o + 20, vb.n_d);
     const double err = fabs(cost32 - cost64);
     const double ref = fabs(ref_cost) > 0. ? fabs(ref_cost) : fabs(cost64);  // (swarm initialisation: relative to the cost itself)
     const double half_tau = 0.5 * arb_margin(ref, ap->n);
@@ -2444,7 +2481,11 @@ __device__ __forceinline__ void exact_task_body(const ExactArgs* ap, unsigned tk
     cn = cs[j];
     sn = cs[ap->S + j];
   }
+#ifdef NDTPSO_BREAK_ARBITRATION  // test builds only (tests/test_gpu_exact_check.py): the whole-task form broken like the unit form
+  const double c = (ap->g.cs_pow2 ? eval_pose_wave_exact<BYTE, true>(ap, cn, sn, x, y) : eval_pose_wave_exact<BYTE, false>(ap, cn, sn, x, y)) * (1. + 0x1p-44);
+#else
   const double c = ap->g.cs_pow2 ? eval_pose_wave_exact<BYTE, true>(ap, cn, sn, x, y) : eval_pose_wave_exact<BYTE, false>(ap, cn, sn, x, y);
+#endif
   if (lane_id() == 0) {
     double* dst = kd == 2 ? ap->xgbc : (kd == 1 ? &ap->pbc[j] : &ap->tcost[j]);
     *dst = c;

@@ -23,6 +23,7 @@ sys.path.insert(0, %r)
 from ndtpso_slam_amd import capi, synth
 ctx = capi.Context(0)
 chk = ctx.exact_check()
+chk["report"] = ctx.exact_check_report()
 p = synth.make_pairs(520, seed=77)
 geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
 args = (p.ref_ranges, p.new_ranges, geom, capi.Grid(60, 60, 0.5), (0, 0, 0), (0.1, 0.1, 3.1415e-3), capi.PSOConfig.make(30, 24))
@@ -48,8 +49,14 @@ def test_shipped_library_passes_its_start_up_check():
     assert d["check"]["state"] == 1, d
     # the check is only worth something if its problem really is arbitrated, in both kernel families
     assert d["check"]["arbitrated_batch"] > 0 and d["check"]["arbitrated_single"] > 0, d
-    assert d["check"]["ms"] < 200., d      # once per process and device
+    assert d["check"]["ms"] < 80., d      # once per process and device
     assert d["equal"] and d["arbitrated"] > 0, d
+    # every arbitrating kernel instantiation the dispatchers can reach went through the check, each confirmed by the launch it
+    # recorded, each with comparisons arbitrated, none differing from the fp64 mode
+    fam = d["check"]["report"]["families"]
+    assert len(fam) == 15 and len({f["instantiation"] for f in fam}) == 14, fam    # (swarm in HBM under the clipping kernel: the same
+    for f in fam:                                                                  #  instantiation, another branch of it)
+        assert f["state"] == "passed" and f["launched"] == f["instantiation"] and f["arbitrated"] > 0 and f["mismatched"] == 0, f
 
 
 def test_a_library_with_a_broken_arbitration_is_refused_the_exact_mode():
@@ -60,5 +67,10 @@ def test_a_library_with_a_broken_arbitration_is_refused_the_exact_mode():
     d, stderr = _child(lib)
     assert d["check"]["state"] == 2, d
     assert "refused" in d["err"] and "refused" in stderr, (d, stderr[-500:])
+    # ... by EVERY family of the check: each was reached, and each saw costs that differ from the fp64 mode's
+    fam = d["check"]["report"]["families"]
+    assert len(fam) == 15
+    for f in fam:
+        assert f["state"] == "refused" and f["launched"] == f["instantiation"] and f["mismatched"] > 0, f
     # ... and what it returns for an exact-mode request is the fp64 mode's result, from the fp64 kernel: nothing arbitrated
     assert d["equal"] and d["arbitrated"] == 0, d
