@@ -23,6 +23,10 @@ const char* ndtpso_slam_last_error(void);
 /* number of failed (skipped) device calls since start-up or the last ndtpso_slam_clear_error() */
 unsigned long ndtpso_slam_error_count(void);
 void ndtpso_slam_clear_error(void);
+/* not an error, but worth a node's attention: alignments that ran on a cluster of workgroups whose members were not scheduled
+ * together (device shared with other work, more streams than hardware queues), hit the exchange's bounded wait (20 ms) and
+ * were redone on one workgroup -- same pose, a latency spike.  Process-wide, since start-up. */
+unsigned long ndtpso_slam_cluster_timeouts(void);
 /* creates the calling thread's device context now instead of at its first frame operation.  Every host thread that uses
  * frames gets a context of its own (stream, workspaces, staged table): frames used by different threads run concurrently on
  * the device.  A frame belongs to the context of the thread that first used it and may be handed to another thread (its

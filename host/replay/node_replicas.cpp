@@ -14,6 +14,7 @@
 //   with more the hardware scheduler time-slices the queues and a cluster's workgroups begin to wait milliseconds for each
 //   other -- 16 replicas 14 k scans/s on 16 queues, 32 replicas 9 k on 16 and 7 k on 24) before the runtime starts.
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -21,6 +22,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include <sys/resource.h>
 
 #include "ndtpso_slam/core.h"
 #include "ndtpso_slam/ndtframe.h"
@@ -59,7 +62,9 @@ int main(int argc, char** argv) {
   std::atomic<int> ready{0};
   std::atomic<bool> go{false};
   std::vector<std::vector<double>> per_scan_ms((size_t)R);
+  std::vector<std::vector<std::array<double, 4>>> parts((size_t)R);  // diagnostics: start (ms since the clock started), loadLaser, align, update
   std::vector<int> failed((size_t)R, 0);
+  std::vector<double> between_ms((size_t)R, 0.);  // time between a scan's end and the next one's start (frame re-allocation, :228-230)
   std::vector<std::thread> threads;
   std::chrono::steady_clock::time_point t_start;
   for (int r = 0; r < R; ++r)
@@ -73,20 +78,29 @@ int main(int argc, char** argv) {
       NDTFrame* current_frame = new NDTFrame(initial_pose, frame_size, frame_size, cell_side, false);             // :73
       Vector3d previous_pose = initial_pose, current_pose = initial_pose;
       std::vector<float> ranges((size_t)n_beams);
+      std::chrono::steady_clock::time_point t_prev_end{};
       for (int k = 0; k < n_scans; ++k) {
         if (k == warm) {  // everybody's buffers exist: meet, start the clock
-          ++ready;
-          while (!go.load()) std::this_thread::yield();
+          ++ready;  // (asleep, not spinning: R threads in a yield loop spend a control group's CPU quota, and the period's
+          while (!go.load()) std::this_thread::sleep_for(std::chrono::microseconds(200));  // throttle then falls on the first timed scans)
         }
         std::copy(all.begin() + (size_t)k * n_beams, all.begin() + (size_t)(k + 1) * n_beams, ranges.begin());
         const auto t0 = std::chrono::steady_clock::now();
+        if (k > warm && k > 1) between_ms[(size_t)r] += std::chrono::duration<double, std::milli>(t0 - t_prev_end).count();
         current_frame->loadLaser(ranges, amin, ainc, rmax);                                                         // :186
+        const auto ta = std::chrono::steady_clock::now();
         current_pose = k == 0 ? previous_pose : ref_frame->align(previous_pose, current_frame);                     // :188-194
+        const auto tb = std::chrono::steady_clock::now();
         if (k > 0 && !ref_frame->lastAlignOk()) ++failed[(size_t)r];
         previous_pose = current_pose;
         ref_frame->update(current_pose, current_frame);                                                             // :198
         const auto t1 = std::chrono::steady_clock::now();
-        if (k >= warm && k > 0) per_scan_ms[(size_t)r].push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t_prev_end = t1;
+        if (k >= warm && k > 0) {
+          per_scan_ms[(size_t)r].push_back(std::chrono::duration<double, std::milli>(t1 - t0).count());
+          auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+          parts[(size_t)r].push_back({ms(t_start, t0), ms(t0, ta), ms(ta, tb), ms(tb, t1)});
+        }
         if (out) std::fprintf(out, "%d %.17g %.17g %.17g\n", k, current_pose.x(), current_pose.y(), current_pose.z());
         delete current_frame;                                                                                       // :228-230
         current_frame = new NDTFrame(initial_pose, frame_size, frame_size, frame_size, false);
@@ -95,16 +109,35 @@ int main(int argc, char** argv) {
       delete ref_frame;
       if (out) std::fclose(out);
     });
-  while (ready.load() < R) std::this_thread::yield();
+  while (ready.load() < R) std::this_thread::sleep_for(std::chrono::microseconds(200));
+  std::this_thread::sleep_for(std::chrono::milliseconds(150));  // (a fresh quota period for everybody)
+  rusage ru0;
+  getrusage(RUSAGE_SELF, &ru0);
   t_start = std::chrono::steady_clock::now();
   go = true;
   for (auto& t : threads) t.join();
   const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+  rusage ru1;
+  getrusage(RUSAGE_SELF, &ru1);
+  auto secs = [](const timeval& a, const timeval& b) { return (double)(b.tv_sec - a.tv_sec) + 1e-6 * (double)(b.tv_usec - a.tv_usec); };
+  const double cpu_user = secs(ru0.ru_utime, ru1.ru_utime), cpu_sys = secs(ru0.ru_stime, ru1.ru_stime);
   std::vector<double> every;
   int n_failed = 0;
   for (int r = 0; r < R; ++r) {
     every.insert(every.end(), per_scan_ms[(size_t)r].begin(), per_scan_ms[(size_t)r].end());
     n_failed += failed[(size_t)r];
+  }
+  if (std::getenv("NODE_REPLICAS_SLOWEST")) {  // diagnostics: the slowest scans, with replica and scan number
+    std::vector<std::pair<double, std::pair<int, int>>> slow;
+    for (int r = 0; r < R; ++r)
+      for (size_t i = 0; i < per_scan_ms[(size_t)r].size(); ++i) slow.push_back({per_scan_ms[(size_t)r][i], {r, (int)i + std::max(warm, 1)}});
+    std::sort(slow.begin(), slow.end(), [](const auto& a, const auto& b) { return a.first > b.first; });
+    for (size_t i = 0; i < std::min<size_t>(slow.size(), 24); ++i)
+    {
+      const auto& q = parts[(size_t)slow[i].second.first][(size_t)(slow[i].second.second - std::max(warm, 1))];
+      std::fprintf(stderr, "slow: %.3f ms replica %d scan %d  at %.2f ms: loadLaser %.3f align %.3f update %.3f\n", slow[i].first,
+                   slow[i].second.first, slow[i].second.second, q[0], q[1], q[2], q[3]);
+    }
   }
   std::sort(every.begin(), every.end());
   double mean = 0.;
@@ -113,8 +146,9 @@ int main(int argc, char** argv) {
   const double p95 = every.empty() ? 0. : every[(size_t)(0.95 * (every.size() - 1))];
   std::printf("{\"replicas\": %d, \"timed_scans_per_replica\": %d, \"wall_s\": %.6f, \"aggregate_scans_per_s\": %.1f, "
               "\"ms_per_scan_mean\": %.4f, \"ms_per_scan_p95\": %.4f, \"ms_per_scan_max\": %.4f, \"failed_alignments\": %d, "
-              "\"device_errors\": %lu}\n",
+              "\"device_errors\": %lu, \"cluster_timeouts\": %lu, \"host_cpus_busy_user\": %.2f, \"host_cpus_busy_sys\": %.2f, \"ms_between_scans_mean\": %.4f}\n",
               R, n_scans - warm, wall, (double)R * (n_scans - warm) / wall, mean, p95, every.empty() ? 0. : every.back(), n_failed,
-              ndtpso_slam_error_count());
+              ndtpso_slam_error_count(), ndtpso_slam_cluster_timeouts(), cpu_user / wall, cpu_sys / wall,
+              [&] { double t = 0.; for (double v : between_ms) t += v; return t / std::max(1., (double)R * (n_scans - warm - 1)); }());
   return 0;
 }

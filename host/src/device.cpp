@@ -300,6 +300,10 @@ const char* ndtpso_slam_last_error(void) {
   return copy.c_str();
 }
 unsigned long ndtpso_slam_error_count(void) { return ndtpso_host::g_err_count.load(); }
+unsigned long ndtpso_slam_cluster_timeouts(void) {
+  uint64_t v[1] = {0};
+  return ndtpso_process_counters(v, 1) == NDTPSO_OK ? (unsigned long)v[0] : 0ul;
+}
 void ndtpso_slam_clear_error(void) {
   std::lock_guard<std::mutex> lock(ndtpso_host::g_err_mutex);
   ndtpso_host::g_last_error.clear();

@@ -118,6 +118,15 @@ const char *ndtpso_last_error(const ndtpso_ctx *ctx);
 /* hipStream_t to enqueue on (NULL = the context's own stream) */
 int ndtpso_set_stream(ndtpso_ctx *ctx, void *hip_stream);
 int ndtpso_synchronize(ndtpso_ctx *ctx);
+/* Process-wide telemetry of the single-alignment path (ndtpso_align, ndtpso_map_align -- the live node, or R replicas of it on
+ * R host threads): out[0] alignments whose cluster of workgroups was not co-resident, ran into the exchange's bounded wait and
+ * was redone on one workgroup (a latency spike each: a device shared with other work, or more streams than hardware queues);
+ * out[1] waits for a kernel's result that slept between looks instead of spinning (more waiting threads than half the CPUs
+ * the process may use: affinity mask cut by the control group's quota); out[2] that CPU budget; out[3] threads waiting now;
+ * out[4] alignments kept on ONE workgroup because 16 (NDTPSO_CLUSTER_MAX_INFLIGHT) were already in flight in the process -- more
+ * clusters than the device's hardware queues run side by side would wait for each other.  n: how many to write (1 .. 5).  The reference has nothing of the kind (single-threaded caller,
+ * ndtpso_slam_node.cpp:182). */
+int ndtpso_process_counters(uint64_t *out, int n);
 /* Batches in flight.  depth 1 (default): every call is enqueued on the context's stream, one after the other.
  * depth 2: consecutive ndtpso_align_pairs_dev calls (batches of more pairs than half the device's compute units) run
  * on two internal streams with their own workspaces, so that the next batch's workgroups fill the compute units the

@@ -116,7 +116,7 @@ EXPORTS = [
     "ndtpso_shard_range", "ndtpso_align_pairs_sharded", "ndtpso_align_pairs_sharded_dev", "ndtpso_shard_last_timing",
     "ndtpso_shard_gathered", "ndtpso_shard_group_describe", "ndtpso_shard_verify_gather",
     "ndtpso_shard_last_gather_device_us",
-    "ndtpso_selftest_exp", "ndtpso_device_math", "ndtpso_exact_check", "ndtpso_exact_check_report",
+    "ndtpso_selftest_exp", "ndtpso_device_math", "ndtpso_exact_check", "ndtpso_exact_check_report", "ndtpso_process_counters",
 ]
 
 _lib = None
@@ -196,6 +196,7 @@ def load(build_if_missing: bool = True):
     L.ndtpso_device_math.argtypes = [vp, C.c_int, dp, C.c_uint32, dp, dp]
     L.ndtpso_exact_check.argtypes = [vp, C.POINTER(C.c_int), up, up, dp]
     L.ndtpso_exact_check_report.argtypes = [vp, C.c_char_p, C.c_uint32]
+    L.ndtpso_process_counters.argtypes = [C.POINTER(C.c_uint64), C.c_int]
     L.ndtpso_points_create.argtypes = [vp, C.c_uint32, C.POINTER(vp)]
     L.ndtpso_points_destroy.argtypes = [vp]
     L.ndtpso_points_destroy.restype = None
@@ -567,6 +568,16 @@ class ShardGroup:
         per, call = np.zeros((G, 3)), np.zeros(3)
         self._lib.ndtpso_shard_last_timing(self._h, _p(per, C.c_double), _p(call, C.c_double))
         return per, call
+
+
+def process_counters() -> dict:
+    """ndtpso_process_counters: cluster timeouts, waits that slept, the CPU budget, threads waiting now."""
+    v = (C.c_uint64 * 5)()
+    rc = load().ndtpso_process_counters(v, 5)
+    if rc != OK:
+        raise NdtpsoError(rc, "ndtpso_process_counters")
+    return {"cluster_timeouts": int(v[0]), "polite_waits": int(v[1]), "cpu_budget": int(v[2]), "waiting_now": int(v[3]),
+            "alignments_kept_on_one_workgroup": int(v[4])}
 
 
 def shard_range(n_pairs: int, rank: int, n_devices: int):

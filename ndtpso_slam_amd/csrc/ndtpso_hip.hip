@@ -15,6 +15,10 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
+#include <sys/prctl.h>
+#include <time.h>
+
 #include "../../include/ndtpso_hip.h"
 
 using namespace ndtpso;
@@ -1848,12 +1852,81 @@ static inline void cpu_relax() {
 #endif
 }
 
+// How many CPUs this process may really keep busy: the affinity mask cut by the control group's quota (a container shows all of
+// the box's logical CPUs and gives the process a fraction of them: the GPU boxes of this project 256 and 16).
+static int host_cpu_budget() {
+  static const int budget = [] {
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0) n = std::min(n, (int)CPU_COUNT(&set));
+    double quota = 0.;
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota us | max> <period us>"
+      char q[64];
+      double per = 0.;
+      if (std::fscanf(f, "%63s %lf", q, &per) == 2 && q[0] != 'm' && per > 0.) quota = std::atof(q) / per;
+      std::fclose(f);
+    } else {
+      double q = -1., per = 0.;
+      if (FILE* fq = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+        if (std::fscanf(fq, "%lf", &q) != 1) q = -1.;
+        std::fclose(fq);
+      }
+      if (FILE* fp = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+        if (std::fscanf(fp, "%lf", &per) != 1) per = 0.;
+        std::fclose(fp);
+      }
+      if (q > 0. && per > 0.) quota = q / per;
+    }
+    if (quota >= 1.) n = std::min(n, (int)quota);
+    if (const char* e = std::getenv("NDTPSO_CPU_BUDGET")) n = std::atoi(e);  // (tests)
+    return std::max(1, n);
+  }();
+  return budget;
+}
+static std::atomic<int> g_word_waiters{0};              // host threads inside wait_pinned_word right now
+static std::atomic<unsigned long long> g_polite_waits{0};    // waits that slept instead of spinning
+static std::atomic<unsigned long long> g_cluster_timeouts{0};  // alignments whose cluster ran into the bounded wait
+static std::atomic<int> g_aligns_in_flight{0};                 // single alignments between launch and result, process-wide
+static std::atomic<unsigned long long> g_crowded_aligns{0};    // alignments kept on one workgroup because too many were in flight
+
+// One waiter spins: the word arrives a microsecond after the kernel wrote it, and a robot's one matcher thread has a CPU to
+// itself.  MANY waiters must not: R replicas of the live sequence are R threads in this loop at once, and past the CPUs the
+// process may use (host_cpu_budget) spinning threads take the time slices of the threads that have launches to make -- under a
+// control group's quota worse than that: 32 threads spinning on a quota of 16 CPUs spend it in half of every 100 ms period and
+// the WHOLE process is frozen for the other half (the 50 - 110 ms stalls and the fall of the aggregate rate beyond 16 replicas
+// that round 5 put down to the hardware queues).  So: with more waiters than half the budget, a waiter sleeps between looks
+// (20 us, the thread's timer slack set to 1 us: ~25 us per look) -- a scan of 350 us hears of its pose a dozen microseconds later
+// and the process's CPU time goes to the threads that launch.  NDTPSO_WAIT=spin / sleep overrides the choice.
 static int wait_pinned_word(ndtpso_ctx* c, const uint32_t* word, uint32_t want) {
+  static const int policy = [] {
+    const char* e = std::getenv("NDTPSO_WAIT");
+    return !e ? 0 : (e[0] == 's' && e[1] == 'p' ? 1 : (e[0] == 's' && e[1] == 'l' ? 2 : 0));
+  }();
+  struct Count {
+    Count() { g_word_waiters.fetch_add(1, std::memory_order_relaxed); }
+    ~Count() { g_word_waiters.fetch_sub(1, std::memory_order_relaxed); }
+  } counted;
   std::chrono::steady_clock::time_point last{};
+  bool slept = false;
   for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return NDTPSO_OK;
-    cpu_relax();
-    if ((spins & 4095u) == 0) {
+    const bool crowded = policy == 2 || (policy == 0 && 2 * g_word_waiters.load(std::memory_order_relaxed) > host_cpu_budget());
+    if (crowded && spins > 64u) {  // (the first looks spin: a result that is all but there)
+      static thread_local bool slack_set = false;
+      if (!slack_set) {
+        slack_set = true;
+        (void)prctl(PR_SET_TIMERSLACK, 1000UL, 0UL, 0UL, 0UL);
+      }
+      if (!slept) {
+        slept = true;
+        g_polite_waits.fetch_add(1, std::memory_order_relaxed);
+      }
+      const timespec ts{0, 20000};
+      (void)nanosleep(&ts, nullptr);
+    } else {
+      cpu_relax();
+    }
+    if ((spins & 4095u) == 0 || (crowded && (spins & 255u) == 0)) {
       const auto now = std::chrono::steady_clock::now();
       if (last.time_since_epoch().count() == 0) last = now;
       if (now - last < std::chrono::milliseconds(10)) continue;
@@ -1865,6 +1938,14 @@ static int wait_pinned_word(ndtpso_ctx* c, const uint32_t* word, uint32_t want) 
       return fail(c, NDTPSO_E_HIP, "kernel ended without reporting");
     }
   }
+}
+
+int ndtpso_process_counters(uint64_t* out, int n) {
+  if (!out || n < 1) return NDTPSO_E_ARG;
+  const uint64_t v[5] = {g_cluster_timeouts.load(), g_polite_waits.load(), (uint64_t)host_cpu_budget(), (uint64_t)g_word_waiters.load(),
+                         g_crowded_aligns.load()};
+  for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+  return NDTPSO_OK;
 }
 
 static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_config* cfg, uint32_t seed, bool have_table,
@@ -1898,6 +1979,24 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
   if (allow_cluster && c->cluster_penalty > 0) {
     --c->cluster_penalty;
     allow_cluster = false;
+  }
+  // A cluster's workgroups wait for each other, which is safe only while every cluster in flight is resident: alignments launched
+  // from more host threads than the device has hardware queues to run side by side (16; a process's streams share them, and
+  // streams on one queue take turns) are the case in which some cluster's workgroups sit behind another stream's kernel while
+  // their siblings spin towards the exchange's bounded wait.  Past that many alignments in flight in the process, the next one
+  // runs on ONE workgroup: half as fast, and it waits for nobody.  (NDTPSO_CLUSTER_MAX_INFLIGHT, default 16.)
+  static const int max_clusters_in_flight = [] {
+    const char* e = std::getenv("NDTPSO_CLUSTER_MAX_INFLIGHT");
+    return e ? std::max(0, std::atoi(e)) : 16;
+  }();
+  struct InFlight {
+    InFlight() : before(g_aligns_in_flight.fetch_add(1, std::memory_order_relaxed)) {}
+    ~InFlight() { g_aligns_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+    int before;
+  } in_flight;
+  if (allow_cluster && in_flight.before >= max_clusters_in_flight) {
+    allow_cluster = false;
+    g_crowded_aligns.fetch_add(1, std::memory_order_relaxed);
   }
   cluster_shape(cfg->population, true, allow_cluster, &K, &cw);
   const unsigned long long seq = ++c->align_issued;
@@ -1985,6 +2084,7 @@ static int align_once(ndtpso_ctx* c, const AlignSrc& src, const ndtpso_pso_confi
     AlignStats st;
     std::memcpy(&st, host + 4, sizeof(st));
     if (st.status & kStatusClusterTimeout) {  // the cluster was not co-resident (device shared with other work): one workgroup,
+      g_cluster_timeouts.fetch_add(1, std::memory_order_relaxed);
       static bool logged = false;
       if (!logged) {
         logged = true;

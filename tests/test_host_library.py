@@ -500,11 +500,14 @@ def test_frame_api_random_operation_sequences(tmp_path, oracle, seed, frame_w, f
 
 
 @pytest.mark.gpu
-def test_replicas_on_threads_of_one_process_reproduce_their_single_process_logs(tmp_path):
+@pytest.mark.parametrize("R", [4, 32])
+def test_replicas_on_threads_of_one_process_reproduce_their_single_process_logs(tmp_path, R):
     """SURVEY 8(b) "one context per host thread", 8(e) "replicas only": host/replay/node_replicas.cpp runs R node sequences on
     R host threads of ONE process -- the library gives each thread a device context and stream of its own, and
     ndtpso_slam_thread_srand a random stream of its own -- and replica r's pose log must be, byte for byte, what
-    `node_replay ... seed + r` prints when it has the process to itself."""
+    `node_replay ... seed + r` prints when it has the process to itself.  R = 32: more replicas than the device has hardware
+    queues to run side by side -- alignments beyond sixteen in flight stay on one workgroup, waiting threads sleep between looks
+    (round 6) --, same logs, no alignment left to the bounded wait."""
     from ndtpso_slam_amd import synth
     _build()
     n_scans, P, I, seed, cs = 16, 30, 50, 11, 0.5
@@ -514,7 +517,6 @@ def test_replicas_on_threads_of_one_process_reproduce_their_single_process_logs(
         np.array([n_scans, synth.N_BEAMS], dtype=np.int32).tofile(f)
         np.array([synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX], dtype=np.float32).tofile(f)
         ranges.tofile(f)
-    R = 4
     alone = []
     for r in range(R):
         alone.append(subprocess.check_output([os.path.join(HOST, "replay", "node_replay"), str(path), str(FRAME_M), str(cs), str(I), str(P),
@@ -527,6 +529,7 @@ def test_replicas_on_threads_of_one_process_reproduce_their_single_process_logs(
                                        str(seed), str(R), prefix], text=True)
         info = json.loads(out.strip().splitlines()[-1])
         assert info["replicas"] == R and info["failed_alignments"] == 0 and info["device_errors"] == 0, info
+        assert info["cluster_timeouts"] == 0, info
         for r in range(R):
             with open("%s.%d.poses" % (prefix, r)) as f:
                 assert f.read() == alone[r], "replica %d's log differs from its single-process log" % r
