@@ -32,6 +32,9 @@ unsigned long ndtpso_slam_cluster_timeouts(void);
  * the device.  A frame belongs to the context of the thread that first used it and may be handed to another thread (its
  * calls are then serialised against that context's other users). */
 void ndtpso_slam_device_init(void);
+/* device contexts the process holds (one per host thread that has used frames; a thread that has ended leaves its context to
+ * the next one that needs it, once no frame is bound to it) */
+unsigned long ndtpso_slam_context_count(void);
 /* The reference draws its PSO's random numbers from the process-wide std::rand() (Eigen's Random(), core.cpp:14,84): ONE
  * stream for every thread, so two matchers in one process disturb each other's streams -- in the reference as here.
  * ndtpso_slam_thread_srand(seed) gives the CALLING THREAD a private generator instead (glibc's own algorithm on private

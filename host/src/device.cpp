@@ -19,6 +19,8 @@ struct Ctx {
   std::recursive_mutex mu;
   const void* table_owner = nullptr;
   std::vector<std::pair<ndtpso_points*, uint32_t>> scan_pool;
+  std::atomic<int> frames{0};        // frames bound to this context (NDTFrame::dev() ... ~NDTFrame)
+  std::atomic<bool> orphan{false};   // the thread it was made for has ended
 };
 
 namespace {
@@ -27,6 +29,16 @@ std::vector<Ctx*> g_registry;  // every context ever made (they outlive their th
 bool g_alive = false, g_atexit = false;
 thread_local Ctx* t_own = nullptr;     // this thread's context
 thread_local Ctx* t_active = nullptr;  // the innermost Use's
+// A context outlives its thread while frames are bound to it.  One whose thread has ended AND that no frame refers to is taken
+// over by the next thread that needs one (a process that serves requests on short-lived threads would otherwise gather a
+// stream, workspaces and pinned buffers per thread it ever had, released only at exit).
+struct Owner {
+  Ctx* x = nullptr;
+  ~Owner() {
+    if (x) x->orphan.store(true);
+  }
+};
+thread_local Owner t_owner;
 
 // error state of the library (ndtpso_slam/status.h)
 std::mutex g_err_mutex;
@@ -60,8 +72,32 @@ void record_error(const char* what, int rc, const char* text) {
 }
 }  // namespace
 
+unsigned long context_count() {
+  std::lock_guard<std::mutex> lock(g_registry_mutex);
+  return (unsigned long)g_registry.size();
+}
+void bind_frame(Ctx* x) {
+  if (x) x->frames.fetch_add(1);
+}
+void unbind_frame(Ctx* x) {
+  if (x) x->frames.fetch_sub(1);
+}
+
 Ctx* thread_ctx() {
   if (t_own) return t_own;
+  {
+    std::lock_guard<std::mutex> lock(g_registry_mutex);
+    for (Ctx* q : g_registry)
+      if (q->c && q->frames.load() == 0 && q->orphan.exchange(false)) {  // (exchange: two new threads never adopt the same one)
+        if (q->frames.load() != 0) {  // bound in the meantime by a frame handed on from its old thread: leave it be
+          q->orphan.store(true);
+          continue;
+        }
+        t_own = q;
+        t_owner.x = q;
+        return q;
+      }
+  }
   Ctx* x = new Ctx();
   int dev = 0;
   if (const char* e = std::getenv("NDTPSO_DEVICE")) dev = std::atoi(e);
@@ -91,6 +127,7 @@ Ctx* thread_ctx() {
     }
   }
   t_own = x;
+  t_owner.x = x;
   return x;
 }
 
@@ -267,7 +304,9 @@ int score_mode() {
 
 bool check(int rc, const char* what) {
   if (rc == NDTPSO_OK) return true;
-  ndtpso_ctx* c = active_ctx()->c;
+  // (the error text of whatever context is at hand: reporting a failure must not create one)
+  Ctx* x = t_active ? t_active : t_own;
+  ndtpso_ctx* c = x ? x->c : nullptr;
   record_error(what, rc, c ? ndtpso_last_error(c) : "no device context");
   return false;
 }
@@ -300,6 +339,7 @@ const char* ndtpso_slam_last_error(void) {
   return copy.c_str();
 }
 unsigned long ndtpso_slam_error_count(void) { return ndtpso_host::g_err_count.load(); }
+unsigned long ndtpso_slam_context_count(void) { return ndtpso_host::context_count(); }
 unsigned long ndtpso_slam_cluster_timeouts(void) {
   uint64_t v[1] = {0};
   return ndtpso_process_counters(v, 1) == NDTPSO_OK ? (unsigned long)v[0] : 0ul;

@@ -20,6 +20,10 @@ namespace ndtpso_host {
 // to another thread therefore still works, serialised against its context's other users.
 struct Ctx;
 Ctx* thread_ctx();                    // the calling thread's own context, created on HIP device $NDTPSO_DEVICE (default 0) at first use
+                                      // (or taken over from a thread that has ended, once no frame is bound to it any more)
+void bind_frame(Ctx* ctx);            // a frame now refers to the context / no longer does: a context is recycled only at zero
+void unbind_frame(Ctx* ctx);
+unsigned long context_count();        // contexts ever made and still held
 class Use {
  public:
   explicit Use(Ctx* ctx);             // nullptr: the calling thread's own

@@ -68,15 +68,20 @@ NDTFrame::NDTFrame(Vector3d trans, unsigned short width_, unsigned short height_
 }
 
 ndtpso_host::Ctx* NDTFrame::dev() const {
-  if (!s_dev) s_dev = ndtpso_host::thread_ctx();
+  if (!s_dev) {
+    s_dev = ndtpso_host::thread_ctx();
+    ndtpso_host::bind_frame(s_dev);
+  }
   return s_dev;
 }
 
 NDTFrame::~NDTFrame() {
-  if (!d_scan_ && !d_map_) return;
-  ndtpso_host::Use use(dev());
-  if (d_scan_) ndtpso_host::release_scan(d_scan_, d_scan_cap_);
-  if (d_map_ && ndtpso_host::alive()) ndtpso_map_destroy(d_map_);
+  if (d_scan_ || d_map_) {
+    ndtpso_host::Use use(dev());
+    if (d_scan_) ndtpso_host::release_scan(d_scan_, d_scan_cap_);
+    if (d_map_ && ndtpso_host::alive()) ndtpso_map_destroy(d_map_);
+  }
+  if (s_dev) ndtpso_host::unbind_frame(s_dev);
 }
 
 // ---- resident mode: the frame's state lives on the device (include/ndtpso_hip.h, ndtpso_map_* / ndtpso_points_*) ----
@@ -284,6 +289,7 @@ void NDTFrame::addScan(const Vector3d& pose, const vector<float>& laser_data, co
   ndtpso_host::Use use(dev());  // (the scratch frame below binds to the active context: this frame's)
   NDTFrame scan(Vector3d::Zero(), width, height, (double)std::max(width, height), false, s_config);  // ndtpso_slam_node.cpp:229-230
   scan.s_dev = dev();
+  ndtpso_host::bind_frame(scan.s_dev);
   scan.loadLaser(laser_data, min_angle, angle_increment, max_range);
   update(pose, &scan);
 }

@@ -1,7 +1,7 @@
 """Is a kernel's machine code the same in two builds of the library?  Disassembles ONE kernel (by a substring of its demangled
 name) out of each library's gfx950 code object and compares the instruction streams (addresses and symbol offsets aside).
 
-    python scripts/kernel_isa_diff.py a.so b.so "k_align_pairs<0, 3, false, true, true, 0, false>"
+    python scripts/kernel_isa_diff.py a.so b.so "k_align_pairs<0, 3, false, true, true, 0, false>" [name in b.so, if it differs]
 """
 import difflib
 import os
@@ -41,7 +41,8 @@ def kernel_text(lib, want):
 
 def main():
     a, b, want = sys.argv[1], sys.argv[2], sys.argv[3]
-    ta, tb = kernel_text(a, want), kernel_text(b, want)
+    want_b = sys.argv[4] if len(sys.argv) > 4 else want   # (a template parameter that changed its type prints differently)
+    ta, tb = kernel_text(a, want), kernel_text(b, want_b)
     print("%s: %d instructions   %s: %d instructions" % (os.path.basename(a), len(ta), os.path.basename(b), len(tb)))
     if ta == tb:
         print("identical")

@@ -31,6 +31,7 @@ def build():
 
 
 CONFIGS = {"config3": dict(B=512, P=70, I=70, beams=1081, cs=0.5, seed=2024, launches=12, warm=6),
+           "beams361": dict(B=512, P=70, I=70, beams=361, cs=0.5, seed=2024, launches=12, warm=6),   # (a short scan: where does the time go?)
            "config5": dict(B=256, P=2048, I=200, beams=2048, cs=0.25, seed=21, launches=3, warm=1)}
 
 

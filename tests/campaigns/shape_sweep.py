@@ -1,6 +1,6 @@
 """Throughput of the fused pairs kernel OFF the benchmark's shapes (512 pairs, 70 x 70 PSO, every score mode asked for).
 
-    python tests/campaigns/shape_sweep.py [--out profiles/r05_shape_sweep.json] [--modes exact,f64] [--quick]
+    python tests/campaigns/shape_sweep.py [--out profiles/r06_shape_sweep.json] [--modes exact,f64] [--quick]
 
 For beams in {361, 541, 721, 1080, 1081, 1441, 2048} x cell side in {0.25, 0.3, 0.5, 1.0} m x frame in {60, 100, 300} m
 (100 m: the node's default, include/ndtpso_slam_node.hpp:26; 300 m: launch/scan.launch:14): alignments per second (HIP
@@ -27,12 +27,14 @@ DEV = (0.1, 0.1, 3.1415e-3)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_shape_sweep.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_shape_sweep.json"))
     ap.add_argument("--modes", default="exact")
     ap.add_argument("--pairs", type=int, default=512)
     ap.add_argument("--launches", type=int, default=8)
     ap.add_argument("--oracle-pairs", type=int, default=8)
     ap.add_argument("--beams", default="", help="comma-separated subset of the beam counts")
+    ap.add_argument("--cells", default="", help="comma-separated subset of the cell sides")
+    ap.add_argument("--frames", default="", help="comma-separated subset of the frame sizes")
     ap.add_argument("--quick", action="store_true", help="beams {541, 1081, 2048} x cells {0.3, 0.5} x frames {60, 100}")
     args = ap.parse_args()
     import torch
@@ -49,6 +51,10 @@ def main():
     beams_l, cells_l, frames_l = (BEAMS, CELLS, FRAMES) if not args.quick else ([541, 1081, 2048], [0.3, 0.5], [60, 100])
     if args.beams:
         beams_l = [int(b) for b in args.beams.split(",")]
+    if args.cells:
+        cells_l = [float(b) for b in args.cells.split(",")]
+    if args.frames:
+        frames_l = [int(b) for b in args.frames.split(",")]
     rows = []
     for nb in beams_l:
         p = synth.make_pairs(B, n_beams=nb, seed=2024)

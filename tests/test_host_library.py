@@ -533,3 +533,16 @@ def test_replicas_on_threads_of_one_process_reproduce_their_single_process_logs(
         for r in range(R):
             with open("%s.%d.poses" % (prefix, r)) as f:
                 assert f.read() == alone[r], "replica %d's log differs from its single-process log" % r
+
+
+@pytest.mark.gpu
+def test_short_lived_threads_recycle_their_device_contexts():
+    """host/replay/thread_churn.cpp: forty host threads one after the other, each with a frame of its own aligned against a
+    frame of the main thread's.  Every thread needs a context (stream, workspaces, pinned buffers); one whose thread has ended
+    and that no frame is bound to is taken over by the next thread instead of piling up until exit."""
+    import json
+    _build()
+    out = subprocess.check_output([os.path.join(HOST, "replay", "thread_churn"), "40"], text=True)
+    d = json.loads(out.strip().splitlines()[-1])
+    assert d["threads"] == 40 and d["failed"] == 0 and d["device_errors"] == 0, d
+    assert d["contexts"] <= 3, d      # the main thread's and one or two that go round
