@@ -26,6 +26,7 @@ ndtpso_pso_config to_abi(const PSOConfig& c) {
   o.w_damping = c.coeff.w_dumping;
   return o;
 }
+thread_local bool t_last_align_failed = false;  // the calling thread's most recent align() / pso_optimization could not run
 constexpr uint32_t kScanCapacity = 4096;  // points of a pooled device scan buffer (grown for longer scans)
 
 uint64_t map_pool_bytes(unsigned num_cells) {
@@ -239,7 +240,9 @@ void NDTFrame::update(Vector3d trans, NDTFrame* const new_frame) {
   // lastAlignOk() says so), and a scan merged at an unrefined guess would corrupt the map for good.  So an update() that
   // follows a failed align() against this frame is REFUSED -- the scan is dropped, counted (updatesRefused()) and recorded
   // in the error state (ndtpso_slam/status.h) -- and the next successful align() clears the condition.
-  if (!s_last_align_ok) {
+  // ... and so is an update() of ANY frame by the thread whose most recent align() failed: the node merges the same pose into
+  // its global map as well (global_map_->update, ndtpso_slam_node.cpp:202), a frame that never aligns and so never learns of it.
+  if (!s_last_align_ok || t_last_align_failed) {
     ++s_updates_refused;
     ndtpso_host::check(NDTPSO_E_STATE, "update after a failed align (scan not merged)");
     return;
@@ -509,6 +512,7 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
     if (ok) built = true;
     if (tmp) ndtpso_host::release_scan(tmp, tmp_cap);
     s_last_align_ok = ok;
+    t_last_align_failed = !ok;
     return ok ? Vector3d(pose[0], pose[1], pose[2]) : guess;  // device fault: the initial guess, never a CPU estimate
   }
   if (!built) build();  // core.cpp:27-28 (lazy build inside cost_function)
@@ -523,6 +527,7 @@ Vector3d NDTFrame::optimize(const Vector3d& guess, const NDTFrame* new_frame, co
   double pose[3] = {g[0], g[1], g[2]};
   s_last_align_ok = table_ok && ndtpso_host::check(ndtpso_align(ndtpso_host::device(), xy.data(), (uint32_t)(xy.size() / 2), g, dv, &abi,
                                                                0u, draws.data(), ndtpso_host::score_mode(), pose, nullptr, nullptr), "align");
+  t_last_align_failed = !s_last_align_ok;
   if (!s_last_align_ok) return guess;
   return Vector3d(pose[0], pose[1], pose[2]);
 }
