@@ -768,7 +768,7 @@ def _roofline(stats, evals_nominal, kern_ms, algo_bytes, hbm_equiv_gbs, step_ms,
     # transform, 4 index, 2 differences, 9 quadratic form, 27 in the exponential's reduction and polynomial, 1 accumulate)
     f64 = score == "f64"
     FLOP_FP64, FLOP_FP32, FLOP_EXP = (51.0, 0.0, 0.0) if f64 else (16.0, 34.0, 1.0)
-    cands = ("r05_isa_mix_f64.json", "r04_isa_mix_f64.json") if f64 else ("r05_isa_mix.json", "r04_isa_mix.json", "r02_isa_mix.json")
+    cands = ("r06_isa_mix_f64.json", "r05_isa_mix_f64.json") if f64 else ("r06_isa_mix.json", "r05_isa_mix.json")
     mix_name = next((n for n in cands if _load_json(n)), cands[-1])
     mix = _load_json(mix_name)
     point_evals = float(stats["n_points"].astype(np.float64).sum()) * evals_nominal
@@ -817,8 +817,7 @@ def _pmc_traffic_bytes(f64=False):
     """HBM bytes per launch of the fused kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x 2 per the
     gfx950 correction in MI355X_MICROARCH.md, + WRITE_SIZE; separate --pmc runs, scripts/pmc.sh).  A profile of
     THIS workload measured on MI355X, not collected live (rocprofv3 cannot wrap the timed run); null if absent."""
-    names = ("r05_pmc_summary_f64.json",) if f64 else ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json",
-                                                       "r02_pmc_summary.json", "r01_pmc_summary.json")
+    names = ("r06_pmc_summary_f64.json", "r05_pmc_summary_f64.json") if f64 else ("r06_pmc_summary.json", "r05_pmc_summary.json")
     for name in names:
         d = _load_json(name)
         try:

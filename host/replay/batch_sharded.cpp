@@ -107,6 +107,11 @@ int main(int argc, char** argv) {
   }
   uint32_t flagged = 0;
   for (const ndtpso_align_stats& s : stats) flagged += NDTPSO_STATUS_FLAGS(s.status) ? 1u : 0u;
+  // what the group was and whether the collective demonstrably moved every shard's poses to every shard
+  ndtpso_shard_info info{};
+  int ranks_seen = 0;
+  (void)ndtpso_shard_group_describe(g, &info);
+  (void)ndtpso_shard_verify_gather(g, &ranks_seen);
   double up_max = 0, up_sum = 0, launch_max = 0;
   for (size_t d = 0; d < devices.size(); ++d) {
     up_max = std::max(up_max, per_dev[3 * d + 1]);
@@ -114,10 +119,12 @@ int main(int argc, char** argv) {
     launch_max = std::max(launch_max, per_dev[3 * d + 2]);
   }
   std::printf("{\"pairs\": %u, \"devices\": %zu, \"repetitions\": %d, \"best_call_s\": %.6f, \"alignments_per_s\": %.1f, "
-              "\"flagged\": %u, \"includes\": \"host-to-device scatter, the all-gather and the copy back\", "
+              "\"flagged\": %u, \"shards\": %d, \"ranks_seen\": %d, \"comm_ranks\": %d, \"rccl_version\": %d, \"gather\": \"%s\", "
+              "\"includes\": \"host-to-device scatter, the all-gather and the copy back\", "
               "\"host_us\": {\"uploads_slowest_device\": %.1f, \"uploads_all_devices_summed\": %.1f, \"launches_slowest_device\": %.1f, "
               "\"all_enqueued\": %.1f, \"collective_enqueue\": %.1f, \"call\": %.1f}}\n",
-              n, devices.size(), reps, best, n / best, flagged, up_max, up_sum, launch_max, call_us[0], call_us[1], call_us[2]);
+              n, devices.size(), reps, best, n / best, flagged, info.n_shards, ranks_seen, info.comm_ranks, info.rccl_version,
+              info.gather_kind ? "host-staged (test)" : "ncclAllGather (RCCL)", up_max, up_sum, launch_max, call_us[0], call_us[1], call_us[2]);
   ndtpso_shard_group_destroy(g);
   std::FILE* o = std::fopen(argv[2], "wb");
   if (!o) { std::perror(argv[2]); return 2; }

@@ -2,8 +2,8 @@
 floor that follows from it -- the `peak` of bench.py's roofline.
 
     python scripts/isa_mix.py [--lib ndtpso_slam_amd/lib/libndtpso_hip.so] [--kernel "k_align_pairs<0, 3, false, true, true, 0, false>"]
-                              [--ubench profiles/r02_ubench_valu.txt] [--out profiles/r02_isa_mix.json]
-                              [--dump profiles/r02_score_loop_isa.txt]
+                              [--ubench profiles/r06_ubench_valu.txt] [--out profiles/r06_isa_mix.json]
+                              [--dump profiles/r06_score_loop_isa.txt]
 
 What it does
   1. pulls the gfx950 code object out of the library's .hip_fatbin section (clang offload bundle) and disassembles it
@@ -184,9 +184,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--lib", default=os.path.join(ROOT, "ndtpso_slam_amd", "lib", "libndtpso_hip.so"))
     ap.add_argument("--kernel", default="k_align_pairs<0, 3, false, true, true, 0, false>")
-    ap.add_argument("--ubench", default=os.path.join(ROOT, "profiles", "r02_ubench_valu.txt"))
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_isa_mix.json"))
-    ap.add_argument("--dump", default=os.path.join(ROOT, "profiles", "r02_score_loop_isa.txt"))
+    ap.add_argument("--ubench", default=os.path.join(ROOT, "profiles", "r06_ubench_valu.txt"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_isa_mix.json"))
+    ap.add_argument("--dump", default=os.path.join(ROOT, "profiles", "r06_score_loop_isa.txt"))
     ap.add_argument("--marker", default="v_exp_f32", help="the instruction a four-chunk trip holds four of (fp64-score kernels: v_ldexp_f64, "
                     "the tail of the library exp)")
     ap.add_argument("--marker-span", type=int, default=8, help="the four lie within this many instructions of each other (fp64: 60)")

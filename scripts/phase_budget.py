@@ -3,7 +3,7 @@ diagnostic build of the library (-DNDTPSO_PHASE_BUDGET: every workgroup accounts
 real-time counter, contiguous marks -- ndtpso_kernels.hpp).
 
     python scripts/phase_budget.py --build                 # in the build container: hipcc the diagnostic library
-    python scripts/phase_budget.py [--score exact|f32] [--out profiles/r03_phase_budget.json]     # on the GPU box
+    python scripts/phase_budget.py [--score exact|f32] [--out profiles/r06_phase_budget.json]     # on the GPU box
 
 The budget of a launch:  kernel time (events) = dispatch offset (mean start of a workgroup after the first one)
 + mean workgroup duration (= the sum of its phases) + tail (the launch ends with its slowest workgroup).
@@ -91,7 +91,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--build", action="store_true")
     ap.add_argument("--score", default="exact", choices=["exact", "f32", "f64"])
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_phase_budget.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06_phase_budget.json"))
     ap.add_argument("--config", default="config3", choices=list(CONFIGS))
     ap.add_argument("--plain", action="store_true", help="(internal) time the shipped library and print the mean launch time")
     args = ap.parse_args()

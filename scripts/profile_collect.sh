@@ -32,6 +32,8 @@ cp $SRC/phase_budget.json ${P}_phase_budget.json
 cp $SRC/phase_budget_f32.json ${P}_phase_budget_f32.json
 cp $SRC/phase_budget_config5.json ${P}_phase_budget_config5.json
 [ -f $SRC/live/live_timeline.json ] && cp $SRC/live/live_timeline.json ${P}_live_timeline.json
+for f in phase_budget_361 bench_self_launched_rccl bench_sharded_capi_g1 bench_sharded_capi_virtual8 shape_sweep; do [ -f $SRC/$f.json ] && cp $SRC/$f.json ${P}_$f.json; done
+[ -f $SRC/live_replicas.txt ] && grep replicas $SRC/live_replicas.txt > ${P}_live_replicas.txt
 [ -f $SRC/verify_config3.json ] && python - <<PY
 import json
 out = {}
@@ -40,6 +42,12 @@ for w in ("config3", "config4", "random", "converged", "config5"):
         d = json.load(open("$SRC/verify_%s.json" % w))
         out[w] = {k: v for k, v in d.items() if k != "runs"}
         out[w]["runs"] = [{k: r[k] for k in ("pairs", "beams", "cs", "P", "I", "evaluations_checked", "points_checked", "max_err", "max_err_over_bound", "max_bound_over_half_tau", "max_err_over_half_tau", "points_binned_differently", "arbitrated_mean")} for r in d["runs"]]
+    except Exception as e:
+        out[w] = {"error": str(e)}
+for w in ("binning_config3_x400", "binning_random_x40"):
+    try:
+        d = json.load(open("$SRC/verify_%s.json" % w))
+        out[w] = {"points_checked": d["points_checked"], "binning": d["binning"], "launches_per_run": d["runs"][0].get("launches"), "runs": len(d["runs"])}
     except Exception as e:
         out[w] = {"error": str(e)}
 json.dump(out, open("${P}_margin_verification.json", "w"), indent=1)

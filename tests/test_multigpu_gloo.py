@@ -317,6 +317,7 @@ def test_cpp_batch_driver_on_all_devices(tmp_path, ctx):
     import json
     info = json.loads(r.stdout.strip().splitlines()[-1])
     assert info["pairs"] == 140 and info["devices"] >= 1 and info["flagged"] == 0
+    assert info["ranks_seen"] == info["shards"] == info["devices"] and info["gather"].startswith("ncclAllGather")
 
 
 def test_cpp_batch_driver_refuses_to_run_without_a_device(tmp_path):
