@@ -1883,6 +1883,31 @@ static int host_cpu_budget() {
   }();
   return budget;
 }
+// The control group may be shared with OTHER processes (two processes of sixteen replicas each are the best way to serve 32:
+// DESIGN 6) whose spinning threads this one cannot count -- but it can see their effect: cpu.stat's nr_throttled goes up whenever
+// the group ran out of quota in a period.  Looked at no more than every 50 ms, by whichever waiting thread gets there first; a
+// throttled period makes every wait of this process a polite one for the next two seconds.
+static std::atomic<long long> g_throttle_look_ns{0}, g_polite_until_ns{0}, g_throttled_seen{-1};
+static bool quota_is_biting() {
+  const long long now = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  long long last = g_throttle_look_ns.load(std::memory_order_relaxed);
+  if (now - last > 50000000LL && g_throttle_look_ns.compare_exchange_strong(last, now, std::memory_order_relaxed)) {
+    long long n = -1;
+    for (const char* path : {"/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"}) {
+      if (FILE* f = std::fopen(path, "r")) {
+        char key[64];
+        long long v;
+        while (std::fscanf(f, "%63s %lld", key, &v) == 2)
+          if (std::strcmp(key, "nr_throttled") == 0) n = v;
+        std::fclose(f);
+        break;
+      }
+    }
+    const long long before = g_throttled_seen.exchange(n, std::memory_order_relaxed);
+    if (n >= 0 && before >= 0 && n > before) g_polite_until_ns.store(now + 2000000000LL, std::memory_order_relaxed);
+  }
+  return now < g_polite_until_ns.load(std::memory_order_relaxed);
+}
 static std::atomic<int> g_word_waiters{0};              // host threads inside wait_pinned_word right now
 static std::atomic<unsigned long long> g_polite_waits{0};    // waits that slept instead of spinning
 static std::atomic<unsigned long long> g_cluster_timeouts{0};  // alignments whose cluster ran into the bounded wait
@@ -1907,10 +1932,12 @@ static int wait_pinned_word(ndtpso_ctx* c, const uint32_t* word, uint32_t want) 
     ~Count() { g_word_waiters.fetch_sub(1, std::memory_order_relaxed); }
   } counted;
   std::chrono::steady_clock::time_point last{};
-  bool slept = false;
+  bool slept = false, throttled = false;
   for (unsigned spins = 1;; ++spins) {
     if (__atomic_load_n(word, __ATOMIC_ACQUIRE) == want) return NDTPSO_OK;
-    const bool crowded = policy == 2 || (policy == 0 && 2 * g_word_waiters.load(std::memory_order_relaxed) > host_cpu_budget());
+    const bool crowded = policy == 2 || (policy == 0 && (2 * g_word_waiters.load(std::memory_order_relaxed) > host_cpu_budget() ||
+                                                       ((spins & 1023u) == 65u && quota_is_biting()) || throttled));
+    if (crowded) throttled = true;  // (once polite, polite to the end of this wait)
     if (crowded && spins > 64u) {  // (the first looks spin: a result that is all but there)
       static thread_local bool slack_set = false;
       if (!slack_set) {
