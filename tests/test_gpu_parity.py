@@ -774,3 +774,37 @@ def test_beam_direction_cache_across_scan_geometries(ctx, oracle):
                 of.load_laser(scans[k], np.float32(amin), np.float32(ainc), 30.0)
                 got = ctx.scan_to_points(scans[k], geom, trans)
                 assert np.array_equal(got, of.points()), (rep, k, trans)
+
+
+@pytest.mark.parametrize("cs", [0.25, 0.125])
+def test_flagged_alignments_of_a_large_batch_are_redone_by_the_striding_kernels(ctx, oracle, monkeypatch, cs):
+    """Round 6: a gated launch ("redo the alignments whose status carries this flag") is eight workgroups that read the flags 64
+    at a time and run their flagged pairs one after the other (k_align_pairs_s), not a workgroup per pair.  600 pairs of 1081
+    beams -- more than one sweep of 8 x 64 flags -- on cells small enough that some rooms outgrow the cell table sized for two
+    workgroups per compute unit (0.25 m: a handful; 0.125 m: all of them, many more flagged pairs than workgroups): which pairs
+    were flagged is read off a run WITHOUT the redo launches (NDTPSO_NO_REDO), and after the normal runs nothing is flagged, the
+    fp64 and the exact mode agree bit for bit on every pair, and the flagged pairs' poses are the oracle's."""
+    from ndtpso_slam_amd import capi, synth
+    B, P, I = 600, 24, 12
+    p = synth.make_pairs(B, seed=606)
+    geom, grid, cfg = _geom(p, capi), capi.Grid(FRAME_M, FRAME_M, cs), capi.PSOConfig.make(I, P)
+    args = (p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), DEVIATION, cfg)
+    monkeypatch.setenv("NDTPSO_NO_REDO", "1")
+    _, _, st0 = ctx.align_pairs(*args, seeds=p.seeds, mode=capi.SCORE_F64)
+    monkeypatch.delenv("NDTPSO_NO_REDO")
+    flagged = np.nonzero((st0["status"] & 0xffff) != 0)[0]
+    print("cells %.3f m: %d of %d pairs flagged by the main launch of the fp64 mode" % (cs, flagged.size, B))
+    assert flagged.size > 0 and (cs > 0.2 or flagged.size > 64)
+    got = {}
+    for name, mode in (("f64", capi.SCORE_F64), ("exact", capi.SCORE_EXACT)):
+        for rep in range(2):     # twice: the second call's gated grid follows what the first one found flagged
+            pose, cost, st = ctx.align_pairs(*args, seeds=p.seeds, mode=mode)
+            assert ((st["status"] & 0xffff) == 0).all(), (name, rep, np.nonzero(st["status"] & 0xffff)[0][:10])
+            if name in got:
+                assert np.array_equal(pose, got[name][0]) and np.array_equal(cost, got[name][1])
+            got[name] = (pose, cost)
+    assert np.array_equal(got["f64"][0], got["exact"][0]) and np.array_equal(got["f64"][1], got["exact"][1])
+    pick = flagged[:: max(1, flagged.size // 8)][:8]
+    want, wcost, _ = oracle.align_pairs(p.ref_ranges[pick], p.new_ranges[pick], p.angle_min, p.angle_inc, p.range_max, 0.1, FRAME_M,
+                                        FRAME_M, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P), p.seeds[pick])
+    assert np.abs(got["f64"][0][pick] - want).max() < 1e-9 and np.abs(got["f64"][1][pick] - wcost).max() < 1e-8
