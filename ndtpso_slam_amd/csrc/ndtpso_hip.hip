@@ -2302,6 +2302,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     gate_fb = c->pairs_fb + 4 + ((mode == NDTPSO_SCORE_F64 ? 2 : 0) | (allow_dense ? 1 : 0));
     const uint32_t seen = __atomic_load_n(gate_fb, __ATOMIC_RELAXED);
     gate_grid = std::min<uint32_t>(n_pairs, std::max<uint32_t>(8u, 2u * seen));
+    if (const char* e = std::getenv("NDTPSO_GATE_GRID")) gate_grid = std::min<uint32_t>(n_pairs, (uint32_t)std::max(1, std::atoi(e)));  // (diagnostics)
   }
 #define LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX)                                                \
   do {                                                                                                             \
