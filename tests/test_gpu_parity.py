@@ -776,7 +776,7 @@ def test_beam_direction_cache_across_scan_geometries(ctx, oracle):
                 assert np.array_equal(got, of.points()), (rep, k, trans)
 
 
-@pytest.mark.parametrize("cs", [0.25, 0.1875])
+@pytest.mark.parametrize("cs", [0.25, 0.1875, 0.125])
 def test_flagged_alignments_of_a_large_batch_are_redone_by_the_striding_kernels(ctx, oracle, monkeypatch, cs):
     """Round 6: a gated launch ("redo the alignments whose status carries this flag") is eight workgroups that read the flags 64
     at a time and run their flagged pairs one after the other (k_align_pairs_s), not a workgroup per pair.  600 pairs of 1081
@@ -795,9 +795,10 @@ def test_flagged_alignments_of_a_large_batch_are_redone_by_the_striding_kernels(
     flagged = np.nonzero((st0["status"] & 0xffff) != 0)[0]
     print("cells %.3f m: %d of %d pairs flagged by the main launch of the fp64 mode" % (cs, flagged.size, B))
     assert flagged.size > 0 and (cs > 0.2 or flagged.size > 64)
-    # (0.125 m cells in this frame are beyond the pairs kernels: a room seen at an angle is 240 x 240 cells, more than the largest
-    # table a workgroup holds, and the bitmap form of a 480 x 480-cell window does not fit LDS either -- 13 of these 600 alignments
-    # then KEEP their flag, in round 5's library as in this one: a capacity limit the status word reports)
+    # (0.125 m cells in this frame are beyond the pairs KERNELS for a dozen of the 600: a room seen at an angle is 240 x 240 cells,
+    # more than the largest table a workgroup holds, and the bitmap form of a 480 x 480-cell window does not fit LDS either.  The
+    # host-buffer entry, which has just synchronised and has the inputs, sends those through the staged path -- table in its HBM
+    # image -- one by one; the asynchronous _dev entry leaves them flagged for its caller.)
     got = {}
     for name, mode in (("f64", capi.SCORE_F64), ("exact", capi.SCORE_EXACT)):
         for rep in range(2):     # twice: the second call's gated grid follows what the first one found flagged
@@ -808,6 +809,8 @@ def test_flagged_alignments_of_a_large_batch_are_redone_by_the_striding_kernels(
             got[name] = (pose, cost)
     assert np.array_equal(got["f64"][0], got["exact"][0]) and np.array_equal(got["f64"][1], got["exact"][1])
     pick = flagged[:: max(1, flagged.size // 8)][:8]
+    if cs < 0.15:   # ... and the pairs only the resident-frame fallback can serve (what the kernels alone leave flagged)
+        pick = np.unique(np.r_[pick[:4], [34, 38, 39, 575, 580, 584]])
     want, wcost, _ = oracle.align_pairs(p.ref_ranges[pick], p.new_ranges[pick], p.angle_min, p.angle_inc, p.range_max, 0.1, FRAME_M,
                                         FRAME_M, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P), p.seeds[pick])
     assert np.abs(got["f64"][0][pick] - want).max() < 1e-9 and np.abs(got["f64"][1][pick] - wcost).max() < 1e-8
