@@ -2638,7 +2638,9 @@ int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges,
   if (fb_a) ndtpso_points_destroy(fb_a);
   if (fb_b) ndtpso_points_destroy(fb_b);
   if (fb_map) ndtpso_map_destroy(fb_map);
-  if (fb_rc != NDTPSO_OK) return fb_rc;
+  // (a frame the resident path cannot hold either -- a million cells -- leaves its pairs flagged, as the kernels did: the other
+  // pairs' results stand)
+  if (fb_rc != NDTPSO_OK && fb_rc != NDTPSO_E_CAPACITY) return fb_rc;
   return NDTPSO_OK;
 }
 
