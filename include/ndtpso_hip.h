@@ -309,8 +309,9 @@ int ndtpso_map_get_occupancy(ndtpso_map *map, int8_t *og, uint64_t og_bytes, uin
  * ranges are [n_pairs][n_beams] row-major; guess/deviation/out_pose [n_pairs][3].
  * A pair the fused kernels cannot hold -- an occupied box beyond the largest cell table of a workgroup whose bitmap form does not
  * fit LDS either: cells of 0.125 m in a 60 m frame, a dozen pairs in 600 -- comes out of them with NDTPSO_STATUS_FLAGS set.  This
- * entry (host buffers, synchronous) then aligns it through a resident frame (ndtpso_map_*: table in HBM), same pose bit for bit;
- * ndtpso_align_pairs_dev and the sharded entries, asynchronous on device buffers, leave the flag to the caller. */
+ * entry (host buffers, synchronous) then aligns it through a resident frame (ndtpso_map_*: table in HBM), same pose bit for bit --
+ * so does ndtpso_align_pairs_sharded, on its first device; ndtpso_align_pairs_dev / ndtpso_align_pairs_sharded_dev, asynchronous
+ * on device buffers, leave the flag to the caller. */
 int ndtpso_align_pairs(ndtpso_ctx *ctx, uint32_t n_pairs, const float *ref_ranges, const float *new_ranges,
                        const ndtpso_scan_geom *geom, const ndtpso_grid *grid, const double *guess,
                        const double *deviation, const ndtpso_pso_config *cfg, const uint32_t *seeds,

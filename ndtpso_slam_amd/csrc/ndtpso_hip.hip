@@ -2551,6 +2551,55 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
   return rc == NDTPSO_E_CAPACITY ? NDTPSO_OK : rc;
 }
 
+// What the fused kernels could not serve -- an occupied box beyond the largest table a workgroup holds whose bitmap form does
+// not fit LDS either (cells of 0.125 m in a 60 m frame: a dozen pairs in 600) -- comes back flagged.  An entry that has the
+// inputs on the host and has just synchronised (ndtpso_align_pairs, ndtpso_align_pairs_sharded) sends those pairs, one by one,
+// through the RESIDENT frame (ndtpso_map_*: scan A inserted into a frame in HBM and built there, the alignment reading the
+// packed table from its HBM image where LDS cannot hold it), whose results are the fused kernels' bit for bit.  One frame per
+// call, cleared between pairs; nothing of this is allocated unless a pair needs it.  A frame the resident path cannot hold
+// either -- a million cells -- leaves its pairs flagged, as the kernels did: the other pairs' results stand.
+// (The asynchronous entries on device buffers leave the flag to their caller: NDTPSO_STATUS_FLAGS.)
+static int resolve_flagged_pairs(ndtpso_ctx* c, size_t B, const float* ref_ranges, const float* new_ranges, const ndtpso_scan_geom* geom,
+                                 const ndtpso_grid* grid, const double* guess, const double* deviation, const ndtpso_pso_config* cfg,
+                                 const uint32_t* seeds, const int32_t* rand_tables, int mode, double* out_pose, double* out_cost,
+                                 AlignStats* hs) {
+  const size_t nb = geom->n_beams, n_draw = ndtpso_rand_draws(cfg);
+  if (std::getenv("NDTPSO_NO_REDO")) return NDTPSO_OK;  // (diagnostics: what the main launch alone left flagged)
+  ndtpso_map* fb_map = nullptr;
+  ndtpso_points *fb_a = nullptr, *fb_b = nullptr;
+  int fb_rc = NDTPSO_OK;
+  for (size_t b = 0; b < B && fb_rc == NDTPSO_OK; ++b) {
+    if (!(hs[b].status & (kStatusNeedsBitmap | kStatusNeedsF64 | kStatusClusterTimeout))) continue;
+    const double zero3[3] = {0., 0., 0.};
+    if (!fb_map) {
+      fb_rc = ndtpso_map_create(c, grid, 0., (uint64_t)std::max<size_t>(nb, 4096) * 16 * 64, &fb_map);
+      if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_points_create(c, (uint32_t)nb, &fb_a);
+      if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_points_create(c, (uint32_t)nb, &fb_b);
+    } else {
+      fb_rc = ndtpso_map_clear(fb_map);
+    }
+    // reference frame <- scan A at identity; the frame being matched is a one-cell frame of the same size, its list the points
+    // inside it (ndtpso_slam_node.cpp:229-230: `clip`)
+    if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_points_load_scan(fb_a, ref_ranges + b * nb, geom, zero3, grid, 0);
+    if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_map_insert(fb_map, fb_a, nullptr);
+    if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_map_build(fb_map);
+    if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_points_load_scan(fb_b, new_ranges + b * nb, geom, zero3, grid, 0);
+    double pose[3] = {0., 0., 0.}, cost = 0.;
+    ndtpso_align_stats st1;
+    if (fb_rc == NDTPSO_OK)
+      fb_rc = ndtpso_map_align(fb_map, fb_b, guess + 3 * b, deviation + 3 * b, cfg, seeds ? seeds[b] : 0u,
+                               rand_tables ? rand_tables + b * n_draw : nullptr, mode, pose, &cost, &st1);
+    if (fb_rc != NDTPSO_OK) break;
+    std::memcpy(out_pose + 3 * b, pose, sizeof(pose));
+    if (out_cost) out_cost[b] = cost;
+    std::memcpy(&hs[b], &st1, sizeof(AlignStats));
+  }
+  if (fb_a) ndtpso_points_destroy(fb_a);
+  if (fb_b) ndtpso_points_destroy(fb_b);
+  if (fb_map) ndtpso_map_destroy(fb_map);
+  return (fb_rc != NDTPSO_OK && fb_rc != NDTPSO_E_CAPACITY) ? fb_rc : NDTPSO_OK;
+}
+
 int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges, const float* new_ranges,
                        const ndtpso_scan_geom* geom, const ndtpso_grid* grid, const double* guess,
                        const double* deviation, const ndtpso_pso_config* cfg, const uint32_t* seeds,
@@ -2599,48 +2648,9 @@ int ndtpso_align_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* ref_ranges,
   }
   HIP_TRY(c, hipMemcpyAsync(hs, d_stats, B * sizeof(AlignStats), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  // What the fused kernels could not serve -- an occupied box beyond the largest table a workgroup holds whose bitmap form does
-  // not fit LDS either (cells of 0.125 m in a 60 m frame: a dozen pairs in 600) -- comes back flagged.  This entry has the
-  // inputs on the host and has just synchronised: those pairs go, one by one, through the RESIDENT frame (ndtpso_map_*: scan A
-  // inserted into a frame in HBM and built there, the alignment reading the packed table from its HBM image where LDS cannot
-  // hold it), whose results are the fused kernels' bit for bit.  One frame per call, cleared between pairs; nothing of this is
-  // allocated unless a pair needs it.  (ndtpso_align_pairs_dev, asynchronous, leaves the flag to its caller: NDTPSO_STATUS_FLAGS.)
-  const bool no_redo = std::getenv("NDTPSO_NO_REDO") != nullptr;  // (diagnostics: what the main launch alone left flagged)
-  ndtpso_map* fb_map = nullptr;
-  ndtpso_points *fb_a = nullptr, *fb_b = nullptr;
-  int fb_rc = NDTPSO_OK;
-  for (size_t b = 0; b < B && !no_redo && fb_rc == NDTPSO_OK; ++b) {
-    if (!(hs[b].status & (kStatusNeedsBitmap | kStatusNeedsF64 | kStatusClusterTimeout))) continue;
-    const double zero3[3] = {0., 0., 0.};
-    if (!fb_map) {
-      fb_rc = ndtpso_map_create(c, grid, 0., (uint64_t)std::max<size_t>(nb, 4096) * 16 * 64, &fb_map);
-      if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_points_create(c, (uint32_t)nb, &fb_a);
-      if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_points_create(c, (uint32_t)nb, &fb_b);
-    } else {
-      fb_rc = ndtpso_map_clear(fb_map);
-    }
-    // reference frame <- scan A at identity; the frame being matched is a one-cell frame of the same size, its list the points
-    // inside it (ndtpso_slam_node.cpp:229-230: `clip`)
-    if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_points_load_scan(fb_a, ref_ranges + b * nb, geom, zero3, grid, 0);
-    if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_map_insert(fb_map, fb_a, nullptr);
-    if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_map_build(fb_map);
-    if (fb_rc == NDTPSO_OK) fb_rc = ndtpso_points_load_scan(fb_b, new_ranges + b * nb, geom, zero3, grid, 0);
-    double pose[3] = {0., 0., 0.}, cost = 0.;
-    ndtpso_align_stats st1;
-    if (fb_rc == NDTPSO_OK)
-      fb_rc = ndtpso_map_align(fb_map, fb_b, guess + 3 * b, deviation + 3 * b, cfg, seeds ? seeds[b] : 0u,
-                               rand_tables ? rand_tables + b * n_draw : nullptr, mode, pose, &cost, &st1);
-    if (fb_rc != NDTPSO_OK) break;
-    std::memcpy(out_pose + 3 * b, pose, sizeof(pose));
-    if (out_cost) out_cost[b] = cost;
-    std::memcpy(&hs[b], &st1, sizeof(AlignStats));
-  }
-  if (fb_a) ndtpso_points_destroy(fb_a);
-  if (fb_b) ndtpso_points_destroy(fb_b);
-  if (fb_map) ndtpso_map_destroy(fb_map);
-  // (a frame the resident path cannot hold either -- a million cells -- leaves its pairs flagged, as the kernels did: the other
-  // pairs' results stand)
-  if (fb_rc != NDTPSO_OK && fb_rc != NDTPSO_E_CAPACITY) return fb_rc;
+  if (int rc = resolve_flagged_pairs(c, B, ref_ranges, new_ranges, geom, grid, guess, deviation, cfg, seeds, rand_tables, mode, out_pose,
+                                     out_cost, hs))
+    return rc;
   return NDTPSO_OK;
 }
 

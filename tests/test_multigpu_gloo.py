@@ -501,3 +501,23 @@ def test_bench_sharded_capi_mode(virtual):
     else:
         assert d["config"]["test_mode"] is None and d["rccl"]["gather"].startswith("ncclAllGather") and d["rccl"]["comm_ranks"] == 1
         assert d["rccl"]["version"]
+
+
+@pytest.mark.gpu
+def test_sharded_host_entry_resolves_pairs_the_kernels_leave_flagged(ctx):
+    """0.125 m cells in the 60 m frame: a few rooms are beyond the fused kernels (largest table too small, bitmap form beyond LDS)
+    and come back flagged from them.  The entries that hold the inputs on the host -- ndtpso_align_pairs and
+    ndtpso_align_pairs_sharded -- align those through a resident frame; both return the same poses, nothing flagged."""
+    from ndtpso_slam_amd import capi, synth
+    p = synth.make_pairs(600, seed=606)
+    sel = np.r_[28:44]          # (34, 38, 39 are three of the thirteen pairs of this set the kernels cannot hold)
+    geom = capi.ScanGeom(p.n_beams, float(p.angle_min), float(p.angle_inc), float(p.range_max), 0.1)
+    grid, cfg = capi.Grid(60, 60, 0.125), capi.PSOConfig.make(10, 16)
+    dev = (0.1, 0.1, 3.1415e-3)
+    want, wcost, wst = ctx.align_pairs(p.ref_ranges[sel], p.new_ranges[sel], geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds[sel], mode=capi.SCORE_EXACT)
+    assert ((wst["status"] & 0xffff) == 0).all()
+    g = capi.ShardGroup([0])
+    got, cost, st = g.align_pairs(p.ref_ranges[sel], p.new_ranges[sel], geom, grid, (0, 0, 0), dev, cfg, seeds=p.seeds[sel], mode=capi.SCORE_EXACT)
+    g.close()
+    assert ((st["status"] & 0xffff) == 0).all()
+    assert np.array_equal(got, want) and np.array_equal(cost, wcost)
