@@ -1,11 +1,12 @@
 """Long node replay: resident frames (clustered alignment) vs host-kept frames vs the oracle, pose by pose.
-usage: python tests/campaigns/soak_replay.py [n_scans] [--oracle]"""
+usage: python tests/campaigns/soak_replay.py [n_scans] [--oracle]      (SOAK_FRAME=60 SOAK_CELL=0.5 SOAK_SCORE=f64|exact in the environment)"""
 import os, subprocess, sys, time
 sys.path.insert(0, '.')
 sys.path.insert(0, 'tests')
 import numpy as np
 from ndtpso_slam_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1500
+FRAME, CELL = os.environ.get("SOAK_FRAME", "60"), os.environ.get("SOAK_CELL", "0.5")
 rng = np.random.default_rng(9)
 s = np.linspace(0.0, 1.0, n)
 # two laps around the room centre, heading turning with the path: the map is revisited, window slots rotate
@@ -19,7 +20,7 @@ with open('/tmp/soak.bin', 'wb') as f:
 outs = {}
 for tag, env in (("resident+cluster", {}), ("resident, one WG", {"NDTPSO_CLUSTER": "0"}), ("host frames", {"NDTPSO_RESIDENT": "0"})):
     t = time.time()
-    r = subprocess.run(['host/replay/node_replay', '/tmp/soak.bin', '60', '0.5', '50', '30', '7', '0.1', '/tmp/soak_' + tag.split()[0].strip(','), '5'],
+    r = subprocess.run(['host/replay/node_replay', '/tmp/soak.bin', FRAME, CELL, '50', '30', '7', '0.1', '/tmp/soak_' + tag.split()[0].strip(','), '5'],
                        capture_output=True, text=True, env=dict(os.environ, NDTPSO_SCORE=os.environ.get("SOAK_SCORE", "f64"), **env))
     outs[tag] = np.array([[float(v) for v in l.split()[1:]] for l in r.stdout.strip().splitlines()])
     print(tag, r.stderr.strip().splitlines()[-1], "wall %.1f s" % (time.time() - t), "final pose", outs[tag][-1])
@@ -34,11 +35,11 @@ if '--oracle' in sys.argv:
     cfg = O.PSOConfig.make(50, 30)
     n_draw = 3 + 3 * 30 + 6 * 30 * 50
     stream = O.glibc_rand(7, n_draw * n)
-    ref = O.Frame((0, 0, 0), 60, 60, 0.5)
+    ref = O.Frame((0, 0, 0), int(FRAME), int(FRAME), float(CELL))
     prev = np.zeros(3); want = []
     t = time.time()
     for k in range(n):
-        cur = O.Frame((0, 0, 0), 60, 60, 60.0)
+        cur = O.Frame((0, 0, 0), int(FRAME), int(FRAME), float(FRAME))
         cur.load_laser(ranges[k], synth.ANGLE_MIN, synth.ANGLE_INC, synth.RANGE_MAX)
         pose = prev.copy() if k == 0 else ref.align(prev, cur, cfg, table=stream[(k - 1) * n_draw:k * n_draw])
         prev = pose; ref.update(pose, cur); want.append(pose)
