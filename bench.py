@@ -338,6 +338,40 @@ def main():
             },
         }
 
+    # (before rank 0's extras: the other ranks take part in these collectives and must not sit in one for minutes)
+    # Did RCCL see N ranks?  Answerable from the record: a real all_gather of the rank numbers (ranks_seen), the gathered
+    # poses held against every rank's own (block r of the gather == rank r's poses, checked by rank r, AND over ranks), the
+    # library's version, and the median duration of the step's one collective by events on the launch stream.
+    if use_dist:
+        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
+        ranks_seen = len({int(t.item()) for t in ids})
+        mine = outs[(args.steps - 1) & 1][0] if depth > 1 and args.steps > 0 else outs[0][0]
+        allp = sharding.gather_poses(mine, equal_sizes=True, force=True)
+        own = torch.tensor([1 if torch.equal(allp[rank * B:(rank + 1) * B], mine) and allp.shape[0] == world * B else 0], device=dev)
+        dist.all_reduce(own, op=dist.ReduceOp.MIN)
+        g_us = []
+        for _ in range(25):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            sharding.gather_poses(mine, equal_sizes=True, force=True)
+            b.record(stream)
+            torch.cuda.synchronize()
+            g_us.append(1e3 * a.elapsed_time(b))
+        if rank == 0:
+            try:
+                ver = ".".join(str(x) for x in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                ver = None
+            out["rccl"] = {"ranks_seen": ranks_seen, "world_size": dist.get_world_size(), "backend": dist.get_backend(),
+                           "version": ver, "gather_us_median": float(np.median(g_us[5:])),
+                           "gather_bytes_per_rank": int(B * 24), "every_rank_found_its_poses_in_the_gather": bool(int(own.item())),
+                           "launch": "one process per GPU (torch.distributed), %s" % ("started by bench.py itself" if os.environ.get("NDTPSO_BENCH_SELF_LAUNCHED") == "1" else "started by a launcher")}
+            assert ranks_seen == world == args.gpus, (ranks_seen, world, args.gpus)
+    elif rank == 0:
+        out["rccl"] = None   # one rank, no process group: nothing was gathered (NDTPSO_BENCH_FORCE_DIST=1 takes the RCCL path anyway)
+
+
     # single-pair latency (BASELINE config 2), rank 0 only
     if rank == 0 and not args.no_latency:
         torch.cuda.synchronize()
@@ -433,38 +467,6 @@ def main():
         out["extra"]["parity_pairs_compared"] = int(len(opose))
     elif rank == 0:
         out["cpu_baseline"] = None
-
-    # Did RCCL see N ranks?  Answerable from the record: a real all_gather of the rank numbers (ranks_seen), the gathered
-    # poses held against every rank's own (block r of the gather == rank r's poses, checked by rank r, AND over ranks), the
-    # library's version, and the median duration of the step's one collective by events on the launch stream.
-    if use_dist:
-        ids = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(ids, torch.tensor([rank], dtype=torch.int64, device=dev))
-        ranks_seen = len({int(t.item()) for t in ids})
-        mine = outs[(args.steps - 1) & 1][0] if depth > 1 and args.steps > 0 else outs[0][0]
-        allp = sharding.gather_poses(mine, equal_sizes=True, force=True)
-        own = torch.tensor([1 if torch.equal(allp[rank * B:(rank + 1) * B], mine) and allp.shape[0] == world * B else 0], device=dev)
-        dist.all_reduce(own, op=dist.ReduceOp.MIN)
-        g_us = []
-        for _ in range(25):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(stream)
-            sharding.gather_poses(mine, equal_sizes=True, force=True)
-            b.record(stream)
-            torch.cuda.synchronize()
-            g_us.append(1e3 * a.elapsed_time(b))
-        if rank == 0:
-            try:
-                ver = ".".join(str(x) for x in torch.cuda.nccl.version())
-            except Exception:  # noqa: BLE001
-                ver = None
-            out["rccl"] = {"ranks_seen": ranks_seen, "world_size": dist.get_world_size(), "backend": dist.get_backend(),
-                           "version": ver, "gather_us_median": float(np.median(g_us[5:])),
-                           "gather_bytes_per_rank": int(B * 24), "every_rank_found_its_poses_in_the_gather": bool(int(own.item())),
-                           "launch": "one process per GPU (torch.distributed), %s" % ("started by bench.py itself" if os.environ.get("NDTPSO_BENCH_SELF_LAUNCHED") == "1" else "started by a launcher")}
-            assert ranks_seen == world == args.gpus, (ranks_seen, world, args.gpus)
-    elif rank == 0:
-        out["rccl"] = None   # one rank, no process group: nothing was gathered (NDTPSO_BENCH_FORCE_DIST=1 takes the RCCL path anyway)
 
     if use_dist:
         dist.barrier()
