@@ -814,3 +814,21 @@ def test_flagged_alignments_of_a_large_batch_are_redone_by_the_striding_kernels(
     want, wcost, _ = oracle.align_pairs(p.ref_ranges[pick], p.new_ranges[pick], p.angle_min, p.angle_inc, p.range_max, 0.1, FRAME_M,
                                         FRAME_M, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P), p.seeds[pick])
     assert np.abs(got["f64"][0][pick] - want).max() < 1e-9 and np.abs(got["f64"][1][pick] - wcost).max() < 1e-8
+
+
+def test_wild_configurations_are_answered_exactly_or_refused_loudly():
+    """tests/campaigns/wild_configs.py, 80 of its configurations (cells 0.1 - 2 m, frames 10 - 300 m and not square, 5 - 3000 beams,
+    swarms of 1 - 300, batches of 1 - 700 pairs, sensors cut short or nearly blind, guesses metres off): fp64 == exact on every
+    pair, up to six pairs of each against the oracle; what the library cannot hold is refused with an error or left flagged --
+    the script asserts that nothing is answered wrongly.  (The campaign itself ran 2000.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "campaigns", "wild_configs.py"), "80", "20260930"], cwd=root,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    last = r.stdout.strip().splitlines()[-1]
+    print(last)
+    assert "configurations identical to the oracle" in last
+    assert int(last.split("/")[0]) >= 60        # (most are served; the rest are the loud refusals and the flagged giants)
