@@ -549,3 +549,20 @@ def test_short_lived_threads_recycle_their_device_contexts():
     d = json.loads(out.strip().splitlines()[-1])
     assert d["threads"] == 40 and d["failed"] == 0 and d["device_errors"] == 0, d
     assert d["contexts"] <= 3, d      # the main thread's and one or two that go round
+
+
+@pytest.mark.gpu
+def test_node_replay_on_a_frame_of_a_million_cells(tmp_path):
+    """A 300 m frame of 0.25 m cells (1.44 M cells; the reference spends 11 GB of host memory on it): until round 6 the resident
+    frame refused anything beyond ~650 000 cells because its table packer sized its LDS for the whole grid; it is the box of the
+    BUILT cells that has to fit.  60 scans of the node sequence through the drop-in -- resident frames with and without clusters,
+    host-kept frames -- and the oracle: every pose identical (tests/campaigns/soak_replay.py)."""
+    import sys
+    _build()
+    env = dict(os.environ, SOAK_FRAME="300", SOAK_CELL="0.25", SOAK_SCORE="exact")
+    env.pop("NDTPSO_ABORT_ON_ERROR", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "campaigns", "soak_replay.py"), "60", "--oracle"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if "max |dpose|" in l]
+    assert len(lines) == 4 and all("max |dpose| 0.000e+00" in l for l in lines), r.stdout[-1500:]
