@@ -124,8 +124,10 @@ int ndtpso_synchronize(ndtpso_ctx *ctx);
  * out[1] waits for a kernel's result that slept between looks instead of spinning (more waiting threads than half the CPUs
  * the process may use: affinity mask cut by the control group's quota); out[2] that CPU budget; out[3] threads waiting now;
  * out[4] alignments kept on ONE workgroup because 16 (NDTPSO_CLUSTER_MAX_INFLIGHT) were already in flight in the process -- more
- * clusters than the device's hardware queues run side by side would wait for each other.  n: how many to write (1 .. 5).  The reference has nothing of the kind (single-threaded caller,
- * ndtpso_slam_node.cpp:182). */
+ * clusters than the device's hardware queues run side by side would wait for each other; out[5] (the batch path,
+ * ndtpso_align_pairs*) batches whose few flagged pairs -- a cell table outgrown, an fp32 score in its underflow regime -- were
+ * redone on clusters of workgroups instead of one workgroup each.  n: how many to write (1 .. 6).  The reference has nothing of
+ * the kind (single-threaded caller, ndtpso_slam_node.cpp:182). */
 int ndtpso_process_counters(uint64_t *out, int n);
 /* Batches in flight.  depth 1 (default): every call is enqueued on the context's stream, one after the other.
  * depth 2: consecutive ndtpso_align_pairs_dev calls (batches of more pairs than half the device's compute units) run

@@ -572,12 +572,12 @@ class ShardGroup:
 
 def process_counters() -> dict:
     """ndtpso_process_counters: cluster timeouts, waits that slept, the CPU budget, threads waiting now."""
-    v = (C.c_uint64 * 5)()
-    rc = load().ndtpso_process_counters(v, 5)
+    v = (C.c_uint64 * 6)()
+    rc = load().ndtpso_process_counters(v, 6)
     if rc != OK:
         raise NdtpsoError(rc, "ndtpso_process_counters")
     return {"cluster_timeouts": int(v[0]), "polite_waits": int(v[1]), "cpu_budget": int(v[2]), "waiting_now": int(v[3]),
-            "alignments_kept_on_one_workgroup": int(v[4])}
+            "alignments_kept_on_one_workgroup": int(v[4]), "batches_redone_on_clusters": int(v[5])}
 
 
 def shard_range(n_pairs: int, rank: int, n_devices: int):

@@ -712,6 +712,27 @@ k_align_pairs_s(const float* __restrict__ ref_ranges, const float* __restrict__ 
   }
 }
 
+// The pairs a redo launch on CLUSTERS serves (launch_pairs: redo_list): list[0] = how many (at most `cap`), list[1 ..] = the
+// pairs whose status carries one of `mask`'s flags, in order; *seen (pinned) = how many there were in all, for the host's next
+// choice.  One wave: 64 flags per sweep.
+__global__ void __launch_bounds__(64)
+k_redo_list(const AlignStats* __restrict__ stats, uint32_t n_pairs, uint32_t mask, uint32_t* __restrict__ list, uint32_t cap,
+            uint32_t* __restrict__ seen) {
+  uint32_t n = 0;
+  for (uint32_t base = 0; base < n_pairs; base += kWave) {
+    const uint32_t i = base + (uint32_t)lane_id();
+    const bool f = i < n_pairs && (stats[i].status & mask) != 0u;
+    const unsigned long long m = __ballot(f);
+    const uint32_t at = n + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1ull));
+    if (f && at < cap) list[1 + at] = i;
+    n += (uint32_t)__popcll(m);
+  }
+  if (lane_id() == 0) {
+    list[0] = min(n, cap);
+    if (seen) __hip_atomic_store(seen, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // =================================================================================================
 // host side
 // =================================================================================================
@@ -892,6 +913,7 @@ struct ndtpso_ctx {
   // call's pairs did, the next calls of the same configuration start with the largest table instead (one workgroup per
   // compute unit) -- a scheduling decision only: the results do not depend on it
   uint32_t* pairs_fb = nullptr;
+  DevBuf redo_list;                   // [count, pair ...] of a redo launch on clusters (k_redo_list)
   uint32_t fb_seen = 0, fb_last_pairs = 0;
   uint64_t fb_key = 0;
   bool fb_big_first = false, fb_overflowed = true;
@@ -1058,6 +1080,9 @@ struct PlanForce {
   int cluster = -1;       // 1 / 0: a batch as clusters of workgroups / one workgroup per alignment, whatever its size
 };
 thread_local PlanForce t_plan_force;
+thread_local bool t_in_exact_check = false;  // this thread is running the start-up check of the exact mode (ndtpso_selftest.inc)
+// NDTPSO_NO_REDO (diagnostics: what the main launch alone leaves flagged) -- not for the start-up check's own batches
+static bool no_redo_requested() { return !t_in_exact_check && std::getenv("NDTPSO_NO_REDO") != nullptr; }
 // what the last main (ungated) launch of this thread was: k_align_pairs / k_align instantiation as
 // PATH | CL << 4 | ARB << 5 | NOCLIP << 6 | SWARM << 7 | BOX << 9 | (fused pairs kernel) << 10 | (fp64 score) << 11
 thread_local uint32_t t_last_launch = 0;
@@ -1913,6 +1938,7 @@ static std::atomic<unsigned long long> g_polite_waits{0};    // waits that slept
 static std::atomic<unsigned long long> g_cluster_timeouts{0};  // alignments whose cluster ran into the bounded wait
 static std::atomic<int> g_aligns_in_flight{0};                 // single alignments between launch and result, process-wide
 static std::atomic<unsigned long long> g_crowded_aligns{0};    // alignments kept on one workgroup because too many were in flight
+static std::atomic<unsigned long long> g_redo_cluster_launches{0};  // batches whose flagged pairs were given to clusters (align_pairs_dev_on_stream)
 
 // One waiter spins: the word arrives a microsecond after the kernel wrote it, and a robot's one matcher thread has a CPU to
 // itself.  MANY waiters must not: R replicas of the live sequence are R threads in this loop at once, and past the CPUs the
@@ -1969,9 +1995,9 @@ static int wait_pinned_word(ndtpso_ctx* c, const uint32_t* word, uint32_t want) 
 
 int ndtpso_process_counters(uint64_t* out, int n) {
   if (!out || n < 1) return NDTPSO_E_ARG;
-  const uint64_t v[5] = {g_cluster_timeouts.load(), g_polite_waits.load(), (uint64_t)host_cpu_budget(), (uint64_t)g_word_waiters.load(),
-                         g_crowded_aligns.load()};
-  for (int i = 0; i < n && i < 5; ++i) out[i] = v[i];
+  const uint64_t v[6] = {g_cluster_timeouts.load(), g_polite_waits.load(), (uint64_t)host_cpu_budget(), (uint64_t)g_word_waiters.load(),
+                         g_crowded_aligns.load(), g_redo_cluster_launches.load()};
+  for (int i = 0; i < n && i < 6; ++i) out[i] = v[i];
   return NDTPSO_OK;
 }
 
@@ -2246,51 +2272,59 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
                         const ndtpso_pso_config* cfg, const uint32_t* d_seeds, const int32_t* d_tables, int mode,
                         double* d_pose, double* d_cost, AlignStats* d_stats, uint32_t gate, bool allow_dense,
                         int* path_out, bool allow_cluster = false, bool exact = false, bool big_table = false,
-                        bool* shrunk_out = nullptr, uint32_t* fb = nullptr) {
+                        bool* shrunk_out = nullptr, uint32_t* fb = nullptr,
+                        // a redo launch on clusters: `redo_units` clusters, cluster i taking pair redo_list[1 + i] if i < redo_list[0]
+                        // (k_redo_list), clearing the flags `redo_mask` of the pairs it completes; E_STATE: no cluster shape for this
+                        const uint32_t* redo_list = nullptr, uint32_t redo_units = 0, uint32_t redo_mask = 0) {
   if (!cfg || cfg->population < 1) return fail(c, NDTPSO_E_ARG, "bad scan/grid/PSO configuration");
   // a batch smaller than the device: the idle compute units join in, K workgroups per alignment (ClusterP)
   int K = 1, cw = 4;
   if (t_plan_force.cluster >= 0) allow_cluster = t_plan_force.cluster != 0;
+  const uint32_t n_units = redo_list ? redo_units : n_pairs;  // alignments this launch provides for (scratch, exchange slots, grid)
   cluster_shape(cfg->population, true, allow_cluster && gate == 0, &K, &cw);
-  if (K > 1) K = std::min<int>(K, c->n_cus / (int)std::min<uint32_t>(n_pairs, (uint32_t)c->n_cus));
+  if (K > 1) K = std::min<int>(K, c->n_cus / (int)std::min<uint32_t>(n_units, (uint32_t)c->n_cus));
   if (K < 2 || !cluster_worthwhile(K, cw)) K = 1;
+  if (redo_list && K < 2) return NDTPSO_E_STATE;  // (not an error of the call: the gated launches serve the pairs)
   GridP g;
   WinP wn;
   Plan plan;
   int waves = 0;
   // (the fp64 score's dense form runs one workgroup per alignment: a cluster keeps the bitmap form)
-  const int rc = pairs_plan(geom, grid, cfg, mode, n_pairs, &g, &wn, &plan, &waves,
+  const int rc = pairs_plan(geom, grid, cfg, mode, n_units, &g, &wn, &plan, &waves,
                             allow_dense && !(mode == NDTPSO_SCORE_F64 && K > 1), (unsigned)c->n_cus, exact, big_table);
   if (path_out) *path_out = plan.path;
   if (shrunk_out) *shrunk_out = plan.shrunk;
   if (rc == NDTPSO_E_ARG) return fail(c, rc, "bad scan/grid/PSO configuration");
-  if (rc == NDTPSO_E_CAPACITY) return fail(c, rc, "scan pair working set does not fit in LDS");
+  if (rc == NDTPSO_E_CAPACITY) return redo_list ? NDTPSO_E_STATE : fail(c, rc, "scan pair working set does not fit in LDS");
+  if (redo_list && plan.L.swarm_global) return NDTPSO_E_STATE;  // (a cluster keeps its swarm in LDS)
   ScanP sp;
   const double2* dirs = nullptr;
   if (int rc = make_scan(c, geom, &sp, &dirs)) return rc;
   if (K > 1) waves = cw;
   PsoP ps = make_pso(cfg, waves, mode, plan.L.swarm_global != 0);
-  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), (int)n_pairs, -1, nullptr, cluster_flags()};
+  ClusterP cl{K, 0, 0, cluster_test_absent(), nullptr, 0u, cluster_one_xcd(), (int)n_units, -1,
+              reinterpret_cast<double*>(const_cast<uint32_t*>(redo_list)) /* ClusterP::spec, on the host's side */,
+              cluster_flags() | (int)(redo_mask << kClusterRedoShift)};
   int lds_total = plan.L.total;
   if (K > 1) cluster_spec_room(cfg->population, &lds_total, &cl);
   // (one XCD per cluster only while an XCD's share of the clusters finds a compute unit per workgroup there; a batch that
   // fills the device is spread as the dispatcher spreads it)
-  if (((int)n_pairs + 7) / 8 * K > std::max(1, c->n_cus / 8)) cl.one_xcd = 0;
+  if (((int)n_units + 7) / 8 * K > std::max(1, c->n_cus / 8)) cl.one_xcd = 0;
   if (K > 1) {
     ps.G = std::min(std::max(cfg->population, 1), K * waves);
     cl.stride = round_up(cfg->population + 1, 8);
-    if (int rc = cluster_slots(c, (size_t)n_pairs * (2 * cl.stride + round_up(K, 8)) * sizeof(uint4), &cl.xc)) return rc;
+    if (int rc = cluster_slots(c, (size_t)n_units * (2 * cl.stride + round_up(K, 8)) * sizeof(uint4), &cl.xc)) return rc;
     cl.nonce = next_cluster_nonce(c);
   }
   const size_t stride = ndtpso_rand_draws(cfg);
   const size_t ws_stride = plan.L.swarm_global ? (size_t)swarm_bytes(cfg->population, true, true) : 0;
-  if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_pairs * (size_t)K));
+  if (ws_stride) HIP_TRY(c, c->ws.reserve(ws_stride * n_units * (size_t)K));
   // exact mode on the dense form: one fp64 table image per workgroup in HBM (bitmap of the per-alignment window, mean,
   // ab, cd), written by the table build and read by the arbitration only
   size_t ximg_stride = 0;
   if (exact && mode == NDTPSO_SCORE_F32 && plan.path == 2) {
     ximg_stride = (size_t)round_up(image_bytes(plan.dense_cap / 32 + 2, wn.rec_cap), 256);
-    HIP_TRY(c, c->ximg.reserve(ximg_stride * n_pairs * (size_t)K));
+    HIP_TRY(c, c->ximg.reserve(ximg_stride * n_units * (size_t)K));
   }
   unsigned char* d_ximg = ximg_stride ? (unsigned char*)c->ximg.p : nullptr;
   // a gated launch of a kernel that strides (gate_strides): eight workgroups, or twice the pairs the last gated launch of this
@@ -2306,7 +2340,7 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   }
 #define LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX)                                                \
   do {                                                                                                             \
-    if (gate == 0) t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, NOCLIP, SWARM, BOX, true);        \
+    if (gate == 0 && !redo_list) t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, NOCLIP, SWARM, BOX, true); \
     if (gate != 0 && gate_strides<MODE, PATH, CL>() && gate_fb) {                                                  \
       launch_pairs_gated<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX>(dim3(gate_grid), dim3(waves * 64), lds_total, c->stream, d_ref, d_new, \
                        sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev, d_seeds, d_tables, stride,   \
@@ -2462,8 +2496,10 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
     HIP_TRY(c, hipHostMalloc((void**)&c->pairs_fb, 64, hipHostMallocMapped | hipHostMallocCoherent));
     std::memset(c->pairs_fb, 0, 64);
   }
+  uint32_t last_overflow = 0;  // pairs of the previous call (same configuration) whose box outgrew the two-per-CU table
   {
     uint64_t key = 1469598103934665603ull;
+    const uint64_t key_before = c->fb_key;
     auto mix = [&key](uint64_t v) { key = (key ^ v) * 1099511628211ull; };
     mix(geom->n_beams), mix((uint64_t)(geom->max_range * 1024.f)), mix(grid->width), mix(grid->height), mix((uint64_t)(grid->cell_side * 65536.));
     mix((uint64_t)cfg->population), mix((uint64_t)mode), mix(exact ? 1 : 0);
@@ -2493,6 +2529,7 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
       c->fb_big_first = false;
       c->fb_big_calls = 0;
     }
+    last_overflow = (key == key_before) ? now - c->fb_seen : 0u;
     c->fb_seen = now;
     c->fb_last_pairs = n_pairs;
   }
@@ -2501,7 +2538,34 @@ static int align_pairs_dev_on_stream(ndtpso_ctx* c, uint32_t n_pairs, const floa
                         st, 0u, true, &path, small_batch, exact, big_first, &shrunk, big_first ? nullptr : c->pairs_fb);
   if (big_first) shrunk = false;  // (nothing larger to fall back to)
   if (rc != NDTPSO_OK) return rc;
-  if (std::getenv("NDTPSO_NO_REDO")) return rc;  // diagnostics only
+  if (no_redo_requested()) return rc;  // diagnostics only
+  // A FEW flagged pairs in a batch that fills the device (1081 beams at 0.25 m: 7 rooms of 512 outgrow the table): on one
+  // workgroup each, behind the main launch, they took as long again as the whole batch (fp64 score: 2.8 ms after 5.1 ms).  They
+  // run as CLUSTERS instead -- the fp64 score on K workgroups per pair, as a batch too small for the device does -- through a
+  // list a one-wave kernel makes of them: 0.9 ms.  Tried only where the previous calls of the configuration saw flagged pairs
+  // (the list's own count, the striding redo's count, the main launch's overflow count: pinned words), for up to 32 of them,
+  // with one batch at a time in the context (two in flight: the other lane's workgroups hold the compute units a cluster needs
+  // together).  Whatever it does not serve -- pairs beyond the list, a cluster that gave up -- keeps its flags and goes through
+  // the gated launches below as before.  Results: the fp64 score's, whichever form computes them.  NDTPSO_REDO_CLUSTERS=0: off.
+  const char* redo_env = std::getenv("NDTPSO_REDO_CLUSTERS");
+  if (!(redo_env && redo_env[0] == '0') && !small_batch && c->pipe_depth < 2 && (exact || mode == NDTPSO_SCORE_F64)) {
+    const uint32_t mask = exact ? (kStatusNeedsF64 | kStatusNeedsBitmap) : kStatusNeedsBitmap;
+    uint32_t* seen_w = c->pairs_fb + 8 + (exact ? 1 : 0);
+    const uint32_t seen = std::max(std::max(__atomic_load_n(seen_w, __ATOMIC_RELAXED), __atomic_load_n(c->pairs_fb + 7, __ATOMIC_RELAXED)),
+                                   (path == 2 || path >= 8) ? last_overflow : 0u);
+    if (seen >= 1u && seen <= 32u) {
+      const uint32_t cap = std::min<uint32_t>(n_pairs, std::max<uint32_t>(8u, 2u * seen));
+      HIP_TRY(c, c->redo_list.reserve((size_t)(1u + 64u) * sizeof(uint32_t)));
+      uint32_t* list = (uint32_t*)c->redo_list.p;
+      hipLaunchKernelGGL(k_redo_list, dim3(1), dim3(kWave), 0, c->stream, (const AlignStats*)st, n_pairs, mask, list, cap, seen_w);
+      HIP_TRY(c, hipGetLastError());
+      rc = launch_pairs(c, n_pairs, d_ref, d_new, geom, grid, d_guess, d_dev, cfg, d_seeds, d_tables, NDTPSO_SCORE_F64, d_pose, d_cost,
+                        st, 0u, true, nullptr, true, false, false, nullptr, nullptr, list, cap, mask);
+      if (rc != NDTPSO_OK && rc != NDTPSO_E_STATE) return rc;
+      if (rc == NDTPSO_OK) g_redo_cluster_launches.fetch_add(1, std::memory_order_relaxed);
+      rc = NDTPSO_OK;
+    }
+  }
   // Gated redo launches (every workgroup whose alignment is not flagged exits on its first instruction).  First of all: the
   // dense forms size their cell table so that two workgroups share a compute unit; an alignment whose box -- scan A's
   // occupied cells -- outgrew that table gets the same kernel again with the largest table a workgroup can hold (0.25 m cells,
@@ -2564,7 +2628,7 @@ static int resolve_flagged_pairs(ndtpso_ctx* c, size_t B, const float* ref_range
                                  const uint32_t* seeds, const int32_t* rand_tables, int mode, double* out_pose, double* out_cost,
                                  AlignStats* hs) {
   const size_t nb = geom->n_beams, n_draw = ndtpso_rand_draws(cfg);
-  if (std::getenv("NDTPSO_NO_REDO")) return NDTPSO_OK;  // (diagnostics: what the main launch alone left flagged)
+  if (no_redo_requested()) return NDTPSO_OK;  // (diagnostics: what the main launch alone left flagged)
   ndtpso_map* fb_map = nullptr;
   ndtpso_points *fb_a = nullptr, *fb_b = nullptr;
   int fb_rc = NDTPSO_OK;

@@ -2878,6 +2878,7 @@ __device__ unsigned g_polls;  // a cluster's first workgroup: sweeps of the exch
 #endif
 
 constexpr int kClusterNoHeartbeat = 2;  // ClusterP::flags
+constexpr int kClusterRedoShift = 8;    // ClusterP::flags >> 8: the status flags a redo launch on clusters serves (ndtpso_pairs_body.inc)
 struct ClusterP {
   int K, rank, stride;  // workgroups, this one's index, slots per exchange buffer
   int absent;           // test hooks: the workgroup of this rank leaves at once (-1: nobody), exercising the timeout; -(2 + r): rank r
@@ -2893,7 +2894,7 @@ struct ClusterP {
   int one_xcd;          // 1 + p: that mapping, cluster 0 on XCD p; 0: K consecutive workgroups per cluster (NDTPSO_CLUSTER_SPREAD=1, for comparison)
   int n;                // clusters in this launch
   int spec_off;         // LDS byte offset of the speculation scratch (16 (P + 1) doubles, SpecP), -1: none
-  double* spec;         // ... as a pointer (set by the kernel)
+  double* spec;         // ... as a pointer (set by the kernel; what the HOST puts here is a redo launch's list of pairs, or null)
   int flags;            // kClusterNoHeartbeat: the exchange does not wait for heartbeats (NDTPSO_CLUSTER_HEARTBEAT=0: tests, comparison)
 };
 

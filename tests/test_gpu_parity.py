@@ -816,6 +816,48 @@ def test_flagged_alignments_of_a_large_batch_are_redone_by_the_striding_kernels(
     assert np.abs(got["f64"][0][pick] - want).max() < 1e-9 and np.abs(got["f64"][1][pick] - wcost).max() < 1e-8
 
 
+def test_a_few_flagged_pairs_of_a_large_batch_are_redone_on_clusters(ctx, oracle, monkeypatch):
+    """Round 6: a handful of flagged pairs behind a batch that fills the device used to take as long again as the batch (one
+    workgroup each); once a configuration has been seen to flag a few, the next calls hand them -- through a list a one-wave
+    kernel makes (k_redo_list) -- to CLUSTERS of workgroups running the fp64 score.  600 pairs on 0.245 m cells: the calls that
+    went through clusters (the process counter says so) give, bit for bit, what NDTPSO_REDO_CLUSTERS=0 gives in both modes, no
+    flag is left, and with one workgroup of every cluster absent (test hook: the clusters run into their bounded wait and give
+    up) the pairs keep their flags for the gated launches and the results are the same again."""
+    from ndtpso_slam_amd import capi, synth
+    B, P, I, cs = 600, 24, 12, 0.245     # (10 pairs outgrow the fp64 score's table, 7 the exact mode's)
+    p = synth.make_pairs(B, seed=606)
+    geom, grid, cfg = _geom(p, capi), capi.Grid(FRAME_M, FRAME_M, cs), capi.PSOConfig.make(I, P)
+    args = (p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), DEVIATION, cfg)
+    monkeypatch.setenv("NDTPSO_NO_REDO", "1")
+    for mode in (capi.SCORE_EXACT, capi.SCORE_F64):
+        _, _, st0 = ctx.align_pairs(*args, seeds=p.seeds, mode=mode)
+        flagged = np.nonzero((st0["status"] & 0xffff) != 0)[0]
+        assert 1 <= flagged.size <= 32, (mode, flagged.size)
+    monkeypatch.delenv("NDTPSO_NO_REDO")
+    want = {}
+    monkeypatch.setenv("NDTPSO_REDO_CLUSTERS", "0")
+    for mode in (capi.SCORE_F64, capi.SCORE_EXACT):
+        before = capi.process_counters()["batches_redone_on_clusters"]
+        for _ in range(2):
+            want[mode] = ctx.align_pairs(*args, seeds=p.seeds, mode=mode)[:2]
+        assert capi.process_counters()["batches_redone_on_clusters"] == before
+    monkeypatch.delenv("NDTPSO_REDO_CLUSTERS")
+    for absent in (None, "1"):
+        if absent:
+            monkeypatch.setenv("NDTPSO_CLUSTER_TEST_ABSENT", absent)
+        for mode in (capi.SCORE_F64, capi.SCORE_EXACT):
+            before = capi.process_counters()["batches_redone_on_clusters"]
+            for rep in range(3):
+                pose, cost, st = ctx.align_pairs(*args, seeds=p.seeds, mode=mode)
+                assert ((st["status"] & 0xffff) == 0).all(), (mode, rep, absent, np.nonzero(st["status"] & 0xffff)[0][:10])
+                assert np.array_equal(pose, want[mode][0]) and np.array_equal(cost, want[mode][1]), (mode, rep, absent)
+            assert capi.process_counters()["batches_redone_on_clusters"] >= before + 2, (mode, absent)
+    monkeypatch.delenv("NDTPSO_CLUSTER_TEST_ABSENT")
+    owant, ocost, _ = oracle.align_pairs(p.ref_ranges[flagged[:8]], p.new_ranges[flagged[:8]], p.angle_min, p.angle_inc, p.range_max, 0.1,
+                                         FRAME_M, FRAME_M, cs, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P), p.seeds[flagged[:8]])
+    assert np.abs(want[capi.SCORE_F64][0][flagged[:8]] - owant).max() < 1e-9
+
+
 def test_wild_configurations_are_answered_exactly_or_refused_loudly():
     """tests/campaigns/wild_configs.py, 80 of its configurations (cells 0.1 - 2 m, frames 10 - 300 m and not square, 5 - 3000 beams,
     swarms of 1 - 300, batches of 1 - 700 pairs, sensors cut short or nearly blind, guesses metres off): fp64 == exact on every
