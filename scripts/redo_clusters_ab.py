@@ -1,7 +1,12 @@
+"""A few flagged pairs redone on clusters of workgroups (align_pairs_dev_on_stream, round 6) against the gated launches alone: eight
+shapes x {fp64, exact}, ms per 512-pair launch and the results, one process per setting (the outputs go to gpurun_out/):
+
+    NDTPSO_REDO_CLUSTERS=0 python scripts/redo_clusters_ab.py off; python scripts/redo_clusters_ab.py on    # "on" also compares
+"""
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ndtpso_slam_amd import capi, synth
 dev = torch.device("cuda", 0)
 P = I = 70
