@@ -3055,7 +3055,9 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
           if (cl.rank == 0 && lane_id() == 0) atomicAdd(&g_polls, 1u);
 #endif
           if (__all(ok)) break;
-          if (wall_clock64() - t0 > kClusterWaitTicks) {
+          // (a redo launch's clusters -- a few flagged pairs behind a batch, ndtpso_pairs_body.inc -- have the gated launches
+          // behind them and give up after an eighth of the wait: 2.5 ms, what the pair costs on one workgroup)
+          if (wall_clock64() - t0 > (((unsigned)cl.flags >> kClusterRedoShift) ? kClusterWaitTicks / 8 : kClusterWaitTicks)) {
             *timed_out = 1;
             break;
           }
