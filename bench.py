@@ -372,8 +372,12 @@ def main():
         out["rccl"] = None   # one rank, no process group: nothing was gathered (NDTPSO_BENCH_FORCE_DIST=1 takes the RCCL path anyway)
 
 
-    # single-pair latency (BASELINE config 2), rank 0 only
-    if rank == 0 and not args.no_latency:
+    # The extras (single-pair latency, the other score modes, config 5, the live sequences): rank 0 of a ONE-GPU run only.  With
+    # N > 1 the other ranks would sit in the closing barrier for as long as rank 0 takes over them -- minutes of a collective in
+    # flight on N - 1 devices for figures the N = 1 line of the same driver pass already carries.
+    extras = rank == 0 and world == 1 and not args.no_latency
+    # single-pair latency (BASELINE config 2)
+    if extras:
         torch.cuda.synchronize()
         lat = []
         for _ in range(5):
@@ -389,7 +393,7 @@ def main():
         out["extra"]["single_pair_latency_note"] = "one pair of this workload, %s score, spread over a cluster of workgroups" % args.score
 
     # the other score modes on the same workload and BASELINE config 5, timed here so that they are driver-visible
-    if rank == 0 and not args.no_latency:
+    if extras:
         def timed(n_pairs, m, steps, geom_, grid_, cfg_, ref_, new_, seeds_):
             for _ in range(2):
                 ctx.align_pairs_dev(n_pairs, ref_.data_ptr(), new_.data_ptr(), geom_, grid_, d_guess.data_ptr(), d_dev.data_ptr(),
@@ -441,7 +445,7 @@ def main():
 
     # the node's live sequence: loadLaser -> align -> update against an accumulating resident map,
     # default 30 x 50 PSO, rand() table from the host as the drop-in library passes it; rank 0 only, 60 scans
-    if rank == 0 and not args.no_latency:
+    if extras:
         try:
             out["extra"]["live_sequence"] = _live_sequence(ctx, capi, synth, mode)
         except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench run fails
