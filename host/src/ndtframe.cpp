@@ -56,7 +56,10 @@ NDTFrame::NDTFrame(Vector3d trans, unsigned short width_, unsigned short height_
   s_x_max = width / 2.;
   s_y_min = -height / 2.;
   s_y_max = height / 2.;
-  s_resident = ndtpso_host::resident_default();
+  // (a resident frame has fewer than 2^21 cells -- ndtpso_map_create, the insert's 32-bit sort key; the reference's `unsigned int
+  // numOfCells` has no such bound: 300 m at 0.2 m cells is 2.25 M -- so a larger frame keeps its cells here, on the host's side of
+  // the C-ABI, as every frame did before round 3: same device kernels for the table, the score and the PSO, same results)
+  s_resident = ndtpso_host::resident_default() && numOfCells < (1u << 21);
 #if BUILD_OCCUPANCY_GRID
   s_occupancy_grid.cell_size = occupancy_grid_cell_size;  // ndtframe.cpp:32-46; 0 = no grid (intermediate frames)
   if (occupancy_grid_cell_size > 0.) {

@@ -552,14 +552,16 @@ def test_short_lived_threads_recycle_their_device_contexts():
 
 
 @pytest.mark.gpu
-def test_node_replay_on_a_frame_of_a_million_cells(tmp_path):
+@pytest.mark.parametrize("cell", ["0.25", "0.2"])
+def test_node_replay_on_a_frame_of_a_million_cells(tmp_path, cell):
     """A 300 m frame of 0.25 m cells (1.44 M cells; the reference spends 11 GB of host memory on it): until round 6 the resident
     frame refused anything beyond ~650 000 cells because its table packer sized its LDS for the whole grid; it is the box of the
-    BUILT cells that has to fit.  60 scans of the node sequence through the drop-in -- resident frames with and without clusters,
-    host-kept frames -- and the oracle: every pose identical (tests/campaigns/soak_replay.py)."""
+    BUILT cells that has to fit.  And of 0.2 m cells (2.25 M, beyond the 2^21 cells a resident frame can have): the drop-in keeps
+    such a frame's cells on its own side of the C-ABI.  60 scans of the node sequence through the drop-in -- resident frames with
+    and without clusters, host-kept frames -- and the oracle: every pose identical (tests/campaigns/soak_replay.py)."""
     import sys
     _build()
-    env = dict(os.environ, SOAK_FRAME="300", SOAK_CELL="0.25", SOAK_SCORE="exact")
+    env = dict(os.environ, SOAK_FRAME="300", SOAK_CELL=cell, SOAK_SCORE="exact")
     env.pop("NDTPSO_ABORT_ON_ERROR", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "campaigns", "soak_replay.py"), "60", "--oracle"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
