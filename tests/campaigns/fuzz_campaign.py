@@ -18,7 +18,7 @@ for k in range(n):
     if os.environ.get("FUZZ_WIDE"):   # frames and cells far from the suite's: up to 150 m, down to 0.15 m
         fw, fh = int(rng.choice([8, 20, 40, 60, 100, 150])), int(rng.choice([8, 20, 40, 60, 100, 150]))
         cs = float(rng.choice([0.15, 0.2, 0.25, 0.3, 0.5, 1.0]))
-        while (fw / cs) * (fh / cs) > 600000:   # (a resident frame holds ~650 000 cells at most: DESIGN 7)
+        while (fw / cs) * (fh / cs) > 2000000:   # (a resident frame has fewer than 2^21 cells: DESIGN 7)
             cs *= 2
     ogcs = float(rng.choice([0.0, 0.1, 0.2, 0.25, 0.5]))
     if ogcs > cs: ogcs = 0.0
