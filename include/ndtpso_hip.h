@@ -424,7 +424,7 @@ int ndtpso_device_math(ndtpso_ctx *ctx, int kind, const double *x, uint32_t n, d
  * point, any context of the process) first sends a fixed small problem through EVERY kernel instantiation that arbitrates
  * and that the library's dispatchers can reach -- the fused pairs kernels over table-entry form x {one workgroup per
  * alignment without / with clipping trips, clusters of workgroups} x swarm in LDS / in HBM x plain / box-guard copies, and the
- * lone alignment's kernel (ndtpso_align, ndtpso_map_align) on one workgroup and on a cluster: 15 families, each forced by a
+ * lone alignment's kernel (ndtpso_align, ndtpso_map_align) on one workgroup and on a cluster: 16 families, each forced by a
  * plan override and confirmed by the instantiation its launch recorded -- in the exact mode and in NDTPSO_SCORE_F64, and
  * compares poses and costs bit for bit (and checks, per family, that comparisons were in fact arbitrated).  If any family
  * differs the device is refused the exact mode: every later request for it runs NDTPSO_SCORE_F64 (the same results by

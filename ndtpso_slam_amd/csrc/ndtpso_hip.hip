@@ -635,7 +635,7 @@ __device__ __attribute__((noinline)) void box_guard_wg(const float* __restrict__
 // 0 / 1 = only the LDS / only the HBM copy.  The NOCLIP kernels -- the ones the batches of the benchmark run -- exist as
 // 0 and 1: at 128 registers what is inlined beside the hot loop decides its allocation (fp32-score kernel of config 3:
 // 21 spills with both copies, none with its own).
-template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, int SWARM = 2, bool BOX = false>
+template <int MODE, int PATH, bool CLUSTER, bool ARB = false, bool NOCLIP = false, int SWARM = 2, bool BOX = false, bool PAIR = false>
 __global__ void __launch_bounds__(CLUSTER ? kClusterMaxThreads : 1024)
 k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ new_ranges, ScanP sp, GridP g, WinP wn,
               Layout L, DenseP dn, int dense_cap, PsoP ps, const double* __restrict__ guess,
@@ -644,6 +644,7 @@ k_align_pairs(const float* __restrict__ ref_ranges, const float* __restrict__ ne
               double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl,
               const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride,
               uint32_t* __restrict__ feedback /* counts the alignments whose box outgrew the cell table (pinned host word) */) {
+  static_assert(!PAIR || (SWARM == 0 && NOCLIP && !CLUSTER && !BOX), "two items per wave: the batches' kernels with the swarm in LDS");
   size_t b = blockIdx.x;
 #include "ndtpso_pairs_body.inc"
 }
@@ -658,6 +659,7 @@ align_pair_wg(size_t b, const float* __restrict__ ref_ranges, const float* __res
               double* __restrict__ out_cost, AlignStats* __restrict__ stats, uint32_t gate, ClusterP cl,
               const double2* __restrict__ beam_dirs, unsigned char* __restrict__ ximg, size_t ximg_stride,
               uint32_t* __restrict__ feedback) {
+  constexpr bool PAIR = false;  // (two items per wave: main launches only)
 #include "ndtpso_pairs_body.inc"
 }
 
@@ -1078,17 +1080,18 @@ struct PlanForce {
   int table_side = 0;     // > 0: the fused kernels' dense table provisioned as side x side entries (a shrunk table)
   int boxy = -1;          // 1 / 0: the box-guard copies / the plain ones, whatever the table's share of the static window
   int cluster = -1;       // 1 / 0: a batch as clusters of workgroups / one workgroup per alignment, whatever its size
+  int pair = -1;          // 1 / 0: the kernels that score two items per wave / one, whatever the scan's length (k_align_pairs<..., PAIR>)
 };
 thread_local PlanForce t_plan_force;
 thread_local bool t_in_exact_check = false;  // this thread is running the start-up check of the exact mode (ndtpso_selftest.inc)
 // NDTPSO_NO_REDO (diagnostics: what the main launch alone leaves flagged) -- not for the start-up check's own batches
 static bool no_redo_requested() { return !t_in_exact_check && std::getenv("NDTPSO_NO_REDO") != nullptr; }
 // what the last main (ungated) launch of this thread was: k_align_pairs / k_align instantiation as
-// PATH | CL << 4 | ARB << 5 | NOCLIP << 6 | SWARM << 7 | BOX << 9 | (fused pairs kernel) << 10 | (fp64 score) << 11
+// PATH | CL << 4 | ARB << 5 | NOCLIP << 6 | SWARM << 7 | BOX << 9 | (fused pairs kernel) << 10 | (fp64 score) << 11 | (two items per wave) << 12
 thread_local uint32_t t_last_launch = 0;
-constexpr uint32_t launch_code(bool f64, int path, bool cl, bool arb, bool noclip, int swarm, bool box, bool pairs) {
+constexpr uint32_t launch_code(bool f64, int path, bool cl, bool arb, bool noclip, int swarm, bool box, bool pairs, bool two_items = false) {
   return (uint32_t)path | (uint32_t)cl << 4 | (uint32_t)arb << 5 | (uint32_t)noclip << 6 | (uint32_t)swarm << 7 | (uint32_t)box << 9 |
-         (uint32_t)pairs << 10 | (uint32_t)f64 << 11;
+         (uint32_t)pairs << 10 | (uint32_t)f64 << 11 | (uint32_t)two_items << 12;
 }
 
 // `wn` is the staging window: final for a prebuilt table; for the fused pairs kernel (dynamic_window) it is the
@@ -1216,6 +1219,20 @@ hipError_t allow_big_lds(K kernel) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
 }
 
+// the kernels that exist with two items per wave (k_align_pairs<..., PAIR = true>: short scans): the fp32 score's dense form
+// with byte entries, no clipping trips, the swarm in LDS, no box-guard copy -- with and without arbitration
+template <int MODE, int PATH, bool CL, bool NOCLIP, int SWARM, bool BOX>
+constexpr bool pair_items_kernel() {
+  return MODE == kScoreF32 && PATH == 3 && !CL && NOCLIP && SWARM == 0 && !BOX;
+}
+template <int MODE, int PATH, bool CL, bool ARB, bool NOCLIP, int SWARM, bool BOX, typename... Args>
+void launch_pairs_pair_items(dim3 grid, dim3 block, int lds, hipStream_t stream, Args... args) {
+  if constexpr (pair_items_kernel<MODE, PATH, CL, NOCLIP, SWARM, BOX>()) {
+    static const hipError_t big = allow_big_lds(k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX, true>);  // once per instantiation
+    (void)big;
+    hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX, true>), grid, block, lds, stream, args...);
+  }
+}
 // a gated launch of a kernel that strides (gate_strides): a function template, so that k_align_pairs_s exists only for those
 template <int MODE, int PATH, bool CL, bool ARB, bool NOCLIP, int SWARM, bool BOX, typename... Args>
 void launch_pairs_gated(dim3 grid, dim3 block, int lds, hipStream_t stream, Args... args) {
@@ -2338,14 +2355,28 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     gate_grid = std::min<uint32_t>(n_pairs, std::max<uint32_t>(8u, 2u * seen));
     if (const char* e = std::getenv("NDTPSO_GATE_GRID")) gate_grid = std::min<uint32_t>(n_pairs, (uint32_t)std::max(1, std::atoi(e)));  // (diagnostics)
   }
+  // Two items per wave (eval_pair_half, k_align_pairs<..., PAIR>): scans of up to nine chunks -- 361 beams + 10-12 %, 541 beams
+  // + 1-5 %, nothing beyond (an evaluation's fixed part is a third of a six-chunk list's time and a tenth of a seventeen-chunk
+  // one's).  NDTPSO_PAIR_ITEMS=0: never.  (The build that verifies the margin per evaluation has its hooks in the one-item forms.)
+#ifdef NDTPSO_VERIFY_MARGIN
+  const bool pair_items = false;
+#else
+  const char* pair_env = std::getenv("NDTPSO_PAIR_ITEMS");
+  const bool pair_items = t_plan_force.pair >= 0 ? t_plan_force.pair != 0 : (!(pair_env && pair_env[0] == '0') && geom->n_beams <= 576u);
+#endif
 #define LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX)                                                \
   do {                                                                                                             \
-    if (gate == 0 && !redo_list) t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, NOCLIP, SWARM, BOX, true); \
+    if (gate == 0 && !redo_list) t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, NOCLIP, SWARM, BOX, true, pair_items && pair_items_kernel<MODE, PATH, CL, NOCLIP, SWARM, BOX>()); \
     if (gate != 0 && gate_strides<MODE, PATH, CL>() && gate_fb) {                                                  \
       launch_pairs_gated<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX>(dim3(gate_grid), dim3(waves * 64), lds_total, c->stream, d_ref, d_new, \
                        sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev, d_seeds, d_tables, stride,   \
                        (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, cl, dirs, d_ximg,        \
                        ximg_stride, fb, n_pairs, gate_fb);                                                         \
+    } else if (pair_items && gate == 0 && pair_items_kernel<MODE, PATH, CL, NOCLIP, SWARM, BOX>()) {               \
+      launch_pairs_pair_items<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX>(dim3(n_pairs), dim3(waves * 64), lds_total, \
+                           c->stream, d_ref, d_new, sp, g, wn, plan.L, plan.dn, plan.dense_cap, ps, d_guess, d_dev, \
+                           d_seeds, d_tables, stride, (unsigned char*)c->ws.p, ws_stride, d_pose, d_cost, d_stats, gate, \
+                           cl, dirs, d_ximg, ximg_stride, fb);                                                     \
     } else {                                                                                                       \
       hipLaunchKernelGGL((k_align_pairs<MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX>),                                 \
                          dim3(CL ? cluster_grid(cl) : n_pairs), dim3(waves * 64), lds_total,                       \

@@ -697,6 +697,109 @@ __device__ __forceinline__ void noclamp_trips(const GridP& g, const DenseP& dn, 
   }
 }
 
+// ---- two items per wave (short lists: NDTPSO_PAIR_ITEMS kernels) ---------------------------------------------------------
+// An evaluation of a few chunks is mostly what surrounds its trips -- the ticket, the item's record, the lane reduction, the
+// decision: 80 of 195 vector instructions at six chunks (profiles/r06_phase_budget_361.json).  Here a wave scores TWO items at
+// once, lanes 0-31 the first and lanes 32-63 the second, each half over the whole list 32 points at a time: the trips' work
+// per item is what it was (an instruction costs the same with 32 lanes busy or 64 ... both halves are busy), everything around
+// them is done once for the two.  The pose constants are per-lane registers in the one-item trips already.  No-clamp form
+// only (both items inside the DenseGuard; the caller takes anything else through the one-item forms).  The sum of an item is
+// its half's: per lane the list's half-chunks in order, groups of four folded in fp32 like the one-item trips' chunks, then
+// the 32 lanes by the first five steps of wave_sum -- another order than the one-item forms' (the fp32 mode's costs differ in
+// the last bits between the two kinds of kernel; which kind runs is decided by the scan's length alone).
+template <int U, bool BYTE, bool MASKLAST>
+__device__ __forceinline__ void score_trip_half(const DenseP& dn, const double2* __restrict__ pts, int base, int n,
+                                                const DenseItem& it, double& acc) {
+  const int hl = lane_id() & 31;
+  double2 p[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) p[u] = pts[base + u * 32 + hl];
+  double gx[U], gy[U];
+  unsigned lin[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    gx[u] = fma(p[u].x, it.C, fma(-p[u].y, it.S, it.TX));
+    gy[u] = fma(p[u].x, it.S, fma(p[u].y, it.C, it.TY));
+    const unsigned rx = (unsigned)(int)gx[u], ry = (unsigned)(int)gy[u];
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lin[u]) : "v"(ry), "s"((unsigned)dense_stride(dn.dw)), "v"(rx));
+    if constexpr (MASKLAST)
+      if (u == U - 1) lin[u] = (base + u * 32 + hl < n) ? lin[u] : 0u;
+  }
+  typedef const unsigned short __attribute__((address_space(3))) * lds_u16_t;
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  typedef const v2d_t __attribute__((address_space(3))) * lds_d2_t;
+  unsigned e[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) e[u] = *(lds_u16_t)(uintptr_t)(lin[u] << 1);
+  v2d_t ra[U], rb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned r = BYTE ? e[u] : e[u] << 4;
+    ra[u] = *(lds_d2_t)(uintptr_t)r;
+    rb[u] = *(lds_d2_t)(uintptr_t)(r + kDenseRecBOff);
+  }
+  float t[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const float l11 = __int_as_float(__double2loint(rb[u].y)), l22 = __int_as_float(__double2hiint(rb[u].y));
+    const float a = l11 * (float)(fma(ra[u].x, gy[u], gx[u]) + ra[u].y);
+    const float b = l22 * (float)(gy[u] - rb[u].x);
+    t[u] = __builtin_amdgcn_exp2f(-fmaf(a, a, b * b));
+  }
+  // (fp32 within a trip -- a group of four, then what is left of the trip -- fp64 across trips)
+  if constexpr (U == 6) {
+    acc += (double)((t[0] + t[1]) + (t[2] + t[3]));
+    acc += (double)(t[4] + t[5]);
+  } else if constexpr (U == 5) {
+    acc += (double)((t[0] + t[1]) + (t[2] + t[3]));
+    acc += (double)t[4];
+  } else if constexpr (U == 4)
+    acc += (double)((t[0] + t[1]) + (t[2] + t[3]));
+  else if constexpr (U == 3)
+    acc += (double)((t[0] + t[1]) + t[2]);
+  else if constexpr (U == 2)
+    acc += (double)(t[0] + t[1]);
+  else
+    acc += (double)t[0];
+}
+// -> the item's cost in lane 31 (first item) and lane 63 (second item) only
+template <bool BYTE>
+__device__ __forceinline__ double eval_pair_half(const DenseP& dn, const double2* __restrict__ pts, int n, const DenseItem& it) {
+  double acc = 0.;
+  const int n_pad = round_up(n, 32), chunks = n_pad >> 5;
+  if (chunks > 0) {
+    // trips of up to six half-chunks, as even as they come (three dependent LDS round trips per trip are what a wave waits
+    // for): 12 -> 6 + 6, 17 -> 6 + 6 + 5, 23 -> 6 + 6 + 6 + 5; the list's last trip masks its padding
+    const int trips = (chunks + 5) / 6, small = chunks / trips, larger = chunks - small * trips;  // `larger` trips of small + 1 first
+    int base = 0;
+    for (int t = 0; t < trips; ++t) {
+      const int u = small + (t < larger ? 1 : 0);
+      if (t + 1 < trips) {
+        if (u == 6) score_trip_half<6, BYTE, false>(dn, pts, base, n, it, acc);
+        else if (u == 5) score_trip_half<5, BYTE, false>(dn, pts, base, n, it, acc);
+        else score_trip_half<4, BYTE, false>(dn, pts, base, n, it, acc);  // (several trips: none shorter than four)
+      } else {
+        switch (u) {
+          case 6: score_trip_half<6, BYTE, true>(dn, pts, base, n, it, acc); break;
+          case 5: score_trip_half<5, BYTE, true>(dn, pts, base, n, it, acc); break;
+          case 4: score_trip_half<4, BYTE, true>(dn, pts, base, n, it, acc); break;
+          case 3: score_trip_half<3, BYTE, true>(dn, pts, base, n, it, acc); break;
+          case 2: score_trip_half<2, BYTE, true>(dn, pts, base, n, it, acc); break;
+          default: score_trip_half<1, BYTE, true>(dn, pts, base, n, it, acc); break;
+        }
+      }
+      base += u * 32;
+    }
+  }
+  double v = acc;
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  v += dpp_f64<0x141>(v);
+  v += dpp_f64<0x140>(v);
+  v += dpp_bcast_f64<0x142, 0xa>(v);  // row_bcast:15: lane 31 = rows 0 + 1, lane 63 = rows 2 + 3
+  return -v;
+}
+
 // the same with the folded constants already at hand (the PSO keeps them with each proposal)
 // NOCLIP: the kernel was chosen by the host for a grid whose cells do not overhang the frame (DenseP::clip == 0), and
 // carries none of the clipping variants of the trips.
@@ -2710,13 +2813,98 @@ __device__ __forceinline__ int take_ticket(int* counter, int* spare /* 32 words 
   const int v = __hip_atomic_fetch_add(a, lane == 0 ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   return __builtin_amdgcn_readfirstlane(v);
 }
+__device__ __forceinline__ int take_two_tickets(int* counter, int* spare /* 32 words */) {  // (the pair kernels: items j, j + 1)
+  typedef int __attribute__((address_space(3))) * lds_int_t;
+  const int lane = lane_id();
+  lds_int_t a = lane == 0 ? (lds_int_t)counter : (lds_int_t)spare + (lane & 31);
+  const int v = __hip_atomic_fetch_add(a, lane == 0 ? 2 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  return __builtin_amdgcn_readfirstlane(v);
+}
 
-template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false, bool BOX = false>
+template <int MODE, int PATH, bool ARB = false, bool NOCLIP = false, bool BOX = false, bool PAIR = false>
 __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, const Swarm& sw, int S, int P, double gbc,
                                    int* ticket, int* spare, int* improver, int* jmax, int* tiny, int* near_cnt,
                                    unsigned short* near_list) {
   typedef int __attribute__((address_space(3))) * lds_int_t;
   int last_done = -1;
+  if constexpr (PAIR) {
+    // ---- two items per wave (eval_pair_half): tickets j and j + 1 at once ----
+    static_assert(!PAIR || (MODE == kScoreF32 && (PATH == 3 || PATH == 2) && NOCLIP), "the pair form: fp32 score, dense table, no clipping trips");
+    unsigned late;
+    asm("s_cmp_ge_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0"
+        : "=s"(late)
+        : "s"(__builtin_amdgcn_readfirstlane((unsigned)blockIdx.x)), "s"(__builtin_amdgcn_readfirstlane((unsigned)gridDim.x >> 1))
+        : "scc");
+    // what lane 0 does with an item's cost in the one-item loop below, by the lane that holds it
+    auto decide = [&](int j, double cost, double pbc_j) {
+      sw.tcost[j] = cost;
+      bool ordinary = true;
+      if (!(cost <= -kTinyCost)) {
+        if (cost != cost || (!ARB && pbc_j > -kTinyCost)) {
+          if constexpr (ARB)
+            *(lds_int_t)tiny = 0;
+          else
+            __hip_atomic_fetch_min((lds_int_t)tiny, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          ordinary = false;
+        }
+      }
+      if constexpr (ARB) {
+        const double tau = arb_margin(gbc, n);
+        const double d1 = cost - pbc_j, d2 = cost - gbc;
+        if (ordinary && !(fmin(d1, d2) > tau)) {
+          if (cost < gbc)
+            if (cost < pbc_j) __hip_atomic_fetch_min((lds_int_t)improver, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (fabs(d1) <= tau || fabs(d2) <= tau) *(lds_int_t)near_cnt = 1;
+        }
+      } else {
+        if (ordinary && cost < gbc)
+          if (cost < pbc_j) __hip_atomic_fetch_min((lds_int_t)improver, j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    };
+    for (;;) {
+      const int seen = __hip_atomic_load((lds_int_t)improver, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int j = take_two_tickets(ticket, spare);
+      if (j >= P || j > seen) break;
+      {
+        unsigned long long now;
+        unsigned turn;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now));
+        asm("s_bfe_u32 %0, %1, 0x40009\n\ts_cmp_lt_u32 %0, %2\n\ts_cselect_b32 %0, 1, 0" : "=&s"(turn) : "s"((unsigned)now), "n"(NDTPSO_PRIO_SHARE) : "scc");
+        if (turn == late)
+          __builtin_amdgcn_s_setprio(1);
+        else
+          __builtin_amdgcn_s_setprio(0);
+      }
+      const bool has_b = j + 1 < P && j + 1 <= seen;  // (uniform)
+      const bool g_a = BOX ? *reinterpret_cast<const unsigned*>(sw.tgd + 4 * j) == 0x01010101u
+                           : *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * j) == 0x0101u;
+      const bool g_b = !has_b || (BOX ? *reinterpret_cast<const unsigned*>(sw.tgd + 4 * (j + 1)) == 0x01010101u
+                                      : *reinterpret_cast<const unsigned short*>(sw.tgd + 2 * (j + 1)) == 0x0101u);
+      last_done = has_b ? j + 1 : j;
+      if (g_a && g_b) {  // both inside the guard: one pass of the list for the two
+        const bool second = lane_id() >= 32;
+        const int jl = (second && has_b) ? j + 1 : j;
+        const DenseItem it{sw.it[4 * jl], sw.it[4 * jl + 1], sw.it[4 * jl + 2], sw.it[4 * jl + 3], E.dn.xmax, E.dn.ymax};
+        const double pbc_l = sw.pbc[jl];
+        const double cost = eval_pair_half<PATH == 3>(E.dn, pts, n, it);
+        if ((lane_id() & 31) == 31 && (!second || has_b)) decide(jl, cost, pbc_l);
+      } else {  // an item outside the guard: the one-item forms, one after the other
+        for (int q = 0; q < (has_b ? 2 : 1); ++q) {
+          const int jq = j + q;
+          const DenseItem it{sw.it[4 * jq], sw.it[4 * jq + 1], sw.it[4 * jq + 2], sw.it[4 * jq + 3], E.dn.xmax, E.dn.ymax};
+          const double pbc_q = sw.pbc[jq];
+          double cost;
+          if (q == 0 ? g_a : g_b)
+            cost = eval_item_wave_dense<false, PATH == 3, true, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
+          else
+            cost = eval_item_wave_dense<false, PATH == 3, false, NOCLIP>(E.g, E.dn, E.lds0, pts, n, it);
+          if (lane_id() == 0) decide(jq, cost, pbc_q);
+        }
+      }
+    }
+    if (lane_id() == 0 && last_done >= 0) __hip_atomic_fetch_max((lds_int_t)jmax, last_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
 #if NDTPSO_ALTERNATE_PRIO
   // (the turn is worked out on the scalar unit, spelt in its own instructions: as C the compiler made a 64-bit vector
   // compare and two selects per item of it -- the clock's value counts as divergent -- whatever was wrapped in readfirstlane)
@@ -3095,7 +3283,7 @@ __device__ inline void eval_round(const EvalCtx& E, const double2* pts, int n, c
 // ARB: the exact mode (NDTPSO_SCORE_EXACT) of the fp32-score dense kernels.  A template parameter, not a run-time
 // switch: the arbitration code in the same kernel cost the plain fp32 mode 11 % (register pressure: spills in the
 // proposal / commit paths), see DESIGN.md.
-template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false, bool KGEN = false, bool UNITS = false, bool BOX = false>
+template <int MODE, int PATH, bool CLUSTER = false, bool ARB = false, bool NOCLIP = false, bool KGEN = false, bool UNITS = false, bool BOX = false, bool PAIR = false>
 __device__ inline bool pso_run_wg(const EvalCtx& E,
                                   const double2* pts, int n, const PsoP& ps, const double* guess,
                                   const double* dev, uint32_t seed, const int32_t* table, const Swarm& sw,
@@ -3450,7 +3638,7 @@ __device__ inline bool pso_run_wg(const EvalCtx& E,
           next_filled = n_draw;
         }
         NDTPSO_PB(5);
-        eval_stream<MODE, PATH, ARB, NOCLIP, BOX>(E, pts, n, sw, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny_j,
+        eval_stream<MODE, PATH, ARB, NOCLIP, BOX, PAIR>(E, pts, n, sw, S, P, gbc_phase, &sh->ticket, sh->spare, &sh->jstar[slot], &sh->jmax, &sh->tiny_j,
                                              &sh->near_cnt[slot], sh->near_list[slot]);
         NDTPSO_PB(4);
         __syncthreads();

@@ -54,7 +54,7 @@ def test_shipped_library_passes_its_start_up_check():
     # every arbitrating kernel instantiation the dispatchers can reach went through the check, each confirmed by the launch it
     # recorded, each with comparisons arbitrated, none differing from the fp64 mode
     fam = d["check"]["report"]["families"]
-    assert len(fam) == 15 and len({f["instantiation"] for f in fam}) == 14, fam    # (swarm in HBM under the clipping kernel: the same
+    assert len(fam) == 16 and len({f["instantiation"] for f in fam}) == 15, fam    # (swarm in HBM under the clipping kernel: the same
     for f in fam:                                                                  #  instantiation, another branch of it)
         assert f["state"] == "passed" and f["launched"] == f["instantiation"] and f["arbitrated"] > 0 and f["mismatched"] == 0, f
 
@@ -69,7 +69,7 @@ def test_a_library_with_a_broken_arbitration_is_refused_the_exact_mode():
     assert "refused" in d["err"] and "refused" in stderr, (d, stderr[-500:])
     # ... by EVERY family of the check: each was reached, and each saw costs that differ from the fp64 mode's
     fam = d["check"]["report"]["families"]
-    assert len(fam) == 15
+    assert len(fam) == 16
     for f in fam:
         assert f["state"] == "refused" and f["launched"] == f["instantiation"] and f["mismatched"] > 0, f
     # ... and what it returns for an exact-mode request is the fp64 mode's result, from the fp64 kernel: nothing arbitrated

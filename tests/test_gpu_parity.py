@@ -858,6 +858,36 @@ def test_a_few_flagged_pairs_of_a_large_batch_are_redone_on_clusters(ctx, oracle
     assert np.abs(want[capi.SCORE_F64][0][flagged[:8]] - owant).max() < 1e-9
 
 
+@pytest.mark.parametrize("n_beams", [181, 361, 541])
+def test_short_scans_two_items_per_wave(ctx, oracle, monkeypatch, n_beams):
+    """Round 6: batches of short scans (up to nine chunks of 64 points) run kernels whose waves score TWO particles at once, one
+    per half wave (k_align_pairs<..., PAIR>, eval_pair_half): everything around an evaluation's trips -- ticket, record, lane
+    reduction, decision -- done once for the two.  The sums are folded in another order than the one-item kernels', so: the exact
+    mode must not notice (poses AND costs bit for bit with NDTPSO_PAIR_ITEMS=0, and with the fp64 mode), the plain fp32 mode stays
+    within its tolerance of the oracle, and the poses are the oracle's.  300 pairs, 30 x 25 and 70 x 12 swarms."""
+    from ndtpso_slam_amd import capi, synth
+    B = 300
+    p = synth.make_pairs(B, n_beams=n_beams, seed=9000 + n_beams)
+    geom, grid = _geom(p, capi), capi.Grid(FRAME_M, FRAME_M, 0.5)
+    for P, I in ((30, 25), (70, 12)):
+        cfg = capi.PSOConfig.make(I, P)
+        args = (p.ref_ranges, p.new_ranges, geom, grid, (0, 0, 0), DEVIATION, cfg)
+        monkeypatch.setenv("NDTPSO_PAIR_ITEMS", "0")
+        one = {m: ctx.align_pairs(*args, seeds=p.seeds, mode=m) for m in (capi.SCORE_EXACT, capi.SCORE_F32)}
+        monkeypatch.delenv("NDTPSO_PAIR_ITEMS")
+        two = {m: ctx.align_pairs(*args, seeds=p.seeds, mode=m) for m in (capi.SCORE_EXACT, capi.SCORE_F32)}
+        f64 = ctx.align_pairs(*args, seeds=p.seeds, mode=capi.SCORE_F64)
+        for r in (one[capi.SCORE_EXACT], two[capi.SCORE_EXACT]):
+            assert np.array_equal(r[0], f64[0]) and np.array_equal(r[1], f64[1]) and ((r[2]["status"] & 0xffff) == 0).all()
+        assert two[capi.SCORE_EXACT][2]["arbitrated"].sum() > 0
+        # the fp32 mode: another summation order, the same tolerance (BASELINE: 1e-3 of the pose)
+        assert np.abs(two[capi.SCORE_F32][0] - f64[0]).max() < 1e-3 and np.abs(one[capi.SCORE_F32][0] - f64[0]).max() < 1e-3
+        k = 6
+        want, wcost, _ = oracle.align_pairs(p.ref_ranges[:k], p.new_ranges[:k], p.angle_min, p.angle_inc, p.range_max, 0.1, FRAME_M, FRAME_M,
+                                            0.5, (0, 0, 0), DEVIATION, oracle.PSOConfig.make(I, P), p.seeds[:k])
+        assert np.abs(f64[0][:k] - want).max() < 1e-9 and np.abs(f64[1][:k] - wcost).max() < 1e-8
+
+
 def test_wild_configurations_are_answered_exactly_or_refused_loudly():
     """tests/campaigns/wild_configs.py, 80 of its configurations (cells 0.1 - 2 m, frames 10 - 300 m and not square, 5 - 3000 beams,
     swarms of 1 - 300, batches of 1 - 700 pairs, sensors cut short or nearly blind, guesses metres off): fp64 == exact on every
