@@ -2357,13 +2357,9 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   }
   // Two items per wave (eval_pair_half, k_align_pairs<..., PAIR>): scans of up to nine chunks -- 361 beams + 10-12 %, 541 beams
   // + 1-5 %, nothing beyond (an evaluation's fixed part is a third of a six-chunk list's time and a tenth of a seventeen-chunk
-  // one's).  NDTPSO_PAIR_ITEMS=0: never.  (The build that verifies the margin per evaluation has its hooks in the one-item forms.)
-#ifdef NDTPSO_VERIFY_MARGIN
-  const bool pair_items = false;
-#else
+  // one's).  NDTPSO_PAIR_ITEMS=0: never.
   const char* pair_env = std::getenv("NDTPSO_PAIR_ITEMS");
   const bool pair_items = t_plan_force.pair >= 0 ? t_plan_force.pair != 0 : (!(pair_env && pair_env[0] == '0') && geom->n_beams <= 576u);
-#endif
 #define LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX)                                                \
   do {                                                                                                             \
     if (gate == 0 && !redo_list) t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, NOCLIP, SWARM, BOX, true, pair_items && pair_items_kernel<MODE, PATH, CL, NOCLIP, SWARM, BOX>()); \

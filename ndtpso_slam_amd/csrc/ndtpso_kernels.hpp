@@ -2887,6 +2887,15 @@ __device__ inline void eval_stream(const EvalCtx& E, const double2* pts, int n, 
         const DenseItem it{sw.it[4 * jl], sw.it[4 * jl + 1], sw.it[4 * jl + 2], sw.it[4 * jl + 3], E.dn.xmax, E.dn.ymax};
         const double pbc_l = sw.pbc[jl];
         const double cost = eval_pair_half<PATH == 3>(E.dn, pts, n, it);
+#ifdef NDTPSO_VERIFY_MARGIN
+        if constexpr (ARB) {
+          if (E.xa) {  // (both items' fp32 scores against their fp64 scores and the bound, as the one-item loop does)
+            const double cost_a = readlane_f64(cost, 31), cost_b = readlane_f64(cost, 63);
+            verify_item<PATH == 3>(E.xa, j, cost_a, gbc);
+            if (has_b) verify_item<PATH == 3>(E.xa, j + 1, cost_b, gbc);
+          }
+        }
+#endif
         if ((lane_id() & 31) == 31 && (!second || has_b)) decide(jl, cost, pbc_l);
       } else {  // an item outside the guard: the one-item forms, one after the other
         for (int q = 0; q < (has_b ? 2 : 1); ++q) {

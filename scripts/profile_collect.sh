@@ -37,7 +37,7 @@ for f in phase_budget_361 bench_self_launched_rccl bench_sharded_capi_g1 bench_s
 [ -f $SRC/verify_config3.json ] && python - <<PY
 import json
 out = {}
-for w in ("config3", "config4", "random", "converged", "config5"):
+for w in ("config3", "config4", "random", "converged", "config5", "short"):
     try:
         d = json.load(open("$SRC/verify_%s.json" % w))
         out[w] = {k: v for k, v in d.items() if k != "runs"}

@@ -38,6 +38,7 @@ timeout 300 python scripts/phase_budget.py --config config3 --score f32 --out $O
 timeout 400 python scripts/phase_budget.py --config config5 --score exact --out $OUT/phase_budget_config5.json >> $OUT/budget.log 2>&1
 # device timeline of the live sequence (C++ drop-in, node replay): kernel spans folded over the scans
 timeout 300 python scripts/live_timeline.py run $OUT/live 200 > $OUT/live_timeline.log 2>&1; rm -rf $OUT/live/trace
+[ -n "$SKIP_VERIFY" ] || timeout 600 python scripts/verify_margin.py --workload short > $OUT/verify_short.json 2>> $OUT/verify.err
 [ -n "$SKIP_VERIFY" ] || for w in config3 config4 random converged config5; do timeout 600 python scripts/verify_margin.py --workload $w $( [ $w = config5 ] && echo --pairs 130 ) > $OUT/verify_$w.json 2>> $OUT/verify.err; done
 # the binning's statistics over 1e12 point evaluations (config 3 x 400 launches of other pairs and seeds) and random configurations
 [ -n "$SKIP_VERIFY" ] || timeout 900 python scripts/verify_margin.py --workload config3 --repeat 400 > $OUT/verify_binning_config3_x400.json 2>> $OUT/verify.err

@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config5", "random", "converged"])
+    ap.add_argument("--workload", default="config3", choices=["config3", "config4", "config5", "random", "converged", "short"])
     ap.add_argument("--pairs", type=int, default=0)
     ap.add_argument("--seed", type=int, default=2024)
     ap.add_argument("--repeat", type=int, default=1,
@@ -45,6 +45,10 @@ def main():
             runs.append(dict(pairs=512, beams=1081, cs=0.5, P=70, I=70, dev=(0.1, 0.1, 3.1415e-3), seed=2024, first=512 * k, total=4096))
     elif args.workload == "config5":
         runs.append(dict(pairs=args.pairs or 2, beams=2048, cs=0.25, P=2048, I=200, dev=(0.1, 0.1, 3.1415e-3), seed=21))
+    elif args.workload == "short":   # short scans: the kernels that score two items per wave (eval_pair_half), swarms wide and converged
+        for k, (nb, cs) in enumerate(((361, 0.5), (181, 0.5), (541, 1.0), (361, 0.3), (500, 0.5), (97, 0.5))):
+            runs.append(dict(pairs=args.pairs or 300, beams=nb, cs=cs, P=(70, 30, 70, 24, 64, 17)[k], I=(40, 50, 30, 30, 20, 40)[k],
+                             dev=tuple(10.0 ** -(k % 3) * np.array([0.1, 0.1, 3e-3])), seed=500 + k))
     elif args.workload == "converged":   # tight deviations: the swarm converges, near-ties everywhere
         for k in range(4):
             runs.append(dict(pairs=args.pairs or 160, beams=1081, cs=0.5, P=30, I=50, dev=tuple(10.0 ** -(k + 2) * np.array([1, 1, 0.03])), seed=90 + k))
