@@ -2359,7 +2359,11 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
   // + 1-5 %, nothing beyond (an evaluation's fixed part is a third of a six-chunk list's time and a tenth of a seventeen-chunk
   // one's).  NDTPSO_PAIR_ITEMS=0: never.
   const char* pair_env = std::getenv("NDTPSO_PAIR_ITEMS");
-  const bool pair_items = t_plan_force.pair >= 0 ? t_plan_force.pair != 0 : (!(pair_env && pair_env[0] == '0') && geom->n_beams <= 576u);
+  static const uint32_t pair_max_beams = [] {  // (NDTPSO_PAIR_MAX_BEAMS: diagnostics -- where the two kinds of kernel cross over)
+    const char* e = std::getenv("NDTPSO_PAIR_MAX_BEAMS");
+    return e ? (uint32_t)std::max(0, std::atoi(e)) : 576u;
+  }();
+  const bool pair_items = t_plan_force.pair >= 0 ? t_plan_force.pair != 0 : (!(pair_env && pair_env[0] == '0') && geom->n_beams <= pair_max_beams);
 #define LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX)                                                \
   do {                                                                                                             \
     if (gate == 0 && !redo_list) t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, NOCLIP, SWARM, BOX, true, pair_items && pair_items_kernel<MODE, PATH, CL, NOCLIP, SWARM, BOX>()); \
