@@ -133,7 +133,7 @@ def main():
     ctx = capi.Context(local_rank)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
-    # the exact mode's once-per-process self check (ndtpso_exact_check, ~30 ms) now, whatever --warmup is: never inside the timed region
+    # the exact mode's once-per-process self check (ndtpso_exact_check, ~40 ms) now, whatever --warmup is: never inside the timed region
     exact_check = ctx.exact_check() if mode == capi.SCORE_EXACT else None
 
     d_ref = torch.from_numpy(pairs.ref_ranges).to(dev)
