@@ -2,6 +2,9 @@
 name) out of each library's gfx950 code object and compares the instruction streams (addresses and symbol offsets aside).
 
     python scripts/kernel_isa_diff.py a.so b.so "k_align_pairs<0, 3, false, true, true, 0, false>" [name in b.so, if it differs]
+
+(round 6's last library names the kernels with an eighth template argument -- "k_align_pairs<0, 3, false, true, true, 0, false, false>" --
+and its benchmark kernels differ from round 5's by 80 of 11 176 instructions since the two-items-per-wave twins exist: NOTEBOOK.)
 """
 import difflib
 import os
