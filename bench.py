@@ -442,6 +442,18 @@ def main():
             out["extra"]["config5"] = c5
         except Exception as e:  # noqa: BLE001 -- an extra, never the reason a bench run fails
             out["extra"]["config5"] = {"error": str(e)}
+        try:
+            # a short scan (361 beams: the kernels that score two particles per wave), same swarm, same cells
+            ps_ = synth.make_pairs(B, n_beams=361, seed=2024)
+            gs_ = capi.ScanGeom(ps_.n_beams, float(ps_.angle_min), float(ps_.angle_inc), float(ps_.range_max), 0.1)
+            rs_, ns_ = torch.from_numpy(ps_.ref_ranges).to(dev), torch.from_numpy(ps_.new_ranges).to(dev)
+            ss_ = torch.from_numpy(ps_.seeds.astype(np.int64)).to(dev).to(torch.int32)
+            short = timed(B, mode, 200, gs_, grid, cfg, rs_, ns_, ss_)
+            short["workload"] = "%d pairs per launch, %d x %d, 361 beams, %.2f m cells, %s score, one launch at a time" % (B, P, I, CELL_SIDE, args.score)
+            short["rate_per_point_evaluation_vs_this_run_one_at_a_time"] = (short["alignments_per_s"] * 361.0) / (B / (serial_ms * 1e-3) * float(n_valid.mean()))
+            out["extra"]["short_scans_361_beams"] = short
+        except Exception as e:  # noqa: BLE001
+            out["extra"]["short_scans_361_beams"] = {"error": str(e)}
 
     # the node's live sequence: loadLaser -> align -> update against an accumulating resident map,
     # default 30 x 50 PSO, rand() table from the host as the drop-in library passes it; rank 0 only, 60 scans
