@@ -2355,15 +2355,22 @@ static int launch_pairs(ndtpso_ctx* c, uint32_t n_pairs, const float* d_ref, con
     gate_grid = std::min<uint32_t>(n_pairs, std::max<uint32_t>(8u, 2u * seen));
     if (const char* e = std::getenv("NDTPSO_GATE_GRID")) gate_grid = std::min<uint32_t>(n_pairs, (uint32_t)std::max(1, std::atoi(e)));  // (diagnostics)
   }
-  // Two items per wave (eval_pair_half, k_align_pairs<..., PAIR>): scans of up to nine chunks -- 361 beams + 10-12 %, 541 beams
-  // + 1-5 %, nothing beyond (an evaluation's fixed part is a third of a six-chunk list's time and a tenth of a seventeen-chunk
-  // one's).  NDTPSO_PAIR_ITEMS=0: never.
+  // Two items per wave (eval_pair_half, k_align_pairs<..., PAIR>): short scans with enough particles per wave.  What a pair
+  // saves is around the trips (a third of a six-chunk evaluation, a tenth of a seventeen-chunk one); what it costs is at a
+  // phase's end, where the waves wait for the last of units twice as long -- the fewer items a wave has per phase, the more.
+  // Measured break-even, 8 waves (512 pairs, 0.5 m cells; scripts/pair_items_ab.py): 181 beams any swarm (+ 5-20 %), 361 beams
+  // from 16 particles (+ 6 % there, + 15-21 % from 70), 541 beams from 30 (+ 1 %; + 6-10 % from 70), nothing at 721; fitted as
+  // particles >= (5 (chunks - 3) + 1) waves / 8 for up to nine chunks.  NDTPSO_PAIR_ITEMS=0: never; NDTPSO_PAIR_MAX_BEAMS
+  // (diagnostics): whatever the swarm, up to that many beams.
   const char* pair_env = std::getenv("NDTPSO_PAIR_ITEMS");
-  static const uint32_t pair_max_beams = [] {  // (NDTPSO_PAIR_MAX_BEAMS: diagnostics -- where the two kinds of kernel cross over)
+  static const int pair_max_beams = [] {
     const char* e = std::getenv("NDTPSO_PAIR_MAX_BEAMS");
-    return e ? (uint32_t)std::max(0, std::atoi(e)) : 576u;
+    return e ? std::max(0, std::atoi(e)) : -1;
   }();
-  const bool pair_items = t_plan_force.pair >= 0 ? t_plan_force.pair != 0 : (!(pair_env && pair_env[0] == '0') && geom->n_beams <= pair_max_beams);
+  const int pair_chunks = ((int)geom->n_beams + 63) / 64;
+  const bool pair_pays = pair_max_beams >= 0 ? (int)geom->n_beams <= pair_max_beams
+                                             : (pair_chunks <= 9 && cfg->population * 8 >= (5 * (pair_chunks - 3) + 1) * waves);
+  const bool pair_items = t_plan_force.pair >= 0 ? t_plan_force.pair != 0 : (!(pair_env && pair_env[0] == '0') && pair_pays);
 #define LAUNCH_PAIRS_CANSB(MODE, PATH, CL, ARB, NOCLIP, SWARM, BOX)                                                \
   do {                                                                                                             \
     if (gate == 0 && !redo_list) t_last_launch = launch_code(MODE == kScoreF64, PATH, CL, ARB, NOCLIP, SWARM, BOX, true, pair_items && pair_items_kernel<MODE, PATH, CL, NOCLIP, SWARM, BOX>()); \
